@@ -1,0 +1,569 @@
+// C-ABI of libdinoseg_hip.so (see include/dinoseg.h): handle, weight binding/packing, workspace, and the
+// forward orchestration of the DINOSeg hot path on one MI355X.  Host code only; kernels live in
+// gemm.hip / attention.hip / elementwise.hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dinoseg.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace dseg;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+
+extern "C" void dinoseg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* dinoseg_last_error(void) { return g_err; }
+extern "C" int dinoseg_version(void) { return 100; }
+
+#define DSEG_TRY(expr)            \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ handle
+struct BoundTensor {
+    const float* ptr = nullptr;
+    std::vector<int64_t> shape;
+};
+
+struct PackedLinear {       // W[N,K] operand planes of one nn.Linear, padded to the GEMM tile
+    bf16_t* w = nullptr;
+    long plane = 0;
+    int n_pad = 0, k_pad = 0;
+    float* bias_pad = nullptr;   // only when N was padded (head layers); else the bound bias is used
+};
+
+struct dinoseg_handle {
+    dinoseg_config cfg;
+    int planes;
+    std::map<std::string, BoundTensor> bound;
+    std::map<std::string, std::vector<int64_t>> expected;
+    // packed weights (library-owned)
+    char* wbuf = nullptr;
+    size_t wbuf_bytes = 0;
+    std::map<std::string, PackedLinear> packed;
+    bool weights_ready = false;
+    // pos-embed cache
+    float* pos_cache = nullptr;
+    int pos_r = -1;
+    size_t pos_cap = 0;
+    // activation workspace (library-owned)
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int ws_B = -1, ws_r = -1;
+};
+
+static int head_planes() { return 2; }   // the classifier head always runs in split precision (it is tiny)
+
+static void add_expected(dinoseg_handle* h) {
+    const dinoseg_config& c = h->cfg;
+    const int64_t D = c.embed_dim, F = (int64_t)c.embed_dim * c.mlp_ratio, C = c.n_classes, p = c.patch;
+    auto& e = h->expected;
+    e["dino.cls_token"] = {1, 1, D};
+    e["dino.pos_embed"] = {1, (int64_t)c.pos_grid * c.pos_grid + 1, D};
+    e["dino.patch_embed.proj.weight"] = {D, 3, p, p};
+    e["dino.patch_embed.proj.bias"] = {D};
+    for (int i = 0; i < c.n_blocks; ++i) {
+        const std::string b = "dino.blocks." + std::to_string(i) + ".";
+        e[b + "norm1.weight"] = {D};
+        e[b + "norm1.bias"] = {D};
+        e[b + "attn.qkv.weight"] = {3 * D, D};
+        e[b + "attn.qkv.bias"] = {3 * D};
+        e[b + "attn.proj.weight"] = {D, D};
+        e[b + "attn.proj.bias"] = {D};
+        e[b + "norm2.weight"] = {D};
+        e[b + "norm2.bias"] = {D};
+        e[b + "mlp.fc1.weight"] = {F, D};
+        e[b + "mlp.fc1.bias"] = {F};
+        e[b + "mlp.fc2.weight"] = {D, F};
+        e[b + "mlp.fc2.bias"] = {D};
+    }
+    e["dino.norm.weight"] = {D};
+    e["dino.norm.bias"] = {D};
+    if (c.head_kind == DINOSEG_HEAD_MLP) {
+        e["clf.layer_1.weight"] = {200, D};
+        e["clf.layer_1.bias"] = {200};
+        e["clf.layer_2.weight"] = {100, 200};
+        e["clf.layer_2.bias"] = {100};
+        e["clf.layer_3.weight"] = {C, 100};
+        e["clf.layer_3.bias"] = {C};
+    } else {
+        e["clf.layer_1.weight"] = {C, D};
+        e["clf.layer_1.bias"] = {C};
+    }
+}
+
+extern "C" int dinoseg_create(const dinoseg_config* cfg, dinoseg_handle** out) {
+    if (!cfg || !out) {
+        dinoseg_set_error("dinoseg_create: null argument");
+        return -1;
+    }
+    if (cfg->embed_dim % 128 != 0 || cfg->embed_dim > 1024 || cfg->num_heads * 64 != cfg->embed_dim || cfg->patch != 8 ||
+        cfg->n_blocks < 0 || cfg->n_classes < 1 || cfg->n_classes > 32 || cfg->mlp_ratio < 1 || cfg->pos_grid < 1 ||
+        (cfg->precision != DINOSEG_BF16 && cfg->precision != DINOSEG_BF16X3) ||
+        (cfg->head_kind != DINOSEG_HEAD_MLP && cfg->head_kind != DINOSEG_HEAD_LINEAR)) {
+        dinoseg_set_error("dinoseg_create: unsupported config (embed_dim=%d heads=%d patch=%d blocks=%d classes=%d)",
+                          cfg->embed_dim, cfg->num_heads, cfg->patch, cfg->n_blocks, cfg->n_classes);
+        return -1;
+    }
+    dinoseg_handle* h = new dinoseg_handle();
+    h->cfg = *cfg;
+    h->planes = cfg->precision == DINOSEG_BF16X3 ? 2 : 1;
+    add_expected(h);
+    *out = h;
+    return 0;
+}
+
+extern "C" int dinoseg_destroy(dinoseg_handle* h) {
+    if (!h) return 0;
+    if (h->wbuf) (void)hipFree(h->wbuf);
+    if (h->pos_cache) (void)hipFree(h->pos_cache);
+    if (h->ws) (void)hipFree(h->ws);
+    delete h;
+    return 0;
+}
+
+extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const void* dev_ptr, const int64_t* shape,
+                                   int32_t ndim) {
+    if (!h || !name || !dev_ptr || !shape) {
+        dinoseg_set_error("dinoseg_bind_weight: null argument");
+        return -1;
+    }
+    auto it = h->expected.find(name);
+    if (it == h->expected.end()) {
+        dinoseg_set_error("dinoseg_bind_weight: unexpected key '%s'", name);
+        return -1;
+    }
+    const std::vector<int64_t>& want = it->second;
+    bool ok = (int)want.size() == ndim;
+    for (int i = 0; ok && i < ndim; ++i) ok = want[i] == shape[i];
+    if (!ok) {
+        dinoseg_set_error("dinoseg_bind_weight: shape mismatch for '%s'", name);
+        return -1;
+    }
+    BoundTensor t;
+    t.ptr = reinterpret_cast<const float*>(dev_ptr);
+    t.shape.assign(shape, shape + ndim);
+    h->bound[name] = t;
+    h->weights_ready = false;
+    h->pos_r = -1;
+    return 0;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static const float* W(const dinoseg_handle* h, const std::string& k) { return h->bound.at(k).ptr; }
+
+// names of every nn.Linear-shaped weight that feeds gemm.hip, with its logical [N, K] and padded [n_pad, k_pad]
+struct LinSpec {
+    std::string wname, bname;
+    int N, K, n_pad, k_pad, planes;
+};
+
+static std::vector<LinSpec> linear_specs(const dinoseg_handle* h) {
+    const dinoseg_config& c = h->cfg;
+    const int D = c.embed_dim, F = c.embed_dim * c.mlp_ratio, P = h->planes;
+    std::vector<LinSpec> v;
+    v.push_back({"dino.patch_embed.proj.weight", "dino.patch_embed.proj.bias", D, 3 * c.patch * c.patch, D, 192, P});
+    for (int i = 0; i < c.n_blocks; ++i) {
+        const std::string b = "dino.blocks." + std::to_string(i) + ".";
+        v.push_back({b + "attn.qkv.weight", b + "attn.qkv.bias", 3 * D, D, 3 * D, D, P});
+        v.push_back({b + "attn.proj.weight", b + "attn.proj.bias", D, D, D, D, P});
+        v.push_back({b + "mlp.fc1.weight", b + "mlp.fc1.bias", F, D, F, D, P});
+        v.push_back({b + "mlp.fc2.weight", b + "mlp.fc2.bias", D, F, D, F, P});
+    }
+    if (c.head_kind == DINOSEG_HEAD_MLP) {
+        v.push_back({"clf.layer_1.weight", "clf.layer_1.bias", 200, D, 256, D, head_planes()});
+        v.push_back({"clf.layer_2.weight", "clf.layer_2.bias", 100, 200, 128, 256, head_planes()});
+    }
+    return v;
+}
+
+extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
+    if (!h) return -1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (auto& kv : h->expected)
+        if (!h->bound.count(kv.first)) {
+            dinoseg_set_error("dinoseg_refresh_weights: missing key '%s' (strict load)", kv.first.c_str());
+            return -3;
+        }
+    const std::vector<LinSpec> specs = linear_specs(h);
+    size_t total = 0;
+    for (const LinSpec& sp : specs) {
+        total += align_up((size_t)sp.planes * sp.n_pad * sp.k_pad * sizeof(bf16_t), 256);
+        if (sp.n_pad != sp.N) total += align_up((size_t)sp.n_pad * sizeof(float), 256);
+    }
+    if (total > h->wbuf_bytes) {
+        if (h->wbuf) DSEG_CHECK_HIP(hipFree(h->wbuf));
+        h->wbuf = nullptr;
+        DSEG_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&h->wbuf), total));
+        h->wbuf_bytes = total;
+    }
+    size_t off = 0;
+    for (const LinSpec& sp : specs) {
+        PackedLinear pk;
+        pk.w = reinterpret_cast<bf16_t*>(h->wbuf + off);
+        pk.plane = (long)sp.n_pad * sp.k_pad;
+        pk.n_pad = sp.n_pad;
+        pk.k_pad = sp.k_pad;
+        off += align_up((size_t)sp.planes * sp.n_pad * sp.k_pad * sizeof(bf16_t), 256);
+        DSEG_TRY(launch_pack_planes(W(h, sp.wname), sp.N, sp.K, pk.w, pk.plane, sp.n_pad, sp.k_pad, sp.planes, s));
+        if (sp.n_pad != sp.N) {
+            pk.bias_pad = reinterpret_cast<float*>(h->wbuf + off);
+            off += align_up((size_t)sp.n_pad * sizeof(float), 256);
+            DSEG_CHECK_HIP(hipMemsetAsync(pk.bias_pad, 0, (size_t)sp.n_pad * sizeof(float), s));
+            DSEG_CHECK_HIP(hipMemcpyAsync(pk.bias_pad, W(h, sp.bname), (size_t)sp.N * sizeof(float),
+                                          hipMemcpyDeviceToDevice, s));
+        }
+        h->packed[sp.wname] = pk;
+    }
+    h->weights_ready = true;
+    h->pos_r = -1;   // pos_embed may have changed (fine-tune)
+    return 0;
+}
+
+extern "C" int dinoseg_prepare_resolution(dinoseg_handle* h, int32_t r, void* stream) {
+    if (!h) return -1;
+    if (r <= 0 || r % 8 != 0) {
+        dinoseg_set_error("Resolution should be a multiple of 8.");
+        return -1;
+    }
+    if (!h->bound.count("dino.pos_embed")) {
+        dinoseg_set_error("dinoseg_prepare_resolution: dino.pos_embed not bound");
+        return -3;
+    }
+    if (h->pos_r == r) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int o = r / 8, D = h->cfg.embed_dim;
+    const size_t need = ((size_t)o * o + 1) * D * sizeof(float);
+    if (need > h->pos_cap) {
+        if (h->pos_cache) DSEG_CHECK_HIP(hipFree(h->pos_cache));
+        h->pos_cache = nullptr;
+        DSEG_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&h->pos_cache), need));
+        h->pos_cap = need;
+    }
+    DSEG_TRY(launch_pos_resample(W(h, "dino.pos_embed"), h->cfg.pos_grid, D, o, h->pos_cache, s));
+    h->pos_r = r;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace
+struct WsLayout {
+    size_t X, A, Q, K, VT, CTX, HB, FEAT, H1, H2, total;
+    long a_plane, qkv_plane, ctx_plane, hb_plane, feat_plane, h1_plane, h2_plane;
+    int n, ntok, npad, M, Mp;
+};
+
+static WsLayout make_layout(const dinoseg_handle* h, int B, int r) {
+    const dinoseg_config& c = h->cfg;
+    const int D = c.embed_dim, F = D * c.mlp_ratio, P = h->planes, HP = head_planes();
+    WsLayout L;
+    L.n = (r / 8) * (r / 8);
+    L.ntok = L.n + 1;
+    L.npad = (L.ntok + 63) / 64 * 64;
+    L.M = B * L.ntok;
+    L.Mp = B * L.n;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    L.X = take((size_t)L.M * D * 4);
+    L.a_plane = (long)L.M * D;                 // LN output; also hosts the patch-gather matrix [Mp,192] (smaller)
+    L.A = take((size_t)P * L.a_plane * 2);
+    L.qkv_plane = (long)B * c.num_heads * L.npad * 64;
+    L.Q = take((size_t)P * L.qkv_plane * 2);
+    L.K = take((size_t)P * L.qkv_plane * 2);
+    L.VT = take((size_t)P * L.qkv_plane * 2);
+    L.ctx_plane = (long)L.M * D;
+    L.CTX = take((size_t)P * L.ctx_plane * 2);
+    L.hb_plane = (long)L.M * F;
+    L.HB = take((size_t)P * L.hb_plane * 2);
+    L.feat_plane = (long)L.Mp * D;
+    L.FEAT = take((size_t)HP * L.feat_plane * 2);
+    L.h1_plane = (long)L.Mp * 256;
+    L.H1 = take((size_t)HP * L.h1_plane * 2);
+    L.h2_plane = (long)L.Mp * 128;
+    L.H2 = take((size_t)HP * L.h2_plane * 2);
+    L.total = off;
+    return L;
+}
+
+extern "C" int64_t dinoseg_workspace_bytes(const dinoseg_handle* h, int32_t B, int32_t r) {
+    if (!h || B <= 0 || r <= 0 || r % 8 != 0) return -1;
+    return (int64_t)(make_layout(h, B, r).total + h->wbuf_bytes);
+}
+
+static int ensure_workspace(dinoseg_handle* h, const WsLayout& L, int B, int r, hipStream_t s) {
+    if (L.total > h->ws_bytes) {
+        if (h->ws) {
+            DSEG_CHECK_HIP(hipStreamSynchronize(s));
+            DSEG_CHECK_HIP(hipFree(h->ws));
+        }
+        h->ws = nullptr;
+        h->ws_bytes = 0;
+        DSEG_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&h->ws), L.total));
+        h->ws_bytes = L.total;
+        h->ws_B = -1;
+    }
+    if (h->ws_B != B || h->ws_r != r) {
+        // key/value pad rows beyond ntok must be finite: zero Q/K/V^T once per layout (never written afterwards)
+        DSEG_CHECK_HIP(hipMemsetAsync(h->ws + L.Q, 0, L.CTX - L.Q, s));
+        h->ws_B = B;
+        h->ws_r = r;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+static const float kImagenetMean[3] = {0.485f, 0.456f, 0.406f};
+static const float kImagenetStd[3] = {0.229f, 0.224f, 0.225f};
+
+static void norm_consts(float mean255[3], float inv255[3]) {
+    for (int c = 0; c < 3; ++c) {
+        mean255[c] = kImagenetMean[c] * 255.0f;          // albumentations: mean * max_pixel_value (fp32)
+        inv255[c] = 1.0f / (kImagenetStd[c] * 255.0f);   // reciprocal of std * max_pixel_value (fp32)
+    }
+}
+
+extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
+                               int32_t* argmax_out, int32_t tap_block, float* tap_out, void* stream) {
+    if (!h || !x || B <= 0) {
+        dinoseg_set_error("dinoseg_forward: bad argument");
+        return -1;
+    }
+    if (r <= 0 || r % 8 != 0) {
+        dinoseg_set_error("Resolution should be a multiple of 8.");
+        return -1;
+    }
+    if (x_kind != DINOSEG_INPUT_U8_HWC && x_kind != DINOSEG_INPUT_F32_CHW) {
+        dinoseg_set_error("dinoseg_forward: bad x_kind %d", x_kind);
+        return -1;
+    }
+    if (!h->weights_ready) {
+        dinoseg_set_error("dinoseg_forward: weights not packed (call dinoseg_refresh_weights after binding)");
+        return -3;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DSEG_TRY(dinoseg_prepare_resolution(h, r, stream));
+
+    const dinoseg_config& c = h->cfg;
+    const int D = c.embed_dim, F = D * c.mlp_ratio, P = h->planes, HP = head_planes(), H = c.num_heads;
+    const WsLayout L = make_layout(h, B, r);
+    DSEG_TRY(ensure_workspace(h, L, B, r, s));
+    char* ws = h->ws;
+    float* X = reinterpret_cast<float*>(ws + L.X);
+    bf16_t* A = reinterpret_cast<bf16_t*>(ws + L.A);
+    bf16_t* Q = reinterpret_cast<bf16_t*>(ws + L.Q);
+    bf16_t* Kb = reinterpret_cast<bf16_t*>(ws + L.K);
+    bf16_t* VT = reinterpret_cast<bf16_t*>(ws + L.VT);
+    bf16_t* CTX = reinterpret_cast<bf16_t*>(ws + L.CTX);
+    bf16_t* HB = reinterpret_cast<bf16_t*>(ws + L.HB);
+    bf16_t* FEAT = reinterpret_cast<bf16_t*>(ws + L.FEAT);
+    bf16_t* H1 = reinterpret_cast<bf16_t*>(ws + L.H1);
+    bf16_t* H2 = reinterpret_cast<bf16_t*>(ws + L.H2);
+
+    // ---- prepare_tokens (vision_transformer.py:224-235) ----
+    float mean255[3], inv255[3];
+    norm_consts(mean255, inv255);
+    const long pg_plane = (long)L.Mp * 192;
+    DSEG_TRY(launch_patch_gather(x, x_kind, B, r, mean255, inv255, A, pg_plane, P, s));
+    {
+        const PackedLinear& pk = h->packed.at("dino.patch_embed.proj.weight");
+        GemmParams g = {};
+        g.A = A; g.a_plane = pg_plane; g.lda = 192;
+        g.W = pk.w; g.w_plane = pk.plane;
+        g.M = L.Mp; g.N = D; g.K = 192; g.planes = P; g.epi = EPI_PATCH;
+        g.bias = W(h, "dino.patch_embed.proj.bias");
+        g.out_f32 = X; g.ldo_f32 = D;
+        g.pos = h->pos_cache; g.n_patches = L.n;
+        DSEG_TRY(launch_gemm(g, s));
+    }
+    DSEG_TRY(launch_cls_rows(X, W(h, "dino.cls_token"), h->pos_cache, B, L.ntok, D, s));
+    const size_t xbytes = (size_t)L.M * D * sizeof(float);
+    if (tap_block == 0 && tap_out) DSEG_CHECK_HIP(hipMemcpyAsync(tap_out, X, xbytes, hipMemcpyDeviceToDevice, s));
+
+    const float qscale = 0.125f * 1.44269504088896340736f;   // head_dim^-0.5 (vision_transformer.py:73) * log2(e)
+
+    // ---- transformer blocks (vision_transformer.py:122-140) ----
+    for (int i = 0; i < c.n_blocks; ++i) {
+        const std::string b = "dino.blocks." + std::to_string(i) + ".";
+        DSEG_TRY(launch_layernorm(X, W(h, b + "norm1.weight"), W(h, b + "norm1.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
+                                  nullptr, 0, L.ntok, s));
+        {
+            const PackedLinear& pk = h->packed.at(b + "attn.qkv.weight");
+            GemmParams g = {};
+            g.A = A; g.a_plane = L.a_plane; g.lda = D;
+            g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.M; g.N = 3 * D; g.K = D; g.planes = P; g.epi = EPI_QKV;
+            g.bias = W(h, b + "attn.qkv.bias");
+            g.q = Q; g.k = Kb; g.vt = VT; g.qkv_plane = L.qkv_plane;
+            g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+        {
+            AttnParams a = {};
+            a.q = Q; a.k = Kb; a.vt = VT; a.qkv_plane = L.qkv_plane;
+            a.ctx = CTX; a.ctx_plane = L.ctx_plane; a.lse = nullptr;
+            a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P;
+            DSEG_TRY(launch_attention(a, s));
+        }
+        {
+            const PackedLinear& pk = h->packed.at(b + "attn.proj.weight");
+            GemmParams g = {};
+            g.A = CTX; g.a_plane = L.ctx_plane; g.lda = D;
+            g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.M; g.N = D; g.K = D; g.planes = P; g.epi = EPI_RESID;
+            g.bias = W(h, b + "attn.proj.bias");
+            g.out_f32 = X; g.ldo_f32 = D;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+        DSEG_TRY(launch_layernorm(X, W(h, b + "norm2.weight"), W(h, b + "norm2.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
+                                  nullptr, 0, L.ntok, s));
+        {
+            const PackedLinear& pk = h->packed.at(b + "mlp.fc1.weight");
+            GemmParams g = {};
+            g.A = A; g.a_plane = L.a_plane; g.lda = D;
+            g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.M; g.N = F; g.K = D; g.planes = P; g.epi = EPI_GELU;
+            g.bias = W(h, b + "mlp.fc1.bias");
+            g.out_bf16 = HB; g.out_plane = L.hb_plane; g.ldo = F;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+        {
+            const PackedLinear& pk = h->packed.at(b + "mlp.fc2.weight");
+            GemmParams g = {};
+            g.A = HB; g.a_plane = L.hb_plane; g.lda = F;
+            g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.M; g.N = D; g.K = F; g.planes = P; g.epi = EPI_RESID;
+            g.bias = W(h, b + "mlp.fc2.bias");
+            g.out_f32 = X; g.ldo_f32 = D;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+        if (tap_block == i + 1 && tap_out) DSEG_CHECK_HIP(hipMemcpyAsync(tap_out, X, xbytes, hipMemcpyDeviceToDevice, s));
+    }
+
+    // ---- final norm, drop CLS (vision_transformer.py:243; pl_torch_modules.py:243,253) ----
+    DSEG_TRY(launch_layernorm(X, W(h, "dino.norm.weight"), W(h, "dino.norm.bias"), c.ln_eps, L.M, D, FEAT, L.feat_plane,
+                              HP, nullptr, 1, L.ntok, s));
+
+    // ---- segmentation head (pl_torch_modules.py:108-138), always in split precision ----
+    if (c.head_kind == DINOSEG_HEAD_MLP) {
+        {
+            const PackedLinear& pk = h->packed.at("clf.layer_1.weight");
+            GemmParams g = {};
+            g.A = FEAT; g.a_plane = L.feat_plane; g.lda = D;
+            g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.Mp; g.N = 256; g.K = D; g.planes = HP; g.epi = EPI_RELU;
+            g.bias = pk.bias_pad;
+            g.out_bf16 = H1; g.out_plane = L.h1_plane; g.ldo = 256;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+        {
+            const PackedLinear& pk = h->packed.at("clf.layer_2.weight");
+            GemmParams g = {};
+            g.A = H1; g.a_plane = L.h1_plane; g.lda = 256;
+            g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.Mp; g.N = 128; g.K = 256; g.planes = HP; g.epi = EPI_RELU;
+            g.bias = pk.bias_pad;
+            g.out_bf16 = H2; g.out_plane = L.h2_plane; g.ldo = 128;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+        DSEG_TRY(launch_head_final(H2, L.h2_plane, 128, L.Mp, 100, W(h, "clf.layer_3.weight"), W(h, "clf.layer_3.bias"),
+                                   c.n_classes, logp_out ? logp_out : reinterpret_cast<float*>(ws + L.HB), argmax_out, s));
+    } else {
+        DSEG_TRY(launch_head_final(FEAT, L.feat_plane, D, L.Mp, D, W(h, "clf.layer_1.weight"), W(h, "clf.layer_1.bias"),
+                                   c.n_classes, logp_out ? logp_out : reinterpret_cast<float*>(ws + L.HB), argmax_out, s));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ stand-alone ops
+extern "C" int dinoseg_op_pack(const float* src, int32_t rows, int32_t cols, void* dst, int64_t plane_stride,
+                               int32_t rows_pad, int32_t cols_pad, int32_t planes, void* stream) {
+    return launch_pack_planes(src, rows, cols, reinterpret_cast<bf16_t*>(dst), plane_stride, rows_pad, cols_pad, planes,
+                              reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_gemm(const void* A, int64_t a_plane, int32_t lda, const void* Wp, int64_t w_plane, int32_t M,
+                               int32_t N, int32_t K, int32_t planes, int32_t epi, const float* bias, float* out_f32,
+                               void* out_bf16, int64_t out_plane, int32_t ldo, void* stream) {
+    if (epi < EPI_PLAIN || epi > EPI_RELU) {
+        dinoseg_set_error("dinoseg_op_gemm: epi must be 0..3");
+        return -1;
+    }
+    GemmParams g = {};
+    g.A = reinterpret_cast<const bf16_t*>(A); g.a_plane = a_plane; g.lda = lda;
+    g.W = reinterpret_cast<const bf16_t*>(Wp); g.w_plane = w_plane;
+    g.M = M; g.N = N; g.K = K; g.planes = planes; g.epi = epi; g.bias = bias;
+    g.out_f32 = out_f32; g.ldo_f32 = N;
+    g.out_bf16 = reinterpret_cast<bf16_t*>(out_bf16); g.out_plane = out_plane; g.ldo = ldo;
+    return launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_qkv_gemm(const void* A, int64_t a_plane, const void* Wp, int64_t w_plane, const float* bias,
+                                   int32_t B, int32_t ntok, int32_t npad, int32_t heads, int32_t planes, float qscale,
+                                   void* q, void* k, void* vt, int64_t qkv_plane, void* stream) {
+    GemmParams g = {};
+    const int D = heads * 64;
+    g.A = reinterpret_cast<const bf16_t*>(A); g.a_plane = a_plane; g.lda = D;
+    g.W = reinterpret_cast<const bf16_t*>(Wp); g.w_plane = w_plane;
+    g.M = B * ntok; g.N = 3 * D; g.K = D; g.planes = planes; g.epi = EPI_QKV; g.bias = bias;
+    g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.vt = reinterpret_cast<bf16_t*>(vt);
+    g.qkv_plane = qkv_plane; g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = D; g.qscale = qscale;
+    return launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_attention(const void* q, const void* k, const void* vt, int64_t qkv_plane, void* ctx,
+                                    int64_t ctx_plane, float* lse, int32_t B, int32_t heads, int32_t ntok, int32_t npad,
+                                    int32_t planes, void* stream) {
+    AttnParams a = {};
+    a.q = reinterpret_cast<const bf16_t*>(q); a.k = reinterpret_cast<const bf16_t*>(k);
+    a.vt = reinterpret_cast<const bf16_t*>(vt); a.qkv_plane = qkv_plane;
+    a.ctx = reinterpret_cast<bf16_t*>(ctx); a.ctx_plane = ctx_plane; a.lse = lse;
+    a.B = B; a.heads = heads; a.ntok = ntok; a.npad = npad; a.planes = planes;
+    return launch_attention(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int32_t M, int32_t D,
+                                    void* out_bf16, int64_t out_plane, int32_t planes, float* out_f32, int32_t drop_cls,
+                                    int32_t ntok, void* stream) {
+    return launch_layernorm(x, gamma, beta, eps, M, D, reinterpret_cast<bf16_t*>(out_bf16), out_plane, planes, out_f32,
+                            drop_cls, ntok, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_pos_resample(const float* pos_embed, int32_t g, int32_t D, int32_t o, float* out, void* stream) {
+    return launch_pos_resample(pos_embed, g, D, o, out, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_patch_gather(const void* x, int32_t x_kind, int32_t B, int32_t r, void* out, int64_t out_plane,
+                                       int32_t planes, void* stream) {
+    if (r <= 0 || r % 8 != 0) {
+        dinoseg_set_error("Resolution should be a multiple of 8.");
+        return -1;
+    }
+    float mean255[3], inv255[3];
+    norm_consts(mean255, inv255);
+    return launch_patch_gather(x, x_kind, B, r, mean255, inv255, reinterpret_cast<bf16_t*>(out), out_plane, planes,
+                               reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_head_final(const void* in, int64_t in_plane, int32_t ld, int32_t M, int32_t K, const float* Wc,
+                                     const float* b, int32_t C, float* logp, int32_t* argmax, void* stream) {
+    return launch_head_final(reinterpret_cast<const bf16_t*>(in), in_plane, ld, M, K, Wc, b, C, logp, argmax,
+                             reinterpret_cast<hipStream_t>(stream));
+}

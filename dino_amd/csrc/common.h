@@ -1,0 +1,89 @@
+// Shared device helpers for the dinoseg HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dseg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+typedef uint16_t bf16_t;   // storage type of a bf16 element in HBM / LDS
+
+constexpr int WAVE = 64;
+
+// ---- bf16 conversion (round-to-nearest-even; hipcc emits v_cvt_pk_bf16_f32) ----
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
+__device__ __forceinline__ float bf16_hi_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed & 0xFFFF0000u); }
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+
+// hi/lo split of two floats: hi = bf16(x), lo = bf16(x - hi).  hi + lo carries ~16 mantissa bits.
+__device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf16x2(a, b);
+    lo = pack_bf16x2(a - bf16_lo_to_f32(hi), b - bf16_hi_to_f32(hi));
+}
+
+// ---- 128-byte-row LDS tile swizzle -------------------------------------------------
+// A tile is [rows][64 bf16] = 128-B rows, i.e. 8 chunks of 16 B per row.  ds_read_b128 is
+// served in 16-lane groups over a 256-B bank row; reading the same logical chunk of 16
+// different rows would hit only 2 of 16 slots.  XOR the chunk index with (row>>1)&7:
+// the 16 rows of every lane group then land on 16 distinct slots (conflict-free) for both
+// the 32x32x16 fragment pattern (row = lane&31) used here.
+// The image is filled by LDS-DMA (global_load_lds, lane-linear destination), so the
+// permutation is applied to the per-lane SOURCE address and again on the read.
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+__device__ __forceinline__ int tile_off_bytes(int row, int chunk) { return row * 128 + (swz_chunk(row, chunk) << 4); }
+
+// async 16-byte global -> LDS copy (LDS-DMA). lds_wave_base must be wave-uniform;
+// lane i's 16 bytes land at lds_wave_base + 16*i.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* p) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
+}
+
+// 32x32 accumulator: register r of lane (col = lane&31, h = lane>>5) is row (r&3) + 8*(r>>2) + 4*h.
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch, speed only).
+// Gives every XCD a contiguous range of logical ids; bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+}  // namespace dseg
+
+// ---- host-side error plumbing shared by all translation units ----
+extern "C" void dinoseg_set_error(const char* fmt, ...);
+#define DSEG_CHECK_HIP(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            dinoseg_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -2;                                                                        \
+        }                                                                                     \
+    } while (0)

@@ -1,0 +1,335 @@
+// HBM-bound helper kernels of the DINOSeg path (gfx950): operand packing, LayerNorm, patch gather,
+// CLS rows, pos-embed bicubic resample, classifier tail.  All are coalesced row kernels; reductions
+// use 64-lane wavefront shuffles.
+#include "common.h"
+#include "kernels.h"
+
+namespace dseg {
+
+// ------------------------------------------------------------------------------------------------
+// fp32 [rows, cols] -> bf16 hi(/lo) planes [planes][rows_pad][cols_pad], zero padded.
+// Used once per weight refresh (nn.Linear weights are [out, in] = the W[N,K] operand of gemm.hip).
+__global__ void pack_planes_kernel(const float* __restrict__ src, int rows, int cols, bf16_t* __restrict__ dst,
+                                   long plane, int rows_pad, int cols_pad, int planes) {
+    const long total = (long)rows_pad * cols_pad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols_pad), c = (int)(i - (long)r * cols_pad);
+        const float v = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+        const uint32_t hi = pack_bf16x2(v, 0.f);
+        dst[i] = (bf16_t)(hi & 0xFFFF);
+        if (planes == 2) dst[plane + i] = (bf16_t)(pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
+    }
+}
+
+int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,
+                       int planes, hipStream_t s) {
+    const long total = (long)rows_pad * cols_pad;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(pack_planes_kernel, dim3(grid), dim3(256), 0, s, src, rows, cols, dst, plane, rows_pad, cols_pad, planes);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (nn.LayerNorm(D, eps=1e-6): vision_transformer.py:303; uses :114,:118,:183).
+// One wavefront per row; the row lives in registers (D/128 float2 per lane); mean, then the biased variance
+// of the centred values (same two-pass arithmetic as the oracle), reductions by wavefront shuffles.
+template <int NV>   // D = 128 * NV
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, int M,
+                                                        bf16_t* __restrict__ out, long out_plane, int planes,
+                                                        float* __restrict__ out_f32, int drop_cls, int ntok) {
+    constexpr int D = 128 * NV;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nw = gridDim.x * 4;
+    f32x2 g[NV], bta[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g[i] = *reinterpret_cast<const f32x2*>(gamma + i * 128 + lane * 2);
+        bta[i] = *reinterpret_cast<const f32x2*>(beta + i * 128 + lane * 2);
+    }
+    for (int m = wid; m < M; m += nw) {
+        long orow = m;
+        if (drop_cls) {
+            const int b = m / ntok, t = m - b * ntok;
+            if (t == 0) continue;
+            orow = (long)b * (ntok - 1) + t - 1;
+        }
+        const float* xr = x + (long)m * D;
+        f32x2 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = *reinterpret_cast<const f32x2*>(xr + i * 128 + lane * 2);
+            s += v[i][0] + v[i][1];
+        }
+        const float mean = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i][0] -= mean;
+            v[i][1] -= mean;
+            q += v[i][0] * v[i][0] + v[i][1] * v[i][1];
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float y0 = v[i][0] * rstd * g[i][0] + bta[i][0];
+            const float y1 = v[i][1] * rstd * g[i][1] + bta[i][1];
+            const long o = orow * D + i * 128 + lane * 2;
+            if (out_f32) {
+                f32x2 y = {y0, y1};
+                *reinterpret_cast<f32x2*>(out_f32 + o) = y;
+            }
+            if (out) {
+                uint32_t hi, lo;
+                split_bf16x2(y0, y1, hi, lo);
+                *reinterpret_cast<uint32_t*>(out + o) = hi;
+                if (planes == 2) *reinterpret_cast<uint32_t*>(out + out_plane + o) = lo;
+            }
+        }
+    }
+}
+
+int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, int M, int D, bf16_t* out,
+                     long out_plane, int planes, float* out_f32, int drop_cls, int ntok, hipStream_t s) {
+    if (M <= 0) return 0;
+    if (D % 128 != 0 || D > 1024) {
+        dinoseg_set_error("layernorm: D=%d must be a multiple of 128 and <= 1024", D);
+        return -1;
+    }
+    int grid = (M + 3) / 4;
+    if (grid > 4096) grid = 4096;
+#define DSEG_LN(NV)                                                                                              \
+    case NV:                                                                                                     \
+        hipLaunchKernelGGL((layernorm_kernel<NV>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, M, out,    \
+                           out_plane, planes, out_f32, drop_cls, ntok);                                          \
+        break;
+    switch (D / 128) {
+        DSEG_LN(1) DSEG_LN(2) DSEG_LN(3) DSEG_LN(4) DSEG_LN(5) DSEG_LN(6) DSEG_LN(7) DSEG_LN(8)
+    }
+#undef DSEG_LN
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Patch gather for Conv2d(3, D, kernel 8, stride 8) as a GEMM (vision_transformer.py:153,157):
+// out[b*n + py*o + px][c*64 + ky*8 + kx] = pixel(b, c, py*8+ky, px*8+kx).
+// kind 0: uint8 HWC frames, with albumentations' Normalize fused: (u8 - 255*mean[c]) * (1 / (255*std[c]))
+//         (pl_torch_modules.py:37) -- frames stay uint8 on the wire (691 KB instead of 2.76 MB @480).
+// kind 1: fp32 CHW tensor as handed to DINOSeg.forward (pl_torch_modules.py:239).
+__global__ __launch_bounds__(256) void patch_gather_kernel(const void* __restrict__ xin, int kind, int B, int r,
+                                                           f32x4 mean255, f32x4 inv255, bf16_t* __restrict__ out,
+                                                           long out_plane, int planes) {
+    const int o = r >> 3;
+    const long total = (long)B * o * o * 8;   // one work item = (patch, ky): 8 pixels x 3 channels
+    for (long w = (long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long)gridDim.x * blockDim.x) {
+        const int ky = (int)(w & 7);
+        const long patch = w >> 3;
+        const int px = (int)(patch % o);
+        const int py = (int)((patch / o) % o);
+        const int b = (int)(patch / ((long)o * o));
+        float v[3][8];
+        if (kind == 0) {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(xin) + (((long)b * r + py * 8 + ky) * r + px * 8) * 3;
+            uint32_t raw[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) raw[i] = reinterpret_cast<const uint32_t*>(src)[i];   // 24 B, 8-byte aligned
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int byte = kx * 3 + c;
+                    const float u = (float)((raw[byte >> 2] >> ((byte & 3) * 8)) & 0xFF);
+                    v[c][kx] = (u - mean255[c]) * inv255[c];
+                }
+        } else {
+            const float* src = reinterpret_cast<const float*>(xin);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* s = src + (((long)b * 3 + c) * r + py * 8 + ky) * r + px * 8;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(s), bq = *reinterpret_cast<const f32x4*>(s + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[c][e] = a[e];
+                    v[c][4 + e] = bq[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            uint4 hi, lo;
+            split_bf16x2(v[c][0], v[c][1], hi.x, lo.x);
+            split_bf16x2(v[c][2], v[c][3], hi.y, lo.y);
+            split_bf16x2(v[c][4], v[c][5], hi.z, lo.z);
+            split_bf16x2(v[c][6], v[c][7], hi.w, lo.w);
+            bf16_t* dst = out + patch * 192 + c * 64 + ky * 8;
+            *reinterpret_cast<uint4*>(dst) = hi;
+            if (planes == 2) *reinterpret_cast<uint4*>(dst + out_plane) = lo;
+        }
+    }
+}
+
+int launch_patch_gather(const void* x, int kind, int B, int r, const float* mean255, const float* inv_std255,
+                        bf16_t* out, long out_plane, int planes, hipStream_t s) {
+    const long total = (long)B * (r / 8) * (r / 8) * 8;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    f32x4 m = {mean255[0], mean255[1], mean255[2], 0.f}, iv = {inv_std255[0], inv_std255[1], inv_std255[2], 0.f};
+    hipLaunchKernelGGL(patch_gather_kernel, dim3(grid), dim3(256), 0, s, x, kind, B, r, m, iv, out, out_plane, planes);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CLS rows: X[b*ntok, :] = cls_token + pos[0]   (vision_transformer.py:229-233)
+__global__ void cls_rows_kernel(float* __restrict__ X, const float* __restrict__ cls, const float* __restrict__ pos,
+                                int B, int ntok, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i - b * D;
+    X[(long)b * ntok * D + d] = cls[d] + pos[d];
+}
+
+int launch_cls_rows(float* X, const float* cls, const float* pos, int B, int ntok, int D, hipStream_t s) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, X, cls, pos, B, ntok, D);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pos-embed resample (vision_transformer.py:202-222): bicubic, A = -0.75, align_corners=False, source
+// coordinate (dst + 0.5) * (g / (o + 0.1)) - 0.5 (torch uses the GIVEN scale factor), taps clamped to the
+// border.  Parameter-only: run once per resolution and cached by the caller.  out: [o*o + 1, D], row 0 = class pos.
+__device__ __forceinline__ void cubic_w(float t, float w[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+__global__ void pos_resample_kernel(const float* __restrict__ pe, int g, int D, int o, float scale,
+                                    float* __restrict__ out) {
+    const long total = ((long)o * o + 1) * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const long tokn = i / D;
+        if (tokn == 0) {
+            out[i] = pe[d];
+            continue;
+        }
+        const int y = (int)((tokn - 1) / o), x = (int)((tokn - 1) % o);
+        const float sy = (y + 0.5f) * scale - 0.5f, sx = (x + 0.5f) * scale - 0.5f;
+        const float fy = floorf(sy), fx = floorf(sx);
+        float wy[4], wx[4];
+        cubic_w(sy - fy, wy);
+        cubic_w(sx - fx, wx);
+        const int iy = (int)fy, ix = (int)fx;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int yy = iy - 1 + a;
+            yy = yy < 0 ? 0 : (yy > g - 1 ? g - 1 : yy);
+            float row = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int xx = ix - 1 + c;
+                xx = xx < 0 ? 0 : (xx > g - 1 ? g - 1 : xx);
+                row += pe[(1 + (long)yy * g + xx) * D + d] * wx[c];
+            }
+            acc += row * wy[a];
+        }
+        out[i] = acc;
+    }
+}
+
+int launch_pos_resample(const float* pos_embed, int g, int D, int o, float* out, hipStream_t s) {
+    const long total = ((long)o * o + 1) * D;
+    if (o == g) {   // the reference returns the stored pos_embed untouched (vision_transformer.py:205-206)
+        DSEG_CHECK_HIP(hipMemcpyAsync(out, pos_embed, (size_t)total * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    // torch: scale_factor = (o + 0.1) / g in double; ATen uses (float)(1.0 / scale_factor) for source coordinates
+    const float scale = (float)(1.0 / (((double)o + 0.1) / (double)g));
+    hipLaunchKernelGGL(pos_resample_kernel, dim3(grid), dim3(256), 0, s, pos_embed, g, D, o, scale, out);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Classifier tail: last Linear (K -> C) + log_softmax(dim=1) + argmax (pl_torch_modules.py:122-123, :294).
+// One thread per patch row; the hi+lo input planes are recombined to fp32; W (<= 32 x K fp32) is read through
+// wave-uniform (scalar) loads.  argmax keeps the first maximum, as torch.argmax does.
+template <int CMAX>
+__global__ __launch_bounds__(256) void head_final_kernel(const bf16_t* __restrict__ in, long in_plane, int ld, int M,
+                                                         int K, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, int C,
+                                                         float* __restrict__ logp, int32_t* __restrict__ amax) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float z[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) z[c] = c < C ? bias[c] : -INFINITY;
+    const bf16_t* hi = in + (long)m * ld;
+    const bf16_t* lo = hi + in_plane;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        const uint4 h = *reinterpret_cast<const uint4*>(hi + k0), l = *reinterpret_cast<const uint4*>(lo + k0);
+        const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+        float xv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xv[2 * e] = bf16_lo_to_f32(hw[e]) + bf16_lo_to_f32(lw[e]);
+            xv[2 * e + 1] = bf16_hi_to_f32(hw[e]) + bf16_hi_to_f32(lw[e]);
+        }
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k0 + e < K) z[c] = fmaf(xv[e], W[c * K + k0 + e], z[c]);
+            }
+        }
+    }
+    float mx = z[0];
+    int am = 0;
+#pragma unroll
+    for (int c = 1; c < CMAX; ++c)
+        if (c < C && z[c] > mx) {
+            mx = z[c];
+            am = c;
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) sum += expf(z[c] - mx);
+    const float lse = logf(sum);
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) logp[(long)m * C + c] = (z[c] - mx) - lse;
+    if (amax) amax[m] = am;
+}
+
+int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, const float* W, const float* b, int C,
+                      float* logp, int32_t* argmax, hipStream_t s) {
+    if (M <= 0) return 0;
+    if (C < 1 || C > 32 || ld % 8 != 0) {
+        dinoseg_set_error("head_final: need 1 <= C <= 32 and ld %% 8 == 0 (C=%d ld=%d)", C, ld);
+        return -1;
+    }
+    const int grid = (M + 255) / 256;
+    if (C <= 8)
+        hipLaunchKernelGGL((head_final_kernel<8>), dim3(grid), dim3(256), 0, s, in, in_plane, ld, M, K, W, b, C, logp, argmax);
+    else
+        hipLaunchKernelGGL((head_final_kernel<32>), dim3(grid), dim3(256), 0, s, in, in_plane, ld, M, K, W, b, C, logp, argmax);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dseg

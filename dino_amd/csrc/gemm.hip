@@ -1,0 +1,227 @@
+// MFMA GEMM for the DINOSeg linear layers:  C[M,N] = A[M,K] . W[N,K]^T  (+ fused epilogues).
+//
+// Replaces the reference's aten::addmm dispatches: attn.qkv (vision_transformer.py:75,82),
+// attn.proj (:105) + residual (:134), mlp.fc1 + GELU (:60-61), mlp.fc2 (:63) + residual (:135), the patch-embed
+// conv as a GEMM (:153,157) and the first two head layers (pl_torch_modules.py:118-121).
+//
+// Structure (gfx950): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave 64x64 =
+// 2x2 v_mfma_f32_32x32x16_bf16 accumulators.  BK = 64: A and W k-slabs are [128][64] bf16 = 128-byte rows,
+// filled by LDS-DMA (global_load_lds 16 B/lane) into a double-buffered, XOR-swizzled image (common.h) and read
+// with conflict-free ds_read_b128.  PLANES = 2 is the parity mode: every operand is a bf16 hi+lo pair and each
+// product is 3 MFMAs (hi*hi + hi*lo + lo*hi), ~16 mantissa bits with fp32 accumulation.
+// The accumulators are staged through LDS once so every epilogue writes whole rows (coalesced).
+#include "common.h"
+#include "kernels.h"
+
+namespace dseg {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 128;   // one [128][64] bf16 slab
+
+template <int PLANES, int EPI>
+__global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE_BYTES = PLANES * 2 * TILE_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order: the nbn column tiles of one row panel run back-to-back on one XCD (A panel L2 reuse).
+    const int nbn = p.N / BN, nbm = (p.M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bm = (slot / nbn) * 8 + xcd, bn = slot % nbn;
+    if (bm >= nbm) return;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int M = p.M, K = p.K;
+
+    auto stage = [&](int st, int kt) {
+        char* sbase = smem + st * STAGE_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int piece = wave * 4 + i;            // 1-KiB piece = 8 rows
+                const int row = piece * 8 + (lane >> 3);
+                const int c = swz_chunk(row, lane & 7);    // logical chunk that lives in physical slot lane&7
+                int gm = m0 + row;
+                gm = gm < M ? gm : M - 1;
+                const bf16_t* srcA = p.A + pl * p.a_plane + (long)gm * p.lda + kt * BK + c * 8;
+                glds16(srcA, sbase + (pl * 2 + 0) * TILE_BYTES + piece * 1024);
+                const bf16_t* srcW = p.W + pl * p.w_plane + (long)(n0 + row) * K + kt * BK + c * 8;
+                glds16(srcW, sbase + (pl * 2 + 1) * TILE_BYTES + piece * 1024);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sb = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[PLANES][2], b[PLANES][2];
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[pl][i] = lds_frag(sb + (pl * 2 + 0) * TILE_BYTES + tile_off_bytes(wr * 64 + i * 32 + lr, kk * 2 + lh));
+                    b[pl][i] = lds_frag(sb + (pl * 2 + 1) * TILE_BYTES + tile_off_bytes(wc * 64 + i * 32 + lr, kk * 2 + lh));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (PLANES == 2) {
+                        acc[i][j] = mfma32(a[1][i], b[0][j], acc[i][j]);
+                        acc[i][j] = mfma32(a[0][i], b[1][j], acc[i][j]);
+                    }
+                    acc[i][j] = mfma32(a[0][i], b[0][j], acc[i][j]);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- stage accumulators through LDS: C[128][128] fp32 (64 KiB) ----
+    float* C = reinterpret_cast<float*>(smem);
+    const bool vpath = (EPI == EPI_QKV) && (n0 / p.dmodel == 2);   // block-uniform: this tile belongs to V
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * 64 + i * 32 + acc_row(r, lh);
+                int col = wc * 64 + j * 32 + lr;
+                if (vpath) col ^= (row & 31);   // conflict-free transposed read below
+                C[row * 128 + col] = acc[i][j][r];
+            }
+    __syncthreads();
+
+    if (EPI == EPI_QKV && vpath) {
+        // V^T[b][head][d][tok]: consecutive threads -> consecutive tokens (coalesced 2-byte stores)
+        const int row = tid & 127, cg = tid >> 7;
+        const int gm = m0 + row;
+        if (gm < M) {
+            const int b = gm / p.ntok, tok = gm - b * p.ntok;
+            const int hcol0 = n0 % p.dmodel + cg * 64;      // a 64-column group is exactly one head
+            const int head = hcol0 >> 6;
+            bf16_t* dst = p.vt + ((long)(b * p.heads + head) * 64) * p.npad + tok;
+#pragma unroll 8
+            for (int d = 0; d < 64; ++d) {
+                const int col = cg * 64 + d;
+                const float v = C[row * 128 + (col ^ (row & 31))] + p.bias[n0 + col];
+                const uint32_t hi = pack_bf16x2(v, 0.f);
+                dst[(long)d * p.npad] = (bf16_t)(hi & 0xFFFF);
+                if (PLANES == 2) {
+                    const uint32_t lo = pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f);
+                    dst[p.qkv_plane + (long)d * p.npad] = (bf16_t)(lo & 0xFFFF);
+                }
+            }
+        }
+        return;
+    }
+
+    const int c4 = tid & 31, rb = tid >> 5;
+    const int gn = n0 + c4 * 4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + gn);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 8 + rb;
+        const int gm = m0 + row;
+        if (gm >= M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(C + row * 128 + c4 * 4);
+        v += bias4;
+        if (EPI == EPI_PLAIN) {
+            *reinterpret_cast<f32x4*>(p.out_f32 + (long)gm * p.ldo_f32 + gn) = v;
+        } else if (EPI == EPI_RESID) {
+            float* dst = p.out_f32 + (long)gm * p.ldo_f32 + gn;
+            f32x4 x = *reinterpret_cast<const f32x4*>(dst);
+            *reinterpret_cast<f32x4*>(dst) = x + v;
+        } else if (EPI == EPI_PATCH) {
+            const int b = gm / p.n_patches, pi = gm - b * p.n_patches;
+            const long xrow = (long)b * (p.n_patches + 1) + 1 + pi;
+            f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (long)(1 + pi) * p.ldo_f32 + gn);
+            *reinterpret_cast<f32x4*>(p.out_f32 + xrow * p.ldo_f32 + gn) = v + pe;
+        } else if (EPI == EPI_GELU || EPI == EPI_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (EPI == EPI_GELU) ? gelu_erf(v[e]) : fmaxf(v[e], 0.f);
+            bf16_t* dst = p.out_bf16 + (long)gm * p.ldo + gn;
+            uint2 hi, lo;
+            split_bf16x2(v[0], v[1], hi.x, lo.x);
+            split_bf16x2(v[2], v[3], hi.y, lo.y);
+            *reinterpret_cast<uint2*>(dst) = hi;
+            if (PLANES == 2) *reinterpret_cast<uint2*>(dst + p.out_plane) = lo;
+        } else if (EPI == EPI_QKV) {
+            const int which = n0 / p.dmodel;               // 0: Q, 1: K  (V handled above)
+            const int hcol = n0 % p.dmodel + c4 * 4;
+            const int head = hcol >> 6, d = hcol & 63;
+            const int b = gm / p.ntok, tok = gm - b * p.ntok;
+            if (which == 0) v *= p.qscale;
+            bf16_t* dst = (which == 0 ? p.q : p.k) + ((long)(b * p.heads + head) * p.npad + tok) * 64 + d;
+            uint2 hi, lo;
+            split_bf16x2(v[0], v[1], hi.x, lo.x);
+            split_bf16x2(v[2], v[3], hi.y, lo.y);
+            *reinterpret_cast<uint2*>(dst) = hi;
+            if (PLANES == 2) *reinterpret_cast<uint2*>(dst + p.qkv_plane) = lo;
+        }
+    }
+}
+
+template <int PLANES, int EPI>
+static int launch_one(const GemmParams& p, hipStream_t s) {
+    const int nbn = p.N / BN, nbm = (p.M + BM - 1) / BM;
+    const int grid = ((nbm + 7) / 8) * 8 * nbn;
+    const size_t lds = (size_t)PLANES * 2 * 2 * TILE_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<PLANES, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<PLANES, EPI>), dim3(grid), dim3(256), lds, s, p);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0) return 0;
+    if (p.N % BN != 0 || p.K % BK != 0 || p.lda % 8 != 0) {
+        dinoseg_set_error("gemm: unsupported shape M=%d N=%d K=%d lda=%d (need N%%128==0, K%%64==0)", p.M, p.N, p.K, p.lda);
+        return -1;
+    }
+    if (p.epi == EPI_QKV && (p.dmodel % 128 != 0 || p.N != 3 * p.dmodel)) {
+        dinoseg_set_error("gemm: QKV epilogue needs dmodel%%128==0 and N==3*dmodel");
+        return -1;
+    }
+#define DSEG_CASE(PL, E) \
+    if (p.planes == PL && p.epi == E) return launch_one<PL, E>(p, s);
+    DSEG_CASE(1, EPI_PLAIN) DSEG_CASE(2, EPI_PLAIN)
+    DSEG_CASE(1, EPI_RESID) DSEG_CASE(2, EPI_RESID)
+    DSEG_CASE(1, EPI_GELU) DSEG_CASE(2, EPI_GELU)
+    DSEG_CASE(1, EPI_RELU) DSEG_CASE(2, EPI_RELU)
+    DSEG_CASE(1, EPI_QKV) DSEG_CASE(2, EPI_QKV)
+    DSEG_CASE(1, EPI_PATCH) DSEG_CASE(2, EPI_PATCH)
+#undef DSEG_CASE
+    dinoseg_set_error("gemm: bad planes/epilogue %d/%d", p.planes, p.epi);
+    return -1;
+}
+
+}  // namespace dseg

@@ -1,0 +1,70 @@
+// Host-side launch interface of the dinoseg HIP kernels (internal; the public C-ABI is include/dinoseg.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dseg {
+
+typedef uint16_t bf16_t;
+
+enum GemmEpilogue {
+    EPI_PLAIN = 0,   // out_f32[M,N] = acc (+ bias)
+    EPI_RESID = 1,   // out_f32[M,N] += acc + bias            (attn.proj / mlp.fc2 + residual add)
+    EPI_GELU = 2,    // out_bf16 planes = gelu_erf(acc + bias) (mlp.fc1)
+    EPI_RELU = 3,    // out_bf16 planes = relu(acc + bias)     (head layer_1 / layer_2)
+    EPI_QKV = 4,     // scatter to Q [B,H,Npad,64] (pre-scaled), K [B,H,Npad,64], V^T [B,H,64,Npad]
+    EPI_PATCH = 5,   // token rows: X[b*(n+1)+1+p, :] = acc + bias + pos[1+p, :]
+};
+
+// C[M,N] = A[M,K] . W[N,K]^T  (both operands K-contiguous, bf16 hi(/lo) planes, fp32 accumulate)
+struct GemmParams {
+    const bf16_t* A; long a_plane; int lda;     // [planes][M][lda]
+    const bf16_t* W; long w_plane;              // [planes][N][K]
+    int M, N, K;
+    int planes;                                 // 1: bf16 ; 2: bf16 hi+lo split (3 MFMAs per product)
+    int epi;
+    const float* bias;                          // [N] or null
+    float* out_f32; int ldo_f32;                // PLAIN / RESID / PATCH
+    bf16_t* out_bf16; long out_plane; int ldo;  // GELU / RELU : [planes][M][ldo]
+    bf16_t* q; bf16_t* k; bf16_t* vt; long qkv_plane;   // QKV
+    int ntok, npad, heads, dmodel; float qscale;
+    const float* pos; int n_patches;            // PATCH
+};
+int launch_gemm(const GemmParams& p, hipStream_t s);
+
+// Flash-style fused multi-head attention, head_dim 64.
+struct AttnParams {
+    const bf16_t* q; const bf16_t* k; const bf16_t* vt; long qkv_plane;  // as written by EPI_QKV
+    bf16_t* ctx; long ctx_plane;       // [planes][B*ntok][heads*64]
+    float* lse;                        // optional [B,H,ntok] log2-domain log-sum-exp (for backward), may be null
+    int B, heads, ntok, npad, planes;
+};
+int launch_attention(const AttnParams& p, hipStream_t s);
+
+// fp32 [rows, cols] -> bf16 planes [planes][rows_pad][cols_pad], zero padded
+int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,
+                       int planes, hipStream_t s);
+
+// LayerNorm over the last dim (D % 128 == 0, D <= 1024). rows of x: [M, D] fp32.
+// drop_cls != 0: input row m = b*ntok + t is skipped for t == 0 and written to output row b*(ntok-1) + t-1.
+int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, int M, int D,
+                     bf16_t* out, long out_plane, int planes, float* out_f32, int drop_cls, int ntok, hipStream_t s);
+
+// Patch gather ("im2col") for the 8x8/stride-8 patch embedding. k index = c*64 + ky*8 + kx.
+// kind 0: uint8 HWC frames [B,r,r,3] with the ImageNet normalisation fused; kind 1: fp32 CHW [B,3,r,r] as is.
+int launch_patch_gather(const void* x, int kind, int B, int r, const float* mean255, const float* inv_std255,
+                        bf16_t* out, long out_plane, int planes, hipStream_t s);
+
+// X[b*ntok + 0, :] = cls[:] + pos[0, :]
+int launch_cls_rows(float* X, const float* cls, const float* pos, int B, int ntok, int D, hipStream_t s);
+
+// Bicubic (A=-0.75, align_corners=False, scale_factor rule) resample of the patch pos-embed grid.
+int launch_pos_resample(const float* pos_embed, int g, int D, int o, float* out, hipStream_t s);
+
+// Final classifier layer + log_softmax + argmax.  in: bf16 hi/lo planes [2][M][ld]; W fp32 [C][K]; C <= 32.
+int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, const float* W, const float* b, int C,
+                      float* logp, int32_t* argmax, hipStream_t s);
+
+int init_kernel_attributes();
+
+}  // namespace dseg

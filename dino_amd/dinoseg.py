@@ -1,0 +1,328 @@
+"""Host-side mirror of the reference ``DINOSeg`` (dt_segmentation/src/pl_torch_modules.py:141-440).
+
+Same public surface -- ``load_from_checkpoint()``, ``.to()``, ``set_resolution()``, ``predict()``,
+``forward()``/``__call__``, ``state_dict()`` keys, ``freeze_bb()/unfreeze_bb()`` -- with every
+tensor op replaced by the hand-written gfx950 kernels behind the C-ABI in ``include/dinoseg.h``.
+PyTorch only owns the parameters, the I/O tensors and the stream.  There is no CPU path: calling
+the model without a ROCm device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import capi
+from .weights import VIT_B8, VIT_S8, ViTConfig
+
+_IMAGENET_MEAN = (0.485, 0.456, 0.406)
+_IMAGENET_STD = (0.229, 0.224, 0.225)
+_PRECISIONS = {"bf16": capi.BF16, "bf16x3": capi.BF16X3}
+
+
+# --------------------------------------------------------------------------- preprocessing mirror
+class _Transforms:
+    """Call-compatible stand-in for the albumentations pipeline of ``get_transforms``
+    (pl_torch_modules.py:33-41): ``t(image=ndarray)['image']`` -> fp32 CHW tensor.
+
+    Resize(res, res) is the identity for frames already at res x res (the benchmark / golden case);
+    other sizes use a half-pixel-centre bilinear resample on uint8 (cv2.INTER_LINEAR convention,
+    not bit-pinned: albumentations/OpenCV are not available here -- see DESIGN.md).
+    """
+
+    def __init__(self, resolution: int):
+        self.resolution = int(resolution)
+
+    def resize(self, img: np.ndarray) -> np.ndarray:
+        r = self.resolution
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError(f"expected an HxWx3 image, got {img.shape}")
+        if img.shape[0] == r and img.shape[1] == r:
+            return np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape[:2]
+        ys = (np.arange(r, dtype=np.float64) + 0.5) * (h / r) - 0.5
+        xs = (np.arange(r, dtype=np.float64) + 0.5) * (w / r) - 0.5
+        y0 = np.floor(ys).astype(np.int64)
+        x0 = np.floor(xs).astype(np.int64)
+        fy = (ys - y0)[:, None, None]
+        fx = (xs - x0)[None, :, None]
+        y0c, y1c = np.clip(y0, 0, h - 1), np.clip(y0 + 1, 0, h - 1)
+        x0c, x1c = np.clip(x0, 0, w - 1), np.clip(x0 + 1, 0, w - 1)
+        f = img.astype(np.float64)
+        top = f[y0c][:, x0c] * (1 - fx) + f[y0c][:, x1c] * fx
+        bot = f[y1c][:, x0c] * (1 - fx) + f[y1c][:, x1c] * fx
+        return np.clip(np.rint(top * (1 - fy) + bot * fy), 0, 255).astype(np.uint8)
+
+    def __call__(self, image: np.ndarray) -> Dict[str, torch.Tensor]:
+        u8 = self.resize(np.asarray(image))
+        mean = np.array(_IMAGENET_MEAN, dtype=np.float32) * np.float32(255.0)
+        inv = np.reciprocal(np.array(_IMAGENET_STD, dtype=np.float32) * np.float32(255.0))
+        x = (u8.astype(np.float32) - mean) * inv
+        return {"image": torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))}
+
+
+def get_transforms(resolution: int = 480) -> _Transforms:
+    return _Transforms(resolution)
+
+
+# --------------------------------------------------------------------------- parameter containers
+class _Attn(nn.Module):
+    def __init__(self, D):
+        super().__init__()
+        self.qkv = nn.Linear(D, 3 * D, bias=True)
+        self.proj = nn.Linear(D, D)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, D, F):
+        super().__init__()
+        self.fc1 = nn.Linear(D, F)
+        self.fc2 = nn.Linear(F, D)
+
+
+class _Block(nn.Module):
+    def __init__(self, D, F, eps):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(D, eps=eps)
+        self.attn = _Attn(D)
+        self.norm2 = nn.LayerNorm(D, eps=eps)
+        self.mlp = _Mlp(D, F)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, D, p):
+        super().__init__()
+        self.proj = nn.Conv2d(3, D, kernel_size=p, stride=p)
+
+
+class _ViTParams(nn.Module):
+    """Parameter holder with the reference ViT's state_dict names (vision_transformer.py:161-196).
+    It has no forward: the arithmetic lives in libdinoseg_hip.so."""
+
+    def __init__(self, cfg: ViTConfig):
+        super().__init__()
+        D = cfg.embed_dim
+        self.patch_embed = _PatchEmbed(D, cfg.patch)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
+        self.pos_embed = nn.Parameter(torch.zeros(1, cfg.pos_grid * cfg.pos_grid + 1, D))
+        self.blocks = nn.ModuleList([_Block(D, cfg.hidden, cfg.ln_eps) for _ in range(cfg.n_blocks)])
+        self.norm = nn.LayerNorm(D, eps=cfg.ln_eps)
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+
+class _MLPHead(nn.Module):
+    def __init__(self, n_classes, input_dim):
+        super().__init__()
+        self.layer_1 = nn.Linear(input_dim, 200)
+        self.layer_2 = nn.Linear(200, 100)
+        self.layer_3 = nn.Linear(100, n_classes)
+
+
+class _LinearHead(nn.Module):
+    def __init__(self, n_classes, input_dim):
+        super().__init__()
+        self.layer_1 = nn.Linear(input_dim, n_classes)
+
+
+# --------------------------------------------------------------------------- the model
+class DINOSeg(nn.Module):
+    """DINO ViT + per-patch segmentation head on MI355X.
+
+    Constructor keywords follow the reference (pl_torch_modules.py:144-147); two extra
+    keyword-only arguments select what the reference hard-codes or cannot express:
+    ``arch`` ('vit_small' | 'vit_base') and ``precision`` ('bf16x3' parity mode, default |
+    'bf16' benchmark mode).
+    """
+
+    def __init__(self, data_path=None, write_path=None, class_names=None, head="linear", n_blocks=1,
+                 batch_size=1, lr=1e-6, optimizer=torch.optim.AdamW, freeze_backbone=True, max_epochs=200,
+                 patience=10, grayscale=False, n_classes=7, pretrain_on_sim=False, comet_logger=None,
+                 augmented=True, random_init=False, backbone="vit", *, arch="vit_small", precision="bf16x3"):
+        super().__init__()
+        if backbone != "vit":
+            raise NotImplementedError("only backbone='vit' is on the MI355X hot path (SURVEY.md §2 row 7)")
+        if head not in ("linear", "mlp"):
+            raise ValueError(f"unknown head {head!r}")
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        base = {"vit_small": VIT_S8, "vit_base": VIT_B8}[arch]
+        self.cfg = ViTConfig(embed_dim=base.embed_dim, num_heads=base.num_heads, n_blocks=int(n_blocks),
+                             n_classes=int(n_classes), head=head)
+        self.arch = arch
+        self.precision = precision
+        self.n_blocks = n_blocks
+        self.head = head
+        self.batch_size = batch_size
+        self.lr = lr
+        self.optimizer = optimizer
+        self.freeze_backbone = freeze_backbone
+        self.max_epochs = max_epochs
+        self.patience = patience
+        self.grayscale = grayscale
+        self.n_classes = n_classes
+        self.comet_logger = comet_logger
+        self.class_names = class_names
+        self.pretrain_on_sim = pretrain_on_sim
+        self.augmented = augmented
+        self.random_init = random_init
+        self.backbone = backbone
+        self.mlp_input_dim = self.cfg.embed_dim
+        self.data_path, self.write_path = data_path, write_path
+        self.best_ck = None
+
+        self.resolution = 480
+        self.transforms = get_transforms(self.resolution)
+
+        # No network: the pretrained DINO fetch of the reference (dt_utils.py:19-29) is replaced by
+        # a random init; real weights arrive through load_state_dict / load_from_checkpoint.
+        self.dino = _ViTParams(self.cfg)
+        self.clf = (_MLPHead(self.cfg.n_classes, self.cfg.embed_dim) if head == "mlp"
+                    else _LinearHead(self.cfg.n_classes, self.cfg.embed_dim))
+
+        self._handle: Optional[C.c_void_p] = None
+        self._bound_sig = None
+
+    # ---- plumbing -------------------------------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self.dino.cls_token.device
+
+    def _require_gpu(self) -> None:
+        if self.device.type != "cuda":
+            raise capi.DinosegError("DINOSeg runs only on a ROCm device (call .to('cuda:0')); there is no CPU path")
+
+    def _param_signature(self):
+        return tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items())
+
+    def _sync_weights(self) -> None:
+        """Create the native handle if needed and (re)bind + repack when any parameter moved or changed."""
+        lib = capi.lib()
+        self._require_gpu()
+        if self._handle is None:
+            cfg = capi.Config(self.cfg.embed_dim, self.cfg.num_heads, self.cfg.n_blocks, self.cfg.patch,
+                              self.cfg.mlp_ratio, self.cfg.n_classes,
+                              capi.HEAD_MLP if self.head == "mlp" else capi.HEAD_LINEAR, self.cfg.pos_grid,
+                              self.cfg.ln_eps, _PRECISIONS[self.precision])
+            h = C.c_void_p()
+            capi.check(lib.dinoseg_create(C.byref(cfg), C.byref(h)))
+            self._handle = h
+            self._bound_sig = None
+        sig = self._param_signature()
+        if sig == self._bound_sig:
+            return
+        for name, t in self.state_dict(keep_vars=True).items():
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise capi.DinosegError(f"parameter {name} must be contiguous fp32")
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            capi.check(lib.dinoseg_bind_weight(self._handle, name.encode(), t.data_ptr(), shape, t.dim()))
+        capi.check(lib.dinoseg_refresh_weights(self._handle, capi.stream_ptr()))
+        self._bound_sig = sig
+
+    def set_precision(self, precision: str) -> None:
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        if precision != self.precision:
+            self.precision = precision
+            self._release()
+
+    def _release(self) -> None:
+        if self._handle is not None:
+            capi.lib().dinoseg_destroy(self._handle)
+            self._handle = None
+            self._bound_sig = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ---- reference API ----------------------------------------------------------------------
+    def set_resolution(self, resolution=480):
+        if resolution % 8 != 0:
+            raise ValueError("Resolution should be a multiple of 8.")
+        self.transforms = get_transforms(resolution)
+        self.resolution = resolution
+
+    def _run(self, x: torch.Tensor, kind: int, B: int, r: int, want_logp: bool = True, want_argmax: bool = False,
+             tap_block: int = -1):
+        self._sync_weights()
+        n = (r // 8) ** 2
+        dev = x.device
+        logp = torch.empty((B * n, self.cfg.n_classes), dtype=torch.float32, device=dev) if want_logp else None
+        amax = torch.empty((B * n,), dtype=torch.int32, device=dev) if want_argmax else None
+        tap = (torch.empty((B * (n + 1), self.cfg.embed_dim), dtype=torch.float32, device=dev)
+               if tap_block >= 0 else None)
+        capi.check(capi.lib().dinoseg_forward(self._handle, x.data_ptr(), kind, B, r, capi.ptr(logp), capi.ptr(amax),
+                                              tap_block, capi.ptr(tap), capi.stream_ptr()))
+        return logp, amax, tap
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 [B,3,r,r] (normalised) -> fp32 [B*(r/8)^2, n_classes] log-probabilities."""
+        self._require_gpu()
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3]:
+            raise ValueError(f"expected [B,3,r,r], got {tuple(x.shape)}")
+        if x.shape[2] % 8 != 0:
+            raise ValueError("Resolution should be a multiple of 8.")
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        logp, _, _ = self._run(x, capi.INPUT_F32_CHW, x.shape[0], x.shape[2])
+        return logp
+
+    @torch.no_grad()
+    def forward_frames(self, frames_u8: torch.Tensor, want_logp: bool = True):
+        """uint8 [B,r,r,3] device frames -> (log-probs or None, int32 argmax [B*(r/8)^2]).
+        The batched form of predict(): normalisation is fused into the patch gather on device."""
+        self._require_gpu()
+        if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[3] != 3 \
+                or frames_u8.shape[1] != frames_u8.shape[2]:
+            raise ValueError(f"expected uint8 [B,r,r,3], got {frames_u8.dtype} {tuple(frames_u8.shape)}")
+        if frames_u8.shape[1] % 8 != 0:
+            raise ValueError("Resolution should be a multiple of 8.")
+        frames_u8 = frames_u8.to(self.device).contiguous()
+        logp, amax, _ = self._run(frames_u8, capi.INPUT_U8_HWC, frames_u8.shape[0], frames_u8.shape[1],
+                                  want_logp=want_logp, want_argmax=True)
+        return logp, amax
+
+    def predict(self, x) -> np.ndarray:
+        """Run inference on a single image (PIL.Image or HxWx3 uint8 array); returns the int64 map the
+        reference returns: np.kron of the (r/8)x(r/8) argmax map with a (480//(r/8))^2 block of ones
+        (pl_torch_modules.py:276-300, including the non-480 sizes it yields when 480 % (r/8) != 0)."""
+        with torch.no_grad():
+            u8 = self.transforms.resize(np.array(x))
+            frames = torch.from_numpy(u8).unsqueeze(0).to(self.device)
+            _, amax = self.forward_frames(frames, want_logp=False)
+            output_size = self.resolution // 8
+            low_res = amax.cpu().numpy().astype(np.int64).reshape((output_size, output_size))
+            high_res_patch_size = 480 // output_size
+            return np.kron(low_res, np.ones((high_res_patch_size, high_res_patch_size), dtype=int))
+
+    def debug_tokens(self, x: torch.Tensor, block: int) -> torch.Tensor:
+        """Token matrix [B, N, D] after prepare_tokens (block=0) or after transformer block `block`."""
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        _, _, tap = self._run(x, capi.INPUT_F32_CHW, x.shape[0], x.shape[2], tap_block=block)
+        return tap.reshape(x.shape[0], -1, self.cfg.embed_dim)
+
+    def freeze_bb(self):
+        for p in self.dino.parameters():
+            p.requires_grad = False
+
+    def unfreeze_bb(self):
+        for p in self.dino.parameters():
+            p.requires_grad = True
+
+    def configure_optimizers(self):
+        return self.optimizer(self.parameters(), lr=self.lr)
+
+    # ---- checkpoints ------------------------------------------------------------------------
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, **overrides):
+        from .ckpt import load_checkpoint
+        return load_checkpoint(cls, checkpoint_path, map_location=map_location, **overrides)

@@ -1,0 +1,127 @@
+/* dinoseg.h -- C-ABI of libdinoseg_hip.so: the MI355X (gfx950) DINOSeg hot path.
+ *
+ * Drop-in boundary for the reference's Python model class (reference = sachaMorin/dino, all
+ * citations relative to its root).  The reference has no FFI of its own -- its "operator interface"
+ * for this path is the DINOSeg module API -- so each entry point names the Python call it replaces.
+ * The host-side mirror (dino_amd/dinoseg.py) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no torch / C++ types.  Every function returns
+ * 0 on success and a negative code on failure (-1 bad argument, -2 HIP runtime error, -3 state error);
+ * dinoseg_last_error() returns the message.  All device pointers are caller-owned (PyTorch-ROCm
+ * tensors); the library owns only its packed-weight copies and its activation workspace, released by
+ * dinoseg_destroy().  Every call is asynchronous on the caller's `stream` (a hipStream_t passed as
+ * void*; pass torch.cuda.current_stream().cuda_stream) and performs no host synchronisation, except
+ * the lazy workspace (re)allocation on the first call for a larger (B, r).
+ * A handle is not re-entrant: one handle per process per GPU.
+ */
+#ifndef DINOSEG_H
+#define DINOSEG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dinoseg_handle dinoseg_handle;
+
+/* Precision of the GEMM / attention operands (accumulation is always fp32):
+ *   DINOSEG_BF16   : bf16 operands, 1 MFMA per product  (benchmark mode, BASELINE.json "bf16")
+ *   DINOSEG_BF16X3 : bf16 hi+lo operand pairs, 3 MFMAs per product (~16 mantissa bits): the parity mode
+ *                    that meets "argmax identical, |dlogp| <= 1e-3" against the fp32 reference. */
+enum { DINOSEG_BF16 = 0, DINOSEG_BF16X3 = 1 };
+enum { DINOSEG_HEAD_LINEAR = 0, DINOSEG_HEAD_MLP = 1 };
+enum { DINOSEG_INPUT_U8_HWC = 0,      /* uint8 [B,r,r,3] frames; ImageNet normalisation fused on device   */
+       DINOSEG_INPUT_F32_CHW = 1 };   /* fp32  [B,3,r,r] already-normalised tensor (DINOSeg.forward input) */
+
+/* Architecture = the reference ctor arguments that shape the path.
+ * DINOSeg.__init__(head, n_blocks, n_classes, backbone='vit')   dt_segmentation/src/pl_torch_modules.py:144-222
+ * vit_small / vit_base(patch_size=8)                             dt_segmentation/src/vision_transformer.py:300-311 */
+typedef struct dinoseg_config {
+    int32_t embed_dim;    /* 384 (ViT-S) / 768 (ViT-B); multiple of 128                         */
+    int32_t num_heads;    /* embed_dim / 64                                                      */
+    int32_t n_blocks;     /* transformer blocks kept (dino.blocks[:n_blocks], :177)              */
+    int32_t patch;        /* 8                                                                   */
+    int32_t mlp_ratio;    /* 4                                                                   */
+    int32_t n_classes;    /* <= 32                                                               */
+    int32_t head_kind;    /* DINOSEG_HEAD_*  (pl_torch_modules.py:219-222)                       */
+    int32_t pos_grid;     /* 28: stored pos_embed is [1, 28*28+1, D]                             */
+    float   ln_eps;       /* 1e-6 (vision_transformer.py:303)                                    */
+    int32_t precision;    /* DINOSEG_BF16 / DINOSEG_BF16X3                                       */
+} dinoseg_config;
+
+const char* dinoseg_last_error(void);
+int dinoseg_version(void);
+
+/* Replaces DINOSeg.__init__ (pl_torch_modules.py:144-237) minus the network fetch (dt_utils.py:19-29). */
+int dinoseg_create(const dinoseg_config* cfg, dinoseg_handle** out);
+int dinoseg_destroy(dinoseg_handle* h);
+
+/* Replaces load_state_dict() inside LightningModule.load_from_checkpoint (call sites README.md:31,
+ * visualize.py:23): bind one fp32 device tensor by its state_dict key ("dino.blocks.0.attn.qkv.weight",
+ * "clf.layer_1.bias", ...).  The pointer is borrowed and must stay valid; shape is checked. */
+int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim);
+
+/* (Re)build the library's packed bf16 operand planes from the bound fp32 tensors.  Call after binding
+ * and after every optimiser step (the role `.to(device)` / optimizer.step() play for torch, README.md:31). */
+int dinoseg_refresh_weights(dinoseg_handle* h, void* stream);
+
+/* Replaces DINOSeg.set_resolution (pl_torch_modules.py:270-274) on the device side: bicubic pos-embed
+ * resample for an (r/8)x(r/8) grid (vision_transformer.py:202-222), cached per resolution.  r % 8 != 0 -> -1. */
+int dinoseg_prepare_resolution(dinoseg_handle* h, int32_t r, void* stream);
+
+/* Replaces DINOSeg.forward (pl_torch_modules.py:239-256) and the argmax of predict() (:294):
+ *   x        : B frames at r x r, layout per x_kind
+ *   logp_out : fp32 [B*(r/8)^2, n_classes] log-probabilities (may be NULL)
+ *   argmax_out: int32 [B*(r/8)^2] first-maximum class index (may be NULL)
+ *   tap_block / tap_out: optional debug tap -- tap_block = 0 copies the token matrix after prepare_tokens,
+ *   i > 0 after block i, into tap_out (fp32 [B*((r/8)^2+1), embed_dim]); pass -1 / NULL to disable. */
+int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
+                    int32_t* argmax_out, int32_t tap_block, float* tap_out, void* stream);
+
+/* Bytes of library-owned device memory a (B, r) forward needs (activations + packed weights). */
+int64_t dinoseg_workspace_bytes(const dinoseg_handle* h, int32_t B, int32_t r);
+
+/* ---- stand-alone operators (same kernels the forward uses; exported for unit parity tests) ------------- */
+
+/* fp32 [rows, cols] -> bf16 planes [planes][rows_pad][cols_pad] (zero padded); plane stride in elements */
+int dinoseg_op_pack(const float* src, int32_t rows, int32_t cols, void* dst, int64_t plane_stride, int32_t rows_pad,
+                    int32_t cols_pad, int32_t planes, void* stream);
+
+/* C[M,N] = A[M,K] . W[N,K]^T on packed planes.  epi: 0 plain(+bias) -> out_f32; 1 residual: out_f32 += acc+bias;
+ * 2 GELU(erf) -> out_bf16 planes; 3 ReLU -> out_bf16 planes.  (aten::addmm of vision_transformer.py:60-63,75,105) */
+int dinoseg_op_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, int64_t w_plane, int32_t M, int32_t N,
+                    int32_t K, int32_t planes, int32_t epi, const float* bias, float* out_f32, void* out_bf16,
+                    int64_t out_plane, int32_t ldo, void* stream);
+
+/* attn.qkv GEMM with the head-scatter epilogue (vision_transformer.py:82): Q [B,H,npad,64] (times qscale),
+ * K [B,H,npad,64], V^T [B,H,64,npad]; M = B*ntok rows. */
+int dinoseg_op_qkv_gemm(const void* A, int64_t a_plane, const void* W, int64_t w_plane, const float* bias, int32_t B,
+                        int32_t ntok, int32_t npad, int32_t heads, int32_t planes, float qscale, void* q, void* k,
+                        void* vt, int64_t qkv_plane, void* stream);
+
+/* fused softmax(q k^T) v (vision_transformer.py:85,101,104); q must be pre-scaled by 64^-0.5 * log2(e).
+ * ctx: bf16 planes [planes][B*ntok][heads*64]; lse (optional): fp32 [B,heads,ntok], log2 domain. */
+int dinoseg_op_attention(const void* q, const void* k, const void* vt, int64_t qkv_plane, void* ctx, int64_t ctx_plane,
+                         float* lse, int32_t B, int32_t heads, int32_t ntok, int32_t npad, int32_t planes, void* stream);
+
+/* nn.LayerNorm over the last dim (vision_transformer.py:303).  out_bf16 / out_f32 may each be NULL. */
+int dinoseg_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int32_t M, int32_t D,
+                         void* out_bf16, int64_t out_plane, int32_t planes, float* out_f32, int32_t drop_cls,
+                         int32_t ntok, void* stream);
+
+/* interpolate_pos_encoding (vision_transformer.py:202-222): pos_embed fp32 [g*g+1, D] -> out fp32 [o*o+1, D] */
+int dinoseg_op_pos_resample(const float* pos_embed, int32_t g, int32_t D, int32_t o, float* out, void* stream);
+
+/* patch gather (+ fused Normalize for uint8 input) -> bf16 planes [planes][B*(r/8)^2][192] */
+int dinoseg_op_patch_gather(const void* x, int32_t x_kind, int32_t B, int32_t r, void* out, int64_t out_plane,
+                            int32_t planes, void* stream);
+
+/* last Linear + log_softmax + argmax (pl_torch_modules.py:122-123,:294); in: hi/lo planes [2][M][ld] */
+int dinoseg_op_head_final(const void* in, int64_t in_plane, int32_t ld, int32_t M, int32_t K, const float* W,
+                          const float* b, int32_t C, float* logp, int32_t* argmax, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINOSEG_H */

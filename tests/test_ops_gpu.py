@@ -1,0 +1,223 @@
+"""Per-kernel parity tests (-m gpu): each HIP operator, called through the C-ABI, against the CPU oracle
+(oracle/dinoseg_oracle.py) or an fp64 restatement on the same seeded inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from dino_amd import capi
+from oracle import dinoseg_oracle as O
+from tests.gpu_util import pack, quant_like, seeded, unpack
+
+pytestmark = pytest.mark.gpu
+S = capi.stream_ptr
+LOG2E = 1.4426950408889634
+
+
+def test_library_loads_and_torch_shares_runtime(cuda):
+    assert capi.lib().dinoseg_version() >= 100
+    x = seeded((5, 7), 0)
+    p = pack(x, 2)
+    torch.cuda.synchronize()
+    rec = unpack(p)
+    assert torch.allclose(rec, x, rtol=0, atol=2.0 ** -15 * float(x.abs().max()))
+    hi = pack(x, 1)
+    assert torch.equal(hi.view(torch.bfloat16)[0], x.to(torch.bfloat16))   # round-to-nearest-even, bit exact
+
+
+def test_pack_padding(cuda):
+    x = seeded((3, 10), 1)
+    p = pack(x, 2, rows_pad=8, cols_pad=16)
+    rec = unpack(p)
+    assert torch.all(rec[3:] == 0) and torch.all(rec[:, 10:] == 0)
+    assert torch.allclose(rec[:3, :10], x, atol=1e-4)
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (128, 128, 64), (1, 128, 384), (515, 384, 1536)])
+def test_gemm_plain(cuda, planes, M, N, K):
+    # asymmetric operands: a transposed / permuted fragment map cannot pass
+    A = seeded((M, K), 10 + M) + torch.arange(K, device="cuda", dtype=torch.float32)[None, :] * 1e-3
+    W = seeded((N, K), 20 + N) * 0.1 + torch.arange(N, device="cuda", dtype=torch.float32)[:, None] * 1e-3
+    bias = seeded((N,), 3)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    Ap, Wp = pack(A, planes), pack(W, planes)
+    capi.check(capi.lib().dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, planes, capi.EPI_PLAIN,
+                                          bias.data_ptr(), out.data_ptr(), None, 0, 0, S()))
+    torch.cuda.synchronize()
+    ref_q = (quant_like(A, planes).double() @ quant_like(W, planes).double().t() + bias.double()).float()
+    scale = float(ref_q.abs().max())
+    assert torch.isfinite(out).all()
+    # same quantised operands, fp32 accumulation: only summation-order noise (+ dropped lo*lo term) remains
+    assert float((out - ref_q).abs().max()) <= (2e-6 if planes == 1 else 3e-5) * scale * math.sqrt(K / 64)
+    if planes == 2:   # split precision must track the true fp32 product
+        ref = (A.double() @ W.double().t() + bias.double()).float()
+        assert float((out - ref).abs().max()) <= 4e-5 * scale
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+def test_gemm_epilogues(cuda, planes):
+    M, N, K = 261, 256, 128
+    A, W, bias = seeded((M, K), 1), seeded((N, K), 2) * 0.2, seeded((N,), 3)
+    Ap, Wp = pack(A, planes), pack(W, planes)
+    base = (quant_like(A, planes).double() @ quant_like(W, planes).double().t() + bias.double()).float()
+    lib = capi.lib()
+    # residual: X += acc + bias
+    X0 = seeded((M, N), 4)
+    X = X0.clone()
+    capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, planes, capi.EPI_RESID,
+                                   bias.data_ptr(), X.data_ptr(), None, 0, 0, S()))
+    assert torch.allclose(X, X0 + base, atol=2e-4, rtol=1e-5)
+    # GELU / ReLU -> bf16 planes
+    for epi, fn in ((capi.EPI_GELU, O.gelu_erf), (capi.EPI_RELU, torch.relu)):
+        outp = torch.zeros((planes, M, N), dtype=torch.int16, device="cuda")
+        capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, planes, epi,
+                                       bias.data_ptr(), None, outp.data_ptr(), M * N, N, S()))
+        got = unpack(outp)
+        want = fn(base.cpu()).cuda()
+        tol = 2.0 ** -8 if planes == 1 else 2.0 ** -15
+        assert float((got - want).abs().max()) <= tol * float(want.abs().max()) + 2e-4
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+def test_qkv_gemm_layout(cuda, planes):
+    B, ntok, H = 2, 197, 2
+    D, npad = H * 64, 256
+    A, W, bias = seeded((B * ntok, D), 5), seeded((3 * D, D), 6) * 0.1, seeded((3 * D,), 7)
+    Ap, Wp = pack(A, planes), pack(W, planes)
+    plane = B * H * npad * 64
+    q = torch.zeros((planes, B, H, npad, 64), dtype=torch.int16, device="cuda")
+    k = torch.zeros_like(q)
+    vt = torch.zeros((planes, B, H, 64, npad), dtype=torch.int16, device="cuda")
+    qscale = 0.125 * LOG2E
+    capi.check(capi.lib().dinoseg_op_qkv_gemm(Ap.data_ptr(), B * ntok * D, Wp.data_ptr(), 3 * D * D, bias.data_ptr(), B,
+                                              ntok, npad, H, planes, qscale, q.data_ptr(), k.data_ptr(), vt.data_ptr(),
+                                              plane, S()))
+    ref = (quant_like(A, planes).double() @ quant_like(W, planes).double().t() + bias.double()).float()
+    ref = ref.reshape(B, ntok, 3, H, 64).permute(2, 0, 3, 1, 4)     # vision_transformer.py:82
+    tol = (2.0 ** -8 if planes == 1 else 2.0 ** -15) * float(ref.abs().max()) + 1e-4
+    gq, gk, gv = unpack(q), unpack(k), unpack(vt)
+    assert float((gq[:, :, :ntok] - ref[0] * qscale).abs().max()) <= tol
+    assert float((gk[:, :, :ntok] - ref[1]).abs().max()) <= tol
+    assert float((gv[:, :, :, :ntok] - ref[2].transpose(-1, -2)).abs().max()) <= tol
+    assert torch.all(gq[:, :, ntok:] == 0) and torch.all(gk[:, :, ntok:] == 0) and torch.all(gv[:, :, :, ntok:] == 0)
+
+
+def _attention_case(B, H, ntok, planes, seed, spike=False):
+    npad = (ntok + 63) // 64 * 64
+    g = np.random.default_rng(seed)
+    Q = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32)) * 1.5
+    K = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32)) * 1.5
+    V = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32))
+    if spike:   # force the online-softmax rescale late in the sweep: one key dominates one query row
+        K[:, :, ntok - 3] = Q[:, :, 5] * 4.0
+    qs = Q * (0.125 * LOG2E)
+
+    def planes_of(x, shape_pad):
+        full = torch.zeros(shape_pad, dtype=torch.float32)
+        full[tuple(slice(0, s) for s in x.shape)] = x
+        flat = full.reshape(-1, shape_pad[-1]).cuda()
+        return pack(flat, planes)
+
+    qp = planes_of(qs, (B, H, npad, 64))
+    kp = planes_of(K, (B, H, npad, 64))
+    vp = planes_of(V.transpose(-1, -2).contiguous(), (B, H, 64, npad))
+    ctx = torch.zeros((planes, B * ntok, H * 64), dtype=torch.int16, device="cuda")
+    lse = torch.zeros((B, H, ntok), dtype=torch.float32, device="cuda")
+    capi.check(capi.lib().dinoseg_op_attention(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), B * H * npad * 64,
+                                               ctx.data_ptr(), B * ntok * H * 64, lse.data_ptr(), B, H, ntok, npad,
+                                               planes, S()))
+    torch.cuda.synchronize()
+    # fp64 reference on the operands the kernel saw
+    qq = unpack(qp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu() / LOG2E
+    kk = unpack(kp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu()
+    vv = unpack(vp).reshape(B, H, 64, npad)[:, :, :, :ntok].double().cpu().transpose(-1, -2)
+    s = qq @ kk.transpose(-1, -2)
+    p = torch.softmax(s, dim=-1)
+    ref = (p @ vv).transpose(1, 2).reshape(B * ntok, H * 64).float()
+    ref_lse = (torch.logsumexp(s, dim=-1) * LOG2E).float()
+    got = unpack(ctx).cpu()
+    return got, ref, lse.cpu(), ref_lse
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+@pytest.mark.parametrize("B,H,ntok", [(1, 1, 64), (2, 2, 197), (1, 3, 65), (1, 1, 901), (1, 2, 3601)])
+def test_attention(cuda, planes, B, H, ntok):
+    got, ref, lse, ref_lse = _attention_case(B, H, ntok, planes, seed=ntok + planes)
+    tol = 1.2e-2 if planes == 1 else 1e-4      # bf16 probabilities vs hi+lo split
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= tol
+    assert float((lse - ref_lse).abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+def test_attention_rescale_branch(cuda, planes):
+    got, ref, _, _ = _attention_case(1, 1, 300, planes, seed=77, spike=True)
+    assert float((got - ref).abs().max()) <= (1.2e-2 if planes == 1 else 1e-4)
+
+
+@pytest.mark.parametrize("D", [128, 384, 768])
+def test_layernorm(cuda, D):
+    M, ntok = 2 * 37, 37
+    x = seeded((M, D), 8) * 3 + 0.7
+    g, b = 1 + 0.2 * seeded((D,), 9), 0.1 * seeded((D,), 10)
+    ref = O.layer_norm(x.cpu(), g.cpu(), b.cpu(), 1e-6)
+    lib = capi.lib()
+    for planes in (1, 2):
+        outp = torch.zeros((planes, M, D), dtype=torch.int16, device="cuda")
+        of = torch.zeros((M, D), device="cuda")
+        capi.check(lib.dinoseg_op_layernorm(x.data_ptr(), g.data_ptr(), b.data_ptr(), 1e-6, M, D, outp.data_ptr(), M * D,
+                                            planes, of.data_ptr(), 0, ntok, S()))
+        assert float((of.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6
+        assert float((unpack(outp).cpu() - ref).abs().max()) <= (2.0 ** -8 if planes == 1 else 2.0 ** -15) * float(ref.abs().max())
+    # drop-CLS remap used by the final norm (vision_transformer.py:243 + pl_torch_modules.py:243)
+    of = torch.zeros((M - 2, D), device="cuda")
+    capi.check(lib.dinoseg_op_layernorm(x.data_ptr(), g.data_ptr(), b.data_ptr(), 1e-6, M, D, None, 0, 1, of.data_ptr(), 1,
+                                        ntok, S()))
+    want = ref.reshape(2, ntok, D)[:, 1:].reshape(-1, D)
+    assert float((of.cpu() - want).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("o", [8, 28, 30, 60, 120])
+def test_pos_resample(cuda, o):
+    g, D = 28, 64
+    pe = seeded((1, g * g + 1, D), 11)
+    ref = O.resample_pos_embed(pe.cpu(), o)[0]
+    out = torch.zeros((o * o + 1, D), device="cuda")
+    capi.check(capi.lib().dinoseg_op_pos_resample(pe.data_ptr(), g, D, o, out.data_ptr(), S()))
+    assert float((out.cpu() - ref).abs().max()) <= 1e-5
+
+
+def test_patch_gather(cuda):
+    B, r = 2, 64
+    frames = np.random.default_rng(3).integers(0, 256, (B, r, r, 3), dtype=np.uint8)
+    x = O.preprocess(frames)                                     # fp32 [B,3,r,r]
+    o = r // 8
+    want = x.reshape(B, 3, o, 8, o, 8).permute(0, 2, 4, 1, 3, 5).reshape(B * o * o, 192)
+    lib = capi.lib()
+    fr = torch.from_numpy(frames).cuda()
+    out = torch.zeros((2, B * o * o, 192), dtype=torch.int16, device="cuda")
+    capi.check(lib.dinoseg_op_patch_gather(fr.data_ptr(), capi.INPUT_U8_HWC, B, r, out.data_ptr(), B * o * o * 192, 2, S()))
+    assert float((unpack(out).cpu() - want).abs().max()) <= 2.0 ** -15 * 3
+    xc = x.cuda().contiguous()
+    out1 = torch.zeros((1, B * o * o, 192), dtype=torch.int16, device="cuda")
+    capi.check(lib.dinoseg_op_patch_gather(xc.data_ptr(), capi.INPUT_F32_CHW, B, r, out1.data_ptr(), B * o * o * 192, 1, S()))
+    assert torch.equal(out1.view(torch.bfloat16)[0].cpu(), want.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("C,K,ld", [(7, 100, 128), (7, 384, 384), (21, 100, 128)])
+def test_head_final(cuda, C, K, ld):
+    M = 333
+    x = torch.zeros((M, ld))
+    x[:, :K] = torch.relu(seeded((M, K), 12).cpu())
+    Wc, b = seeded((C, K), 13) * 0.3, seeded((C,), 14)
+    xp = pack(x.cuda(), 2)
+    logp = torch.zeros((M, C), device="cuda")
+    am = torch.zeros((M,), dtype=torch.int32, device="cuda")
+    capi.check(capi.lib().dinoseg_op_head_final(xp.data_ptr(), M * ld, ld, M, K, Wc.data_ptr(), b.data_ptr(), C,
+                                                logp.data_ptr(), am.data_ptr(), S()))
+    z = unpack(xp).cpu()[:, :K] @ Wc.cpu().t() + b.cpu()
+    ref = torch.log_softmax(z, dim=1)
+    assert float((logp.cpu() - ref).abs().max()) <= 2e-5
+    assert torch.equal(am.cpu().long(), ref.argmax(dim=1))
