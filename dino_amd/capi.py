@@ -22,6 +22,7 @@ BF16, BF16X3 = 0, 1
 HEAD_LINEAR, HEAD_MLP = 0, 1
 INPUT_U8_HWC, INPUT_F32_CHW = 0, 1
 EPI_PLAIN, EPI_RESID, EPI_GELU, EPI_RELU = 0, 1, 2, 3
+PROF_CLASSES = ("patch_embed", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm", "head")
 
 
 class DinosegError(RuntimeError):
@@ -50,6 +51,8 @@ SIGNATURES = {
     "dinoseg_prepare_resolution": (C.c_int, [_vp, _i32, _vp]),
     "dinoseg_forward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _fp, _i32, _fp, _vp]),
     "dinoseg_workspace_bytes": (_i64, [_vp, _i32, _i32]),
+    "dinoseg_profile": (C.c_int, [_vp, _i32]),
+    "dinoseg_profile_read": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_i32)]),
     "dinoseg_op_pack": (C.c_int, [_fp, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dinoseg_op_gemm": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _fp, _fp, _vp, _i64, _i32, _vp]),
     "dinoseg_op_qkv_gemm": (C.c_int, [_vp, _i64, _vp, _i64, _fp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _i64, _vp]),

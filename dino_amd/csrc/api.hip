@@ -64,7 +64,37 @@ struct dinoseg_handle {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     int ws_B = -1, ws_r = -1;
+    // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
+    int prof_level = 0;                    // 0 off, 1 attention only, 2 every class
+    struct ProfRec { int cat; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
 };
+
+static int prof_begin(dinoseg_handle* h, int cat, hipStream_t s) {
+    if (h->prof_level == 0 || (h->prof_level == 1 && cat != DINOSEG_PROF_ATTN)) return -1;
+    hipEvent_t ev[2];
+    for (int i = 0; i < 2; ++i) {
+        if (!h->prof_pool.empty()) {
+            ev[i] = h->prof_pool.back();
+            h->prof_pool.pop_back();
+        } else if (hipEventCreate(&ev[i]) != hipSuccess) {
+            return -1;
+        }
+    }
+    h->prof_recs.push_back({cat, ev[0], ev[1]});
+    (void)hipEventRecord(ev[0], s);
+    return (int)h->prof_recs.size() - 1;
+}
+static void prof_end(dinoseg_handle* h, int idx, hipStream_t s) {
+    if (idx >= 0) (void)hipEventRecord(h->prof_recs[idx].b, s);
+}
+#define DSEG_PROF(cat, stmt)                  \
+    do {                                      \
+        const int _pi = prof_begin(h, cat, s); \
+        stmt;                                 \
+        prof_end(h, _pi, s);                  \
+    } while (0)
 
 static int head_planes() { return 2; }   // the classifier head always runs in split precision (it is tiny)
 
@@ -132,6 +162,11 @@ extern "C" int dinoseg_destroy(dinoseg_handle* h) {
     if (h->wbuf) (void)hipFree(h->wbuf);
     if (h->pos_cache) (void)hipFree(h->pos_cache);
     if (h->ws) (void)hipFree(h->ws);
+    for (auto& r : h->prof_recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
     delete h;
     return 0;
 }
@@ -381,7 +416,7 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
     float mean255[3], inv255[3];
     norm_consts(mean255, inv255);
     const long pg_plane = (long)L.Mp * 192;
-    DSEG_TRY(launch_patch_gather(x, x_kind, B, r, mean255, inv255, A, pg_plane, P, s));
+    DSEG_PROF(DINOSEG_PROF_PATCH, DSEG_TRY(launch_patch_gather(x, x_kind, B, r, mean255, inv255, A, pg_plane, P, s)));
     {
         const PackedLinear& pk = h->packed.at("dino.patch_embed.proj.weight");
         GemmParams g = {};
@@ -391,9 +426,9 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
         g.bias = W(h, "dino.patch_embed.proj.bias");
         g.out_f32 = X; g.ldo_f32 = D;
         g.pos = h->pos_cache; g.n_patches = L.n;
-        DSEG_TRY(launch_gemm(g, s));
+        DSEG_PROF(DINOSEG_PROF_PATCH, DSEG_TRY(launch_gemm(g, s)));
     }
-    DSEG_TRY(launch_cls_rows(X, W(h, "dino.cls_token"), h->pos_cache, B, L.ntok, D, s));
+    DSEG_PROF(DINOSEG_PROF_PATCH, DSEG_TRY(launch_cls_rows(X, W(h, "dino.cls_token"), h->pos_cache, B, L.ntok, D, s)));
     const size_t xbytes = (size_t)L.M * D * sizeof(float);
     if (tap_block == 0 && tap_out) DSEG_CHECK_HIP(hipMemcpyAsync(tap_out, X, xbytes, hipMemcpyDeviceToDevice, s));
 
@@ -402,8 +437,8 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
     // ---- transformer blocks (vision_transformer.py:122-140) ----
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
-        DSEG_TRY(launch_layernorm(X, W(h, b + "norm1.weight"), W(h, b + "norm1.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
-                                  nullptr, 0, L.ntok, s));
+        DSEG_PROF(DINOSEG_PROF_LN, DSEG_TRY(launch_layernorm(X, W(h, b + "norm1.weight"), W(h, b + "norm1.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
+                                  nullptr, 0, L.ntok, s)));
         {
             const PackedLinear& pk = h->packed.at(b + "attn.qkv.weight");
             GemmParams g = {};
@@ -413,14 +448,14 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
             g.bias = W(h, b + "attn.qkv.bias");
             g.q = Q; g.k = Kb; g.vt = VT; g.qkv_plane = L.qkv_plane;
             g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
-            DSEG_TRY(launch_gemm(g, s));
+            DSEG_PROF(DINOSEG_PROF_QKV, DSEG_TRY(launch_gemm(g, s)));
         }
         {
             AttnParams a = {};
             a.q = Q; a.k = Kb; a.vt = VT; a.qkv_plane = L.qkv_plane;
             a.ctx = CTX; a.ctx_plane = L.ctx_plane; a.lse = nullptr;
             a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P;
-            DSEG_TRY(launch_attention(a, s));
+            DSEG_PROF(DINOSEG_PROF_ATTN, DSEG_TRY(launch_attention(a, s)));
         }
         {
             const PackedLinear& pk = h->packed.at(b + "attn.proj.weight");
@@ -430,10 +465,10 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
             g.M = L.M; g.N = D; g.K = D; g.planes = P; g.epi = EPI_RESID;
             g.bias = W(h, b + "attn.proj.bias");
             g.out_f32 = X; g.ldo_f32 = D;
-            DSEG_TRY(launch_gemm(g, s));
+            DSEG_PROF(DINOSEG_PROF_PROJ, DSEG_TRY(launch_gemm(g, s)));
         }
-        DSEG_TRY(launch_layernorm(X, W(h, b + "norm2.weight"), W(h, b + "norm2.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
-                                  nullptr, 0, L.ntok, s));
+        DSEG_PROF(DINOSEG_PROF_LN, DSEG_TRY(launch_layernorm(X, W(h, b + "norm2.weight"), W(h, b + "norm2.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
+                                  nullptr, 0, L.ntok, s)));
         {
             const PackedLinear& pk = h->packed.at(b + "mlp.fc1.weight");
             GemmParams g = {};
@@ -442,7 +477,7 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
             g.M = L.M; g.N = F; g.K = D; g.planes = P; g.epi = EPI_GELU;
             g.bias = W(h, b + "mlp.fc1.bias");
             g.out_bf16 = HB; g.out_plane = L.hb_plane; g.ldo = F;
-            DSEG_TRY(launch_gemm(g, s));
+            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_gemm(g, s)));
         }
         {
             const PackedLinear& pk = h->packed.at(b + "mlp.fc2.weight");
@@ -452,14 +487,14 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
             g.M = L.M; g.N = D; g.K = F; g.planes = P; g.epi = EPI_RESID;
             g.bias = W(h, b + "mlp.fc2.bias");
             g.out_f32 = X; g.ldo_f32 = D;
-            DSEG_TRY(launch_gemm(g, s));
+            DSEG_PROF(DINOSEG_PROF_FC2, DSEG_TRY(launch_gemm(g, s)));
         }
         if (tap_block == i + 1 && tap_out) DSEG_CHECK_HIP(hipMemcpyAsync(tap_out, X, xbytes, hipMemcpyDeviceToDevice, s));
     }
 
     // ---- final norm, drop CLS (vision_transformer.py:243; pl_torch_modules.py:243,253) ----
-    DSEG_TRY(launch_layernorm(X, W(h, "dino.norm.weight"), W(h, "dino.norm.bias"), c.ln_eps, L.M, D, FEAT, L.feat_plane,
-                              HP, nullptr, 1, L.ntok, s));
+    DSEG_PROF(DINOSEG_PROF_LN, DSEG_TRY(launch_layernorm(X, W(h, "dino.norm.weight"), W(h, "dino.norm.bias"), c.ln_eps, L.M, D, FEAT, L.feat_plane,
+                              HP, nullptr, 1, L.ntok, s)));
 
     // ---- segmentation head (pl_torch_modules.py:108-138), always in split precision ----
     if (c.head_kind == DINOSEG_HEAD_MLP) {
@@ -471,7 +506,7 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
             g.M = L.Mp; g.N = 256; g.K = D; g.planes = HP; g.epi = EPI_RELU;
             g.bias = pk.bias_pad;
             g.out_bf16 = H1; g.out_plane = L.h1_plane; g.ldo = 256;
-            DSEG_TRY(launch_gemm(g, s));
+            DSEG_PROF(DINOSEG_PROF_HEAD, DSEG_TRY(launch_gemm(g, s)));
         }
         {
             const PackedLinear& pk = h->packed.at("clf.layer_2.weight");
@@ -481,14 +516,51 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
             g.M = L.Mp; g.N = 128; g.K = 256; g.planes = HP; g.epi = EPI_RELU;
             g.bias = pk.bias_pad;
             g.out_bf16 = H2; g.out_plane = L.h2_plane; g.ldo = 128;
-            DSEG_TRY(launch_gemm(g, s));
+            DSEG_PROF(DINOSEG_PROF_HEAD, DSEG_TRY(launch_gemm(g, s)));
         }
-        DSEG_TRY(launch_head_final(H2, L.h2_plane, 128, L.Mp, 100, W(h, "clf.layer_3.weight"), W(h, "clf.layer_3.bias"),
-                                   c.n_classes, logp_out ? logp_out : reinterpret_cast<float*>(ws + L.HB), argmax_out, s));
+        DSEG_PROF(DINOSEG_PROF_HEAD, DSEG_TRY(launch_head_final(H2, L.h2_plane, 128, L.Mp, 100, W(h, "clf.layer_3.weight"), W(h, "clf.layer_3.bias"),
+                                   c.n_classes, logp_out ? logp_out : reinterpret_cast<float*>(ws + L.HB), argmax_out, s)));
     } else {
-        DSEG_TRY(launch_head_final(FEAT, L.feat_plane, D, L.Mp, D, W(h, "clf.layer_1.weight"), W(h, "clf.layer_1.bias"),
-                                   c.n_classes, logp_out ? logp_out : reinterpret_cast<float*>(ws + L.HB), argmax_out, s));
+        DSEG_PROF(DINOSEG_PROF_HEAD, DSEG_TRY(launch_head_final(FEAT, L.feat_plane, D, L.Mp, D, W(h, "clf.layer_1.weight"), W(h, "clf.layer_1.bias"),
+                                   c.n_classes, logp_out ? logp_out : reinterpret_cast<float*>(ws + L.HB), argmax_out, s)));
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+extern "C" int dinoseg_profile(dinoseg_handle* h, int32_t level) {
+    if (!h || level < 0 || level > 2) {
+        dinoseg_set_error("dinoseg_profile: level must be 0, 1 or 2");
+        return -1;
+    }
+    for (auto& r : h->prof_recs) {
+        h->prof_pool.push_back(r.a);
+        h->prof_pool.push_back(r.b);
+    }
+    h->prof_recs.clear();
+    h->prof_level = level;
+    return 0;
+}
+
+extern "C" int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts) {
+    if (!h || !ms_sum || !counts) {
+        dinoseg_set_error("dinoseg_profile_read: null argument");
+        return -1;
+    }
+    for (int c = 0; c < DINOSEG_PROF_COUNT; ++c) {
+        ms_sum[c] = 0.f;
+        counts[c] = 0;
+    }
+    for (auto& r : h->prof_recs) {
+        DSEG_CHECK_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        DSEG_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        ms_sum[r.cat] += ms;
+        counts[r.cat] += 1;
+        h->prof_pool.push_back(r.a);
+        h->prof_pool.push_back(r.b);
+    }
+    h->prof_recs.clear();
     return 0;
 }
 

@@ -138,7 +138,7 @@ class DINOSeg(nn.Module):
 
     Constructor keywords follow the reference (pl_torch_modules.py:144-147); two extra
     keyword-only arguments select what the reference hard-codes or cannot express:
-    ``arch`` ('vit_small' | 'vit_base') and ``precision`` ('bf16x3' parity mode, default |
+    ``arch`` ('vit_small' | 'vit_base' | a ViTConfig giving embed_dim/num_heads) and ``precision`` ('bf16x3' parity mode, default |
     'bf16' benchmark mode).
     """
 
@@ -153,7 +153,7 @@ class DINOSeg(nn.Module):
             raise ValueError(f"unknown head {head!r}")
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
-        base = {"vit_small": VIT_S8, "vit_base": VIT_B8}[arch]
+        base = arch if isinstance(arch, ViTConfig) else {"vit_small": VIT_S8, "vit_base": VIT_B8}[arch]
         self.cfg = ViTConfig(embed_dim=base.embed_dim, num_heads=base.num_heads, n_blocks=int(n_blocks),
                              n_classes=int(n_classes), head=head)
         self.arch = arch
@@ -309,6 +309,18 @@ class DINOSeg(nn.Module):
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         _, _, tap = self._run(x, capi.INPUT_F32_CHW, x.shape[0], x.shape[2], tap_block=block)
         return tap.reshape(x.shape[0], -1, self.cfg.embed_dim)
+
+    def profile(self, level: int) -> None:
+        """Per-kernel-class HIP-event timing inside forward (0 off, 1 attention only, 2 all classes)."""
+        self._sync_weights()
+        capi.check(capi.lib().dinoseg_profile(self._handle, int(level)))
+
+    def profile_read(self) -> Dict[str, tuple]:
+        """{class name: (summed ms, launches)} since the last read; waits for the recorded events."""
+        n = len(capi.PROF_CLASSES)
+        ms, cnt = (C.c_float * n)(), (C.c_int32 * n)()
+        capi.check(capi.lib().dinoseg_profile_read(self._handle, ms, cnt))
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(capi.PROF_CLASSES)}
 
     def freeze_bb(self):
         for p in self.dino.parameters():

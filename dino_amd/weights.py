@@ -135,6 +135,9 @@ def procedural_state_dict(cfg: ViTConfig = VIT_S8, salt: int = 0) -> "OrderedDic
     for name, shape in tensor_shapes(cfg).items():
         n = int(np.prod(shape))
         off, amp = _scale_for(name, shape)
+        if cfg.embed_dim > 384 and name.endswith(".weight") and len(shape) == 2 and "norm" not in name:
+            # keep activation / logit magnitudes of the ViT-S recipe when the fan-in grows with embed_dim (ViT-B)
+            amp *= float(np.sqrt(384.0 / cfg.embed_dim))
         w = _hash_uniform(name, n, salt) * np.float32(amp) + np.float32(off)
         if name == "dino.pos_embed":
             # low-frequency structure on top of the hash so the bicubic resample is exercised
@@ -144,7 +147,11 @@ def procedural_state_dict(cfg: ViTConfig = VIT_S8, salt: int = 0) -> "OrderedDic
             wave = 0.25 * np.sin(0.21 * yy[..., None] + 0.013 * d) * np.cos(0.17 * xx[..., None] - 0.007 * d)
             w = w.reshape(shape)
             w[0, 1:, :] += wave.reshape(g * g, shape[2]).astype(np.float32)
-        out[name] = np.ascontiguousarray(w.reshape(shape), dtype=np.float32)
+        w = w.reshape(shape)
+        if name in ("clf.layer_2.weight", "clf.layer_3.weight") or (name == "clf.layer_1.weight" and cfg.head == "linear"):
+            # zero row mean: a constant (post-ReLU / common-mode) input favours no unit or class by construction
+            w = w - w.mean(axis=1, keepdims=True, dtype=np.float32)
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
     return out
 
 

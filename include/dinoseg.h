@@ -79,6 +79,15 @@ int dinoseg_prepare_resolution(dinoseg_handle* h, int32_t r, void* stream);
 int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
                     int32_t* argmax_out, int32_t tap_block, float* tap_out, void* stream);
 
+/* Per-kernel-class timing with HIP events recorded on the forward's stream (used by bench.py for the
+ * roofline leg).  level 0 = off, 1 = the dominant kernel only (fused attention), 2 = every class.
+ * dinoseg_profile_read() waits for the recorded events, writes the summed milliseconds and launch counts
+ * per class (arrays of DINOSEG_PROF_COUNT) and clears the records. */
+enum { DINOSEG_PROF_PATCH = 0, DINOSEG_PROF_LN = 1, DINOSEG_PROF_QKV = 2, DINOSEG_PROF_ATTN = 3, DINOSEG_PROF_PROJ = 4,
+       DINOSEG_PROF_FC1 = 5, DINOSEG_PROF_FC2 = 6, DINOSEG_PROF_HEAD = 7, DINOSEG_PROF_COUNT = 8 };
+int dinoseg_profile(dinoseg_handle* h, int32_t level);
+int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
+
 /* Bytes of library-owned device memory a (B, r) forward needs (activations + packed weights). */
 int64_t dinoseg_workspace_bytes(const dinoseg_handle* h, int32_t B, int32_t r);
 

@@ -1,0 +1,120 @@
+"""CPU tests of the host side: C-ABI library loads and exports every declared symbol, the DINOSeg mirror
+keeps the reference's surface (state_dict keys, ValueError text, checkpoint round trip) and fails loudly
+without a GPU (no CPU fallback)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dino_amd
+from dino_amd import DINOSeg, ViTConfig, capi, procedural_state_dict
+from dino_amd.ckpt import read_checkpoint, save_checkpoint
+from dino_amd.weights import synthetic_frames, tensor_shapes
+
+
+def test_library_exports_every_header_symbol():
+    lib = capi.lib()
+    declared = capi.header_symbols()
+    assert len(declared) >= 17
+    assert set(declared) == set(capi.SIGNATURES), "capi.SIGNATURES must mirror include/dinoseg.h"
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.dinoseg_version() >= 100
+
+
+def test_handle_lifecycle_and_errors_without_gpu():
+    lib = capi.lib()
+    h = ctypes.c_void_p()
+    bad = capi.Config(100, 2, 1, 8, 4, 7, capi.HEAD_MLP, 28, 1e-6, capi.BF16)
+    assert lib.dinoseg_create(ctypes.byref(bad), ctypes.byref(h)) == -1
+    assert "unsupported config" in capi.last_error()
+    cfg = capi.Config(384, 6, 1, 8, 4, 7, capi.HEAD_MLP, 28, 1e-6, capi.BF16X3)
+    assert lib.dinoseg_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    assert lib.dinoseg_workspace_bytes(h, 1, 480) > 3601 * 384 * 4
+    assert lib.dinoseg_workspace_bytes(h, 1, 250) == -1
+    assert lib.dinoseg_prepare_resolution(h, 250, None) == -1
+    with pytest.raises(ValueError, match="Resolution should be a multiple of 8."):
+        capi.check(-1)
+    # strict binding: unknown key and wrong shape are rejected
+    buf = (ctypes.c_float * 4)()
+    shape = (ctypes.c_int64 * 1)(4)
+    assert lib.dinoseg_bind_weight(h, b"dino.nope", ctypes.addressof(buf), shape, 1) == -1
+    assert lib.dinoseg_bind_weight(h, b"dino.norm.weight", ctypes.addressof(buf), shape, 1) == -1
+    assert lib.dinoseg_refresh_weights(h, None) == -3          # missing keys
+    assert "missing key" in capi.last_error()
+    assert lib.dinoseg_destroy(h) == 0
+
+
+def test_state_dict_keys_match_reference_schema():
+    for head, L in (("mlp", 3), ("linear", 1)):
+        m = DINOSeg(head=head, n_blocks=L)
+        want = tensor_shapes(ViTConfig(n_blocks=L, head=head))
+        got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert got == dict(want)
+    assert len(DINOSeg(head="mlp", n_blocks=3).state_dict()) == 48      # 48 tensors for L=3
+    assert sum(v.numel() for v in DINOSeg(head="mlp", n_blocks=3).state_dict().values()) == 5797903
+
+
+def test_set_resolution_and_no_cpu_fallback():
+    m = DINOSeg(head="mlp", n_blocks=1)
+    with pytest.raises(ValueError, match="Resolution should be a multiple of 8."):
+        m.set_resolution(250)
+    m.set_resolution(240)
+    assert m.resolution == 240 and m.transforms.resolution == 240
+    assert m.device.type == "cpu"
+    with pytest.raises(capi.DinosegError, match="no CPU path"):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(capi.DinosegError, match="no CPU path"):
+        m.predict(np.zeros((240, 240, 3), np.uint8))
+
+
+def test_transforms_match_oracle_preprocess():
+    from oracle import dinoseg_oracle as O
+    fr = synthetic_frames(1, 64, seed=2)
+    t = dino_amd.get_transforms(64)(image=fr[0])["image"]
+    assert t.dtype == torch.float32 and tuple(t.shape) == (3, 64, 64)
+    assert torch.equal(t, O.preprocess(fr)[0])
+    big = dino_amd.get_transforms(32).resize(fr[0])
+    assert big.shape == (32, 32, 3) and big.dtype == np.uint8
+
+
+def test_checkpoint_round_trip(tmp_path):
+    sd = procedural_state_dict(ViTConfig(n_blocks=2))
+    m = DINOSeg(data_path="d", write_path="w", head="mlp", n_blocks=2, optimizer=torch.optim.Adam, lr=1e-3)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    path = os.path.join(tmp_path, "two_block.ckpt")
+    save_checkpoint(m, path, epoch=3)
+    ck = read_checkpoint(path)
+    assert ck["pytorch-lightning_version"] == "1.5.10" and ck["hyper_parameters"]["n_blocks"] == 2
+    m2 = DINOSeg.load_from_checkpoint(path)
+    assert m2.n_blocks == 2 and m2.head == "mlp" and m2.optimizer is torch.optim.Adam and m2.lr == 1e-3
+    for k, v in m2.state_dict().items():
+        assert np.array_equal(v.numpy(), sd[k]), k
+    with pytest.raises(RuntimeError):        # strict load, as the reference
+        m2.load_state_dict({"dino.cls_token": torch.zeros(1, 1, 384)}, strict=True)
+
+
+def test_checkpoint_with_unimportable_hyperparameters(tmp_path):
+    """PL checkpoints pickle objects of packages that are absent here (comet logger...): they must not block loading."""
+    import pickle
+    import types
+    fake = types.ModuleType("comet_like_pkg")
+
+    class Logger:
+        def __init__(self):
+            self.key = "secret"
+    Logger.__module__ = "comet_like_pkg"
+    Logger.__qualname__ = "Logger"
+    fake.Logger = Logger
+    import sys
+    sys.modules["comet_like_pkg"] = fake
+    sd = procedural_state_dict(ViTConfig(n_blocks=1))
+    path = os.path.join(tmp_path, "pl.ckpt")
+    torch.save({"state_dict": {k: torch.from_numpy(v) for k, v in sd.items()},
+                "hyper_parameters": {"head": "mlp", "n_blocks": 1, "comet_logger": Logger(), "data_path": "x",
+                                     "write_path": "y", "optimizer": torch.optim.AdamW}}, path, pickle_module=pickle)
+    del sys.modules["comet_like_pkg"]
+    m = DINOSeg.load_from_checkpoint(path)
+    assert m.n_blocks == 1 and m.comet_logger is None and m.optimizer is torch.optim.AdamW

@@ -1,0 +1,180 @@
+"""Whole-path parity tests (-m gpu): the HIP DINOSeg (through the C-ABI) against the golden vectors captured
+from the reference and against the CPU oracle.
+
+Bar (BASELINE.json north_star): log-probabilities within 1e-3 and argmax identical in the parity mode
+('bf16x3'); the benchmark mode ('bf16') is reported and bounded separately (it cannot meet 1e-3:
+SURVEY.md §6/§7 hard part 1).  "argmax identical" is asserted on every patch; patches whose reference
+top-2 margin is below 2e-3 (= 2 x the log-prob tolerance) are the only ones that could legitimately
+differ, and the tests still require zero flips on the committed fixtures.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dino_amd import DINOSeg, ViTConfig, procedural_state_dict
+from dino_amd.weights import synthetic_frames
+from oracle import dinoseg_oracle as O
+
+pytestmark = pytest.mark.gpu
+TINY = ViTConfig(embed_dim=128, num_heads=2, n_blocks=2)
+TOL = 1e-3
+
+
+def build(cfg, precision):
+    if isinstance(cfg, int):
+        cfg = ViTConfig(n_blocks=cfg)
+    sd = procedural_state_dict(cfg)
+    m = DINOSeg(head=cfg.head, n_blocks=cfg.n_blocks, n_classes=cfg.n_classes, precision=precision, arch=cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.to("cuda:0"), sd, cfg
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def test_g1_tiny_intermediates(cuda, golden_dir):
+    g = load(golden_dir, "g1_tiny_vit_r64")
+    m, sd, cfg = build(TINY, "bf16x3")
+    x = O.preprocess(g["frames"]).cuda()
+    for blk, key in ((0, "tokens"), (1, "block1"), (2, "block2")):
+        got = m.debug_tokens(x, blk).cpu()
+        assert float((got - torch.from_numpy(g[key])).abs().max()) <= 2e-4, key
+    lp = m(x).cpu()
+    assert float((lp - torch.from_numpy(g["logp"])).abs().max()) <= TOL
+    assert torch.equal(lp.argmax(1), torch.from_numpy(g["logp"]).argmax(1))
+    # uint8 path (Normalize fused on device) gives the same numbers as the fp32 CHW path
+    lp2, am = m.forward_frames(torch.from_numpy(g["frames"]).cuda())
+    assert float((lp2.cpu() - lp).abs().max()) <= 1e-5
+    assert torch.equal(am.cpu().long(), lp.argmax(1))
+
+
+@pytest.mark.parametrize("L", [1, 3, 12])
+def test_g3_vits8_480_parity_mode(cuda, golden_dir, L):
+    g = load(golden_dir, f"g3_vits8_L{L}_r480")
+    m, _, _ = build(L, "bf16x3")
+    frames = torch.from_numpy(synthetic_frames(1, 480, seed=int(g["frame_seed"]))).cuda()
+    lp, am = m.forward_frames(frames)
+    err = float((lp.cpu() - torch.from_numpy(g["logp"])).abs().max())
+    flips = int((am.cpu().numpy() != g["argmax"].astype(np.int32)).sum())
+    print(f"L={L} parity mode: max|dlogp|={err:.3e} flips={flips}/3600 min margin={float(g['margin'].min()):.2e}")
+    assert err <= TOL
+    assert flips == 0
+
+
+@pytest.mark.parametrize("L", [1, 12])
+def test_g3_vits8_480_bf16_mode_is_bounded(cuda, golden_dir, L):
+    """Benchmark mode: plain bf16 operands.  Not the parity mode -- bounded and reported, not 1e-3."""
+    g = load(golden_dir, f"g3_vits8_L{L}_r480")
+    m, _, _ = build(L, "bf16")
+    frames = torch.from_numpy(synthetic_frames(1, 480, seed=int(g["frame_seed"]))).cuda()
+    lp, am = m.forward_frames(frames)
+    err = float((lp.cpu() - torch.from_numpy(g["logp"])).abs().max())
+    differ = am.cpu().numpy() != g["argmax"].astype(np.int32)
+    print(f"L={L} bf16 mode: max|dlogp|={err:.3e} flips={int(differ.sum())}/3600")
+    assert err <= 0.35
+    assert differ.mean() <= 0.03
+    assert np.all(g["margin"][differ] <= 2 * err)      # only near-ties move
+
+
+def test_g4_vits8_960(cuda, golden_dir):
+    g = load(golden_dir, "g4_vits8_L3_r960")
+    m, _, _ = build(3, "bf16x3")
+    m.set_resolution(960)
+    frames = torch.from_numpy(synthetic_frames(1, 960, seed=int(g["frame_seed"]))).cuda()
+    lp, am = m.forward_frames(frames)
+    rows = torch.from_numpy(g["rows"])
+    err = float((lp.cpu()[rows] - torch.from_numpy(g["logp_rows"])).abs().max())
+    flips = int((am.cpu().numpy() != g["argmax"].astype(np.int32)).sum())
+    print(f"960: max|dlogp|={err:.3e} flips={flips}/14400")
+    assert err <= TOL and flips == 0
+
+
+def test_g5_predict_maps(cuda, golden_dir):
+    g = load(golden_dir, "g5_predict_L3")
+    m, _, _ = build(3, "bf16x3")
+    for r in (240, 400, 480):
+        m.set_resolution(r)
+        pred = m.predict(g[f"frame_r{r}"])
+        assert pred.dtype == np.int64 and tuple(pred.shape) == tuple(g[f"shape_r{r}"])
+        k = 480 // (r // 8)
+        assert np.array_equal(pred[::k, ::k], g[f"low_r{r}"].astype(np.int64)), r
+        assert np.array_equal(np.kron(pred[::k, ::k], np.ones((k, k), dtype=int)), pred)
+    with pytest.raises(ValueError, match="Resolution should be a multiple of 8."):
+        m.set_resolution(250)
+
+
+def test_g9_against_reference_dinoseg_outputs(cuda, golden_dir):
+    g = load(golden_dir, "g9_reference_dinoseg")
+    for L in (1, 3):
+        m, _, _ = build(L, "bf16x3")
+        for r in (240, 480):
+            m.set_resolution(r)
+            frame = synthetic_frames(1, r, seed=90 + r + L)[0]
+            pred = m.predict(frame)
+            k = 480 // (r // 8)
+            assert tuple(pred.shape) == tuple(g[f"L{L}_r{r}_pred_shape"])
+            assert np.array_equal(pred[::k, ::k], g[f"L{L}_r{r}_low"].astype(np.int64)), (L, r)
+            x = m.transforms(image=frame)["image"].unsqueeze(0)
+            lp = m(x.to(m.device)).cpu()
+            assert float((lp - torch.from_numpy(g[f"L{L}_r{r}_logp"])).abs().max()) <= TOL
+
+
+def test_g7_vitb8(cuda, golden_dir):
+    g = load(golden_dir, "g7_vitb8_L12_r480")
+    m, _, _ = build(ViTConfig(embed_dim=768, num_heads=12, n_blocks=12), "bf16x3")
+    frames = torch.from_numpy(synthetic_frames(1, 480, seed=int(g["frame_seed"]))).cuda()
+    lp, am = m.forward_frames(frames)
+    rows = torch.from_numpy(g["rows"])
+    err = float((lp.cpu()[rows] - torch.from_numpy(g["logp_rows"])).abs().max())
+    flips = int((am.cpu().numpy() != g["argmax"].astype(np.int32)).sum())
+    print(f"ViT-B/8: max|dlogp|={err:.3e} flips={flips}/3600")
+    assert err <= TOL and flips == 0
+
+
+def test_linear_head_and_batch_independence(cuda):
+    """Linear head variant (pl_torch_modules.py:127-138); frames are independent, so a batch equals its singles
+    (the size-independent property used at full benchmark sizes)."""
+    m, sd, cfg = build(ViTConfig(n_blocks=1, head="linear"), "bf16x3")
+    frames = synthetic_frames(3, 96, seed=21)
+    W = O.to_torch(sd)
+    with torch.no_grad():
+        ref = O.dinoseg_forward(O.preprocess(frames), W, cfg.num_heads)
+    lp, am = m.forward_frames(torch.from_numpy(frames).cuda())
+    assert float((lp.cpu() - ref).abs().max()) <= TOL
+    assert torch.equal(am.cpu().long(), ref.argmax(1))
+    n = (96 // 8) ** 2
+    for b in range(3):
+        lp1, _ = m.forward_frames(torch.from_numpy(frames[b:b + 1]).cuda())
+        assert torch.equal(lp1, lp[b * n:(b + 1) * n])        # bit-identical: no cross-frame coupling
+
+
+def test_full_size_batch32_properties(cuda):
+    """BASELINE configs[1] shape (ViT-S/8, 480x480, batch 32) in benchmark precision: rows are valid
+    log-distributions, argmax agrees with log-probs, and duplicated frames give bit-identical rows."""
+    m, _, _ = build(12, "bf16")
+    f = synthetic_frames(4, 480, seed=5)
+    frames = torch.from_numpy(np.concatenate([f] * 8, axis=0)).cuda()        # 32 frames, period 4
+    lp, am = m.forward_frames(frames)
+    assert lp.shape == (32 * 3600, 7) and torch.isfinite(lp).all()
+    assert float((lp.exp().sum(1) - 1).abs().max()) <= 1e-4
+    assert torch.equal(am.long(), lp.argmax(1))
+    lp4 = lp.reshape(8, 4 * 3600, 7)
+    assert torch.equal(lp4[0], lp4[7]) and torch.equal(lp4[0], lp4[3])
+
+
+def test_weights_update_is_picked_up(cuda):
+    m, sd, cfg = build(1, "bf16x3")
+    frames = torch.from_numpy(synthetic_frames(1, 64, seed=3)).cuda()
+    lp0, _ = m.forward_frames(frames)
+    with torch.no_grad():
+        m.clf.layer_3.bias.add_(torch.tensor([3.0, 0, 0, 0, 0, 0, 0], device="cuda"))
+    lp1, am1 = m.forward_frames(frames)
+    assert not torch.equal(lp0, lp1)
+    sd2 = dict(sd)
+    sd2["clf.layer_3.bias"] = sd["clf.layer_3.bias"] + np.array([3, 0, 0, 0, 0, 0, 0], np.float32)
+    with torch.no_grad():
+        ref = O.dinoseg_forward(O.preprocess(frames.cpu().numpy()), O.to_torch(sd2), cfg.num_heads)
+    assert float((lp1.cpu() - ref).abs().max()) <= TOL

@@ -1,0 +1,116 @@
+"""CPU tests: the oracle (oracle/dinoseg_oracle.py) against the golden vectors captured from the reference
+(oracle/gen_golden.py -> tests/golden/*.npz).  This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dino_amd.weights import ViTConfig, procedural_state_dict, synthetic_frames, synthetic_labels
+from oracle import dinoseg_oracle as O
+
+TINY = ViTConfig(embed_dim=128, num_heads=2, n_blocks=2)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def test_g1_tiny_vit_intermediates(golden_dir):
+    g = load(golden_dir, "g1_tiny_vit_r64")
+    W = O.to_torch(procedural_state_dict(TINY))
+    taps = {}
+    with torch.no_grad():
+        x = O.preprocess(g["frames"])
+        final = O.vit_forward(x, W, TINY.num_heads, taps=taps)
+        lp = O.head_forward(final[:, 1:].reshape(-1, TINY.embed_dim), W)
+    for key, val in (("tokens", taps["tokens"]), ("block1", taps["block0"]), ("block2", taps["block1"]), ("final", final),
+                     ("logp", lp)):
+        assert float((val - torch.from_numpy(g[key])).abs().max()) <= 2e-5, key
+
+
+def test_g2_pos_resample(golden_dir):
+    g = load(golden_dir, "g2_pos_resample")
+    pe = torch.from_numpy(procedural_state_dict(ViTConfig(n_blocks=0))["dino.pos_embed"])
+    for o in (28, 30, 60, 120):
+        mine = O.resample_pos_embed(pe, o)[0, :, :8]
+        assert mine.shape == g[f"o{o}"].shape
+        assert float((mine - torch.from_numpy(g[f"o{o}"])).abs().max()) <= 2e-6, o
+
+
+@pytest.mark.parametrize("L", [1, 3, 12])
+def test_g3_vits8_480(golden_dir, L):
+    g = load(golden_dir, f"g3_vits8_L{L}_r480")
+    cfg = ViTConfig(n_blocks=L)
+    W = O.to_torch(procedural_state_dict(cfg))
+    with torch.no_grad():
+        lp = O.dinoseg_forward(O.preprocess(synthetic_frames(1, 480, seed=int(g["frame_seed"]))), W, cfg.num_heads)
+    assert float((lp - torch.from_numpy(g["logp"])).abs().max()) <= 5e-5
+    assert np.array_equal(lp.argmax(1).numpy(), g["argmax"].astype(np.int64))
+
+
+def test_g5_predict_maps(golden_dir):
+    g = load(golden_dir, "g5_predict_L3")
+    cfg = ViTConfig(n_blocks=3)
+    W = O.to_torch(procedural_state_dict(cfg))
+    for r in (240, 400):
+        pred = O.predict(g[f"frame_r{r}"], W, cfg.num_heads, r)
+        assert pred.dtype == np.int64 and tuple(pred.shape) == tuple(g[f"shape_r{r}"])
+        k = 480 // (r // 8)
+        low = pred[::k, ::k]
+        same = low == g[f"low_r{r}"].astype(np.int64)
+        # fp32 CPU summation order differs between the oracle and the reference; only near-ties may move
+        assert np.all(same | (g[f"margin_r{r}"].reshape(low.shape) < 1e-4))
+    assert tuple(g["shape_r400"]) == (450, 450)      # the reference's r=400 quirk: 480 // 50 = 9
+    with pytest.raises(ValueError, match="Resolution should be a multiple of 8."):
+        O.predict(np.zeros((250, 250, 3), np.uint8), W, cfg.num_heads, 250)
+
+
+def test_g9_reference_dinoseg_class(golden_dir):
+    """Outputs of the reference's own DINOSeg.forward / predict / training_step (run under import stand-ins)."""
+    g = load(golden_dir, "g9_reference_dinoseg")
+    assert str(g["set_resolution_250_error"]) == "Resolution should be a multiple of 8."
+    for L in (1, 3):
+        cfg = ViTConfig(n_blocks=L)
+        sd = procedural_state_dict(cfg)
+        W = O.to_torch(sd)
+        r = 240
+        frame = synthetic_frames(1, r, seed=90 + r + L)[0]
+        with torch.no_grad():
+            lp = O.dinoseg_forward(O.preprocess(frame[None]), W, cfg.num_heads)
+        assert float((lp - torch.from_numpy(g[f"L{L}_r{r}_logp"])).abs().max()) <= 5e-5
+        pred = O.predict(frame, W, cfg.num_heads, r)
+        assert tuple(pred.shape) == tuple(g[f"L{L}_r{r}_pred_shape"]) == (480, 480)
+        assert str(g[f"L{L}_r{r}_pred_dtype"]) == str(pred.dtype) == "int64"
+        k = 480 // (r // 8)
+        same = pred[::k, ::k] == g[f"L{L}_r{r}_low"].astype(np.int64)
+        assert np.all(same | (g[f"L{L}_r{r}_margin"].reshape(same.shape) < 1e-4))
+        assert tuple(g[f"L{L}_r400_pred_shape"]) == (450, 450)
+        # training_step loss (mean NLL over B*n patches) and gradient coverage: 6 head tensors frozen, all unfrozen
+        Wg = O.to_torch(sd, requires_grad=True)
+        frames = synthetic_frames(2, 64, seed=61)
+        labels = torch.from_numpy(synthetic_labels(2, 64, 7, seed=62))
+        loss = O.nll_loss(O.dinoseg_forward(O.preprocess(frames), Wg, cfg.num_heads), labels)
+        assert abs(float(loss) - float(g[f"L{L}_train_unfrozen_loss"])) <= 2e-5
+        assert abs(float(loss) - float(g[f"L{L}_train_frozen_loss"])) <= 2e-5
+        assert int(g[f"L{L}_train_frozen_ngrad"]) == 6
+        assert int(g[f"L{L}_train_unfrozen_ngrad"]) == len(sd)
+        assert str(g[f"L{L}_optimizer"]) == "Adam"
+
+
+def test_g6_finetune_gradients(golden_dir):
+    g = load(golden_dir, "g6_finetune")
+    for tag, cfg in (("tiny_r64_B2", TINY), ("vits8_L3_r64_B2", ViTConfig(n_blocks=3))):
+        sd = procedural_state_dict(cfg)
+        W = O.to_torch(sd, requires_grad=True)
+        frames = synthetic_frames(2, 64, seed=61)
+        labels = torch.from_numpy(synthetic_labels(2, 64, cfg.n_classes, seed=62))
+        loss = O.nll_loss(O.dinoseg_forward(O.preprocess(frames), W, cfg.num_heads), labels)
+        loss.backward()
+        assert abs(float(loss) - float(g[f"{tag}|loss"])) <= 2e-5
+        for k, p in W.items():
+            gv = p.grad.reshape(-1)
+            gn = float(g[f"{tag}|gnorm|{k}"])
+            assert abs(float(gv.norm()) - gn) <= 1e-4 * gn + 1e-7, k
+            idx = torch.from_numpy(g[f"{tag}|gidx|{k}"])
+            assert float((gv[idx] - torch.from_numpy(g[f"{tag}|gval|{k}"])).abs().max()) <= 2e-4 * gn + 1e-7, k
