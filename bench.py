@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class (adds event overhead)")
+    ap.add_argument("--option", action="append", default=[], help="library tuning knob key=int (dinoseg_set_option)")
     a = ap.parse_args()
 
     import numpy as np
@@ -106,6 +107,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
+    from dino_amd import capi
+    for kv in a.option:
+        key, val = kv.split("=")
+        capi.check(capi.lib().dinoseg_set_option(key.encode(), int(val)))
     base = VIT_S8 if a.arch == "vit_small" else VIT_B8
     cfg = ViTConfig(embed_dim=base.embed_dim, num_heads=base.num_heads, n_blocks=a.blocks)
     sd = procedural_state_dict(cfg)

@@ -297,7 +297,7 @@ extern "C" int dinoseg_prepare_resolution(dinoseg_handle* h, int32_t r, void* st
 
 // ------------------------------------------------------------------------------------------------ workspace
 struct WsLayout {
-    size_t X, A, Q, K, VT, CTX, HB, FEAT, H1, H2, total;
+    size_t X, A, Q, K, V, CTX, HB, FEAT, H1, H2, total;
     long a_plane, qkv_plane, ctx_plane, hb_plane, feat_plane, h1_plane, h2_plane;
     int n, ntok, npad, M, Mp;
 };
@@ -323,7 +323,7 @@ static WsLayout make_layout(const dinoseg_handle* h, int B, int r) {
     L.qkv_plane = (long)B * c.num_heads * L.npad * 64;
     L.Q = take((size_t)P * L.qkv_plane * 2);
     L.K = take((size_t)P * L.qkv_plane * 2);
-    L.VT = take((size_t)P * L.qkv_plane * 2);
+    L.V = take((size_t)P * L.qkv_plane * 2);
     L.ctx_plane = (long)L.M * D;
     L.CTX = take((size_t)P * L.ctx_plane * 2);
     L.hb_plane = (long)L.M * F;
@@ -356,7 +356,7 @@ static int ensure_workspace(dinoseg_handle* h, const WsLayout& L, int B, int r, 
         h->ws_B = -1;
     }
     if (h->ws_B != B || h->ws_r != r) {
-        // key/value pad rows beyond ntok must be finite: zero Q/K/V^T once per layout (never written afterwards)
+        // key/value pad rows beyond ntok must be finite: zero Q/K/V once per layout (never written afterwards)
         DSEG_CHECK_HIP(hipMemsetAsync(h->ws + L.Q, 0, L.CTX - L.Q, s));
         h->ws_B = B;
         h->ws_r = r;
@@ -405,7 +405,7 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
     bf16_t* A = reinterpret_cast<bf16_t*>(ws + L.A);
     bf16_t* Q = reinterpret_cast<bf16_t*>(ws + L.Q);
     bf16_t* Kb = reinterpret_cast<bf16_t*>(ws + L.K);
-    bf16_t* VT = reinterpret_cast<bf16_t*>(ws + L.VT);
+    bf16_t* V = reinterpret_cast<bf16_t*>(ws + L.V);
     bf16_t* CTX = reinterpret_cast<bf16_t*>(ws + L.CTX);
     bf16_t* HB = reinterpret_cast<bf16_t*>(ws + L.HB);
     bf16_t* FEAT = reinterpret_cast<bf16_t*>(ws + L.FEAT);
@@ -446,13 +446,13 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
             g.W = pk.w; g.w_plane = pk.plane;
             g.M = L.M; g.N = 3 * D; g.K = D; g.planes = P; g.epi = EPI_QKV;
             g.bias = W(h, b + "attn.qkv.bias");
-            g.q = Q; g.k = Kb; g.vt = VT; g.qkv_plane = L.qkv_plane;
+            g.q = Q; g.k = Kb; g.v = V; g.qkv_plane = L.qkv_plane;
             g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
             DSEG_PROF(DINOSEG_PROF_QKV, DSEG_TRY(launch_gemm(g, s)));
         }
         {
             AttnParams a = {};
-            a.q = Q; a.k = Kb; a.vt = VT; a.qkv_plane = L.qkv_plane;
+            a.q = Q; a.k = Kb; a.v = V; a.qkv_plane = L.qkv_plane;
             a.ctx = CTX; a.ctx_plane = L.ctx_plane; a.lse = nullptr;
             a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P;
             DSEG_PROF(DINOSEG_PROF_ATTN, DSEG_TRY(launch_attention(a, s)));
@@ -527,6 +527,28 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ options
+namespace dseg {
+Options& options() {
+    static Options o;
+    return o;
+}
+}  // namespace dseg
+
+extern "C" int dinoseg_set_option(const char* key, int32_t value) {
+    if (!key) return -1;
+    if (strcmp(key, "gemm_big") == 0) {
+        dseg::options().gemm_big = value;
+        return 0;
+    }
+    if (strcmp(key, "gemm_dbg") == 0) {
+        dseg::options().gemm_dbg = value;
+        return 0;
+    }
+    dinoseg_set_error("dinoseg_set_option: unknown key '%s'", key);
+    return -1;
+}
+
 // ------------------------------------------------------------------------------------------------ profiling
 extern "C" int dinoseg_profile(dinoseg_handle* h, int32_t level) {
     if (!h || level < 0 || level > 2) {
@@ -589,23 +611,23 @@ extern "C" int dinoseg_op_gemm(const void* A, int64_t a_plane, int32_t lda, cons
 
 extern "C" int dinoseg_op_qkv_gemm(const void* A, int64_t a_plane, const void* Wp, int64_t w_plane, const float* bias,
                                    int32_t B, int32_t ntok, int32_t npad, int32_t heads, int32_t planes, float qscale,
-                                   void* q, void* k, void* vt, int64_t qkv_plane, void* stream) {
+                                   void* q, void* k, void* v, int64_t qkv_plane, void* stream) {
     GemmParams g = {};
     const int D = heads * 64;
     g.A = reinterpret_cast<const bf16_t*>(A); g.a_plane = a_plane; g.lda = D;
     g.W = reinterpret_cast<const bf16_t*>(Wp); g.w_plane = w_plane;
     g.M = B * ntok; g.N = 3 * D; g.K = D; g.planes = planes; g.epi = EPI_QKV; g.bias = bias;
-    g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.vt = reinterpret_cast<bf16_t*>(vt);
+    g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
     g.qkv_plane = qkv_plane; g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = D; g.qscale = qscale;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int dinoseg_op_attention(const void* q, const void* k, const void* vt, int64_t qkv_plane, void* ctx,
+extern "C" int dinoseg_op_attention(const void* q, const void* k, const void* v, int64_t qkv_plane, void* ctx,
                                     int64_t ctx_plane, float* lse, int32_t B, int32_t heads, int32_t ntok, int32_t npad,
                                     int32_t planes, void* stream) {
     AttnParams a = {};
     a.q = reinterpret_cast<const bf16_t*>(q); a.k = reinterpret_cast<const bf16_t*>(k);
-    a.vt = reinterpret_cast<const bf16_t*>(vt); a.qkv_plane = qkv_plane;
+    a.v = reinterpret_cast<const bf16_t*>(v); a.qkv_plane = qkv_plane;
     a.ctx = reinterpret_cast<bf16_t*>(ctx); a.ctx_plane = ctx_plane; a.lse = lse;
     a.B = B; a.heads = heads; a.ntok = ntok; a.npad = npad; a.planes = planes;
     return launch_attention(a, reinterpret_cast<hipStream_t>(stream));

@@ -10,8 +10,14 @@
 // The K fragment rows are read through the bit-2<->bit-3 swap sigma(i): accumulator registers 8s..8s+7 of a
 // lane half h then hold keys 16s+8h+0..7 in natural order, which is exactly the B-operand fragment of
 // O^T += V^T . P^T -- the probabilities never leave registers (no LDS round trip, no permutes).
-// V is consumed as V^T[d][key] (written transposed by the QKV GEMM epilogue), so both LDS images are plain
-// row tiles.  Q arrives pre-scaled by head_dim^-0.5 * log2(e); exp is v_exp_f32 (2^x).
+// V stays row-major [key][d] like K (same LDS-DMA loader, same swizzled image); the A operand of the PV product
+// (rows = d, k = keys) is read column-wise with gfx950's transposing ds_read_b64_tr_b16 (two reads of 4 keys per
+// fragment).  Q arrives pre-scaled by head_dim^-0.5 * log2(e); exp is v_exp_f32 (2^x).
+//
+// VALU diet (the first version was bound by VALU issue, 193 instructions per 64-key tile and wave, MFMA pipe
+// 43 % busy): the running maximum rides in the score accumulator's initial value, the rescale is deferred behind a
+// threshold, and the row sums are an extra ones-vector MFMA -- what is left per tile is 32 v_exp, 16 v_max3 and
+// 16 v_cvt_pk.
 //
 // PLANES = 2 (parity mode): Q, K, V and P are bf16 hi+lo pairs; each product is 3 MFMAs.
 #include "common.h"
@@ -24,14 +30,30 @@ constexpr int QB = 128;         // query rows per workgroup (4 waves)
 constexpr int KB = 64;          // keys per tile
 constexpr int KV_TILE = 64 * 128;   // [64][64] bf16 slab = 8 KiB
 
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+
+// K/V tile swizzle: chunk ^ (bit1(row) << 2 | (row >> 2) & 3).  Like common.h's swizzle it gives every 16-row
+// ds_read_b128 lane group 16 distinct 16-byte slots (it is a bit permutation of (row>>1)&7), and in addition the
+// 4 key rows of a transposing ds_read_b64_tr_b16 block fall on 4 distinct 64-byte quarters of the bank row
+// (rows r and r+2 differ in chunk bit 2), so the V^T reads are conflict-free too.
+__device__ __forceinline__ int swz2(int row, int chunk) { return chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)); }
+__device__ __forceinline__ int tile_off2(int row, int chunk) { return row * 128 + (swz2(row, chunk) << 4); }
+
 __device__ __forceinline__ int sigma23(int i) {   // swap bits 2 and 3
     return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
+}
+
+// A-operand fragment (8 keys of one d column) from a row-major [key][d] LDS image: two transposing reads
+__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
+    const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)p0);
+    const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)p1);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 template <int PLANES>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE_BYTES = PLANES * 2 * KV_TILE;   // per plane: K slab + V^T slab
+    constexpr int STAGE_BYTES = PLANES * 2 * KV_TILE;   // per plane: K slab + V slab
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,10 +67,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     if (pair >= npairs) return;
 
     const int ntok = p.ntok, npad = p.npad;
-    const long pair_off = (long)pair * npad * 64;       // same element count for Q, K ([npad][64]) and V^T ([64][npad])
+    const long pair_off = (long)pair * npad * 64;       // Q, K, V are [B*H][npad][64]
     const bf16_t* Qg = p.q + pair_off;
     const bf16_t* Kg = p.k + pair_off;
-    const bf16_t* Vg = p.vt + pair_off;
+    const bf16_t* Vg = p.v + pair_off;
 
     // ---- Q fragments (B operand: k = d, col = query) straight from global into registers ----
     int qrow = qt * QB + wave * QW + lr;
@@ -67,12 +89,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int pl = 0; pl < PLANES; ++pl) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int piece = wave * 4 + i;               // 0..7: K rows, 8..15: V^T rows
+                const int piece = wave * 4 + i;               // 0..7: K rows, 8..15: V rows
                 const int row = (piece & 7) * 8 + (lane >> 3);
-                const int c = swz_chunk(row, lane & 7);
-                const bf16_t* src = (piece < 8)
-                    ? Kg + pl * p.qkv_plane + (long)(key0 + row) * 64 + c * 8
-                    : Vg + pl * p.qkv_plane + (long)row * npad + key0 + c * 8;
+                const int c = swz2(row, lane & 7);
+                const bf16_t* src = (piece < 8 ? Kg : Vg) + pl * p.qkv_plane + (long)(key0 + row) * 64 + c * 8;
                 glds16(src, sbase + pl * 2 * KV_TILE + piece * 1024);
             }
         }
@@ -83,7 +103,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    // Softmax state.  m_run is the (log2-domain) reference each row's scores are measured against; it enters the
+    // score MFMA chain as the accumulator's initial value (negm = -m_run in all 16 registers), so S' = S - m_run
+    // costs no VALU.  m_run moves only when a row maximum exceeds it by more than RESCALE_THR (rare after the first
+    // tiles), so the O / l rescale is off the steady-state path.  l is summed by the matrix core (ones . P^T).
+    constexpr float RESCALE_THR = 16.f;     // P <= 2^16: far from fp32 / bf16 overflow
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+    const uint4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
     const int ntiles = (ntok + KB - 1) / KB;
     stage(0, 0);
@@ -91,6 +121,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     __syncthreads();
 
     const int krow_perm = sigma23(lr);
+    // transposed V read (ds_read_b64_tr_b16): within each 16-lane group, lane 4q+p addresses key row q, d columns
+    // 4p..4p+3 of a 4-key x 16-d block and receives column (lane&15) of the 4 keys.  Group g = lane>>4 covers
+    // d = 16*(g&1) + 0..15 of the 32-d block and keys 8*(g>>1) + 0..3 (second read: +4) of the 16-key step.
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_gl = (lane >> 4) & 1;
 
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
@@ -101,11 +135,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         f32x16 sacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+            sacc[kb] = negm;            // C input of the chain: S' = K.Q^T - m_run
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int off = tile_off_bytes(kb * 32 + krow_perm, s * 2 + lh);
+                const int off = tile_off2(kb * 32 + krow_perm, s * 2 + lh);
                 const bf16x8 khi = lds_frag(sb + off);
                 if (PLANES == 2) {
                     const bf16x8 klo = lds_frag(sb + 2 * KV_TILE + off);
@@ -127,30 +160,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
                 }
         }
 
-        // ---- online softmax (log2 domain) ----
+        // ---- online softmax (log2 domain), deferred rescale ----
         float mx = sacc[0][0];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
+        if (t == 0 || __any(mx > RESCALE_THR)) {
+            // everything still measured against the old reference is rescaled exactly once: S', O, l and negm
+            const float delta = (t == 0) ? mx : fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            m_run += delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] -= delta;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] -= delta;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(sacc[kb][r] - m_new);
-                sacc[kb][r] = e;
-                psum += e;
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = __builtin_amdgcn_exp2f(sacc[kb][r]);
 
         // ---- P fragments (B operand: k = key, col = query): registers 8*s2..8*s2+7 of sacc[kb] ----
         bf16x8 pf[PLANES][4];
@@ -167,15 +204,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
                 if (PLANES == 2) pf[PLANES - 1][kb * 2 + s2] = __builtin_bit_cast(bf16x8, lo);
             }
 
-        // ---- O^T[d][q] += V^T . P^T ----
+        // ---- row sums on the matrix core: ones[32 x 16] . P^T gives sum_k P[k][q] in every row (both lane halves) ----
+        {
+            f32x16 lsum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lsum[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                lsum = mfma32(ones, pf[0][ks], lsum);
+                if (PLANES == 2) lsum = mfma32(ones, pf[PLANES - 1][ks], lsum);
+            }
+            l_run += lsum[0];
+        }
+
+        // ---- O^T[d][q] += V^T . P^T  (V^T fragments by transposing LDS reads) ----
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int off = KV_TILE + tile_off_bytes(db * 32 + lr, ks * 2 + lh);
-                const bf16x8 vhi = lds_frag(sb + off);
+                const int krow0 = ks * 16 + lh * 8 + tr_q;
+                const int vch = db * 4 + tr_gl * 2 + (tr_p >> 1);
+                const int off0 = KV_TILE + tile_off2(krow0, vch) + (tr_p & 1) * 8;
+                const int off1 = KV_TILE + tile_off2(krow0 + 4, vch) + (tr_p & 1) * 8;
+                const bf16x8 vhi = tr_frag(sb + off0, sb + off1);
                 if (PLANES == 2) {
-                    const bf16x8 vlo = lds_frag(sb + 2 * KV_TILE + off);
+                    const bf16x8 vlo = tr_frag(sb + 2 * KV_TILE + off0, sb + 2 * KV_TILE + off1);
                     o[db] = mfma32(vlo, pf[0][ks], o[db]);
                     o[db] = mfma32(vhi, pf[PLANES - 1][ks], o[db]);
                 }
@@ -188,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     }
 
     // ---- normalise and write ctx[b*ntok + q][head*64 + d] ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = l_run;      // the MFMA row sum already covers both lane halves
     const float inv = 1.0f / l_tot;
     if (qrow < ntok) {
         const int b = pair / p.heads, head = pair - b * p.heads;

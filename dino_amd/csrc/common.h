@@ -66,7 +66,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact-form GELU 0.5*x*(1+erf(x/sqrt2)) (nn.GELU() default, vision_transformer.py:50,55) with erfc by
+// Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7) written without cancellation:
+//   1 + erf(z) = 2 - t*P(t)*exp(-z^2) for z >= 0,  = t*P(t)*exp(-z^2) for z < 0,  t = 1/(1 + 0.3275911 |z|).
+// ~14 VALU ops (one v_rcp, one v_exp) instead of libm erff's ~60.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float pe = pl * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    return 0.5f * x * (x >= 0.f ? 2.0f - pe : pe);
+}
 
 // XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch, speed only).
 // Gives every XCD a contiguous range of logical ids; bijective for any nwg.

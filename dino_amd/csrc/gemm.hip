@@ -10,6 +10,7 @@
 // with conflict-free ds_read_b128.  PLANES = 2 is the parity mode: every operand is a bf16 hi+lo pair and each
 // product is 3 MFMAs (hi*hi + hi*lo + lo*hi), ~16 mantissa bits with fp32 accumulation.
 // The accumulators are staged through LDS once so every epilogue writes whole rows (coalesced).
+// GELU uses the A&S 7.1.26 erfc form (|err| <= 1.5e-7): libm erff cost more VALU time than the fc1 main loop.
 #include "common.h"
 #include "kernels.h"
 
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        if (kt + 1 < nk && !(p.dbg & 2)) stage(cur ^ 1, kt + 1);
         const char* sb = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -98,45 +99,17 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
         __syncthreads();
     }
 
+    if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;   // ablation: no epilogue (keeps the accumulators live)
     // ---- stage accumulators through LDS: C[128][128] fp32 (64 KiB) ----
     float* C = reinterpret_cast<float*>(smem);
-    const bool vpath = (EPI == EPI_QKV) && (n0 / p.dmodel == 2);   // block-uniform: this tile belongs to V
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wr * 64 + i * 32 + acc_row(r, lh);
-                int col = wc * 64 + j * 32 + lr;
-                if (vpath) col ^= (row & 31);   // conflict-free transposed read below
-                C[row * 128 + col] = acc[i][j][r];
-            }
+            for (int r = 0; r < 16; ++r)
+                C[(wr * 64 + i * 32 + acc_row(r, lh)) * 128 + wc * 64 + j * 32 + lr] = acc[i][j][r];
     __syncthreads();
-
-    if (EPI == EPI_QKV && vpath) {
-        // V^T[b][head][d][tok]: consecutive threads -> consecutive tokens (coalesced 2-byte stores)
-        const int row = tid & 127, cg = tid >> 7;
-        const int gm = m0 + row;
-        if (gm < M) {
-            const int b = gm / p.ntok, tok = gm - b * p.ntok;
-            const int hcol0 = n0 % p.dmodel + cg * 64;      // a 64-column group is exactly one head
-            const int head = hcol0 >> 6;
-            bf16_t* dst = p.vt + ((long)(b * p.heads + head) * 64) * p.npad + tok;
-#pragma unroll 8
-            for (int d = 0; d < 64; ++d) {
-                const int col = cg * 64 + d;
-                const float v = C[row * 128 + (col ^ (row & 31))] + p.bias[n0 + col];
-                const uint32_t hi = pack_bf16x2(v, 0.f);
-                dst[(long)d * p.npad] = (bf16_t)(hi & 0xFFFF);
-                if (PLANES == 2) {
-                    const uint32_t lo = pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f);
-                    dst[p.qkv_plane + (long)d * p.npad] = (bf16_t)(lo & 0xFFFF);
-                }
-            }
-        }
-        return;
-    }
 
     const int c4 = tid & 31, rb = tid >> 5;
     const int gn = n0 + c4 * 4;
@@ -170,12 +143,12 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
             *reinterpret_cast<uint2*>(dst) = hi;
             if (PLANES == 2) *reinterpret_cast<uint2*>(dst + p.out_plane) = lo;
         } else if (EPI == EPI_QKV) {
-            const int which = n0 / p.dmodel;               // 0: Q, 1: K  (V handled above)
+            const int which = n0 / p.dmodel;               // 0: Q, 1: K, 2: V  (block-uniform)
             const int hcol = n0 % p.dmodel + c4 * 4;
             const int head = hcol >> 6, d = hcol & 63;
             const int b = gm / p.ntok, tok = gm - b * p.ntok;
             if (which == 0) v *= p.qscale;
-            bf16_t* dst = (which == 0 ? p.q : p.k) + ((long)(b * p.heads + head) * p.npad + tok) * 64 + d;
+            bf16_t* dst = (which == 0 ? p.q : (which == 1 ? p.k : p.v)) + ((long)(b * p.heads + head) * p.npad + tok) * 64 + d;
             uint2 hi, lo;
             split_bf16x2(v[0], v[1], hi.x, lo.x);
             split_bf16x2(v[2], v[3], hi.y, lo.y);
@@ -201,7 +174,15 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     return 0;
 }
 
-int launch_gemm(const GemmParams& p, hipStream_t s) {
+int launch_gemm(const GemmParams& p0, hipStream_t s) {
+    if (p0.M <= 0) return 0;
+    GemmParams p = p0;
+    p.dbg = options().gemm_dbg;
+    if (options().gemm_big && gemm_big_supported(p)) return launch_gemm_big(p, s);
+    return launch_gemm_small(p, s);
+}
+
+int launch_gemm_small(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0) return 0;
     if (p.N % BN != 0 || p.K % BK != 0 || p.lda % 8 != 0) {
         dinoseg_set_error("gemm: unsupported shape M=%d N=%d K=%d lda=%d (need N%%128==0, K%%64==0)", p.M, p.N, p.K, p.lda);

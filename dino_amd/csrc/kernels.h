@@ -12,7 +12,7 @@ enum GemmEpilogue {
     EPI_RESID = 1,   // out_f32[M,N] += acc + bias            (attn.proj / mlp.fc2 + residual add)
     EPI_GELU = 2,    // out_bf16 planes = gelu_erf(acc + bias) (mlp.fc1)
     EPI_RELU = 3,    // out_bf16 planes = relu(acc + bias)     (head layer_1 / layer_2)
-    EPI_QKV = 4,     // scatter to Q [B,H,Npad,64] (pre-scaled), K [B,H,Npad,64], V^T [B,H,64,Npad]
+    EPI_QKV = 4,     // scatter to Q (pre-scaled), K, V : each [B,H,Npad,64]
     EPI_PATCH = 5,   // token rows: X[b*(n+1)+1+p, :] = acc + bias + pos[1+p, :]
 };
 
@@ -21,20 +21,32 @@ struct GemmParams {
     const bf16_t* A; long a_plane; int lda;     // [planes][M][lda]
     const bf16_t* W; long w_plane;              // [planes][N][K]
     int M, N, K;
+    int n_off;                                  // (gemm_big only) first output column / W row of this launch
+    int dbg;                                    // timing-only ablations: bit0 skip epilogue stores, bit1 skip steady-state loads
     int planes;                                 // 1: bf16 ; 2: bf16 hi+lo split (3 MFMAs per product)
     int epi;
     const float* bias;                          // [N] or null
     float* out_f32; int ldo_f32;                // PLAIN / RESID / PATCH
     bf16_t* out_bf16; long out_plane; int ldo;  // GELU / RELU : [planes][M][ldo]
-    bf16_t* q; bf16_t* k; bf16_t* vt; long qkv_plane;   // QKV
+    bf16_t* q; bf16_t* k; bf16_t* v; long qkv_plane;    // QKV
     int ntok, npad, heads, dmodel; float qscale;
     const float* pos; int n_patches;            // PATCH
 };
-int launch_gemm(const GemmParams& p, hipStream_t s);
+int launch_gemm(const GemmParams& p, hipStream_t s);       // dispatches between the two kernels below
+int launch_gemm_small(const GemmParams& p, hipStream_t s); // 128x128 tile, bf16 or bf16x3 (gemm.hip)
+bool gemm_big_supported(const GemmParams& p);
+int launch_gemm_big(const GemmParams& p, hipStream_t s);   // 256x384 persistent tile, bf16 only (gemm_big.hip)
+
+// tuning knobs (dinoseg_set_option): see api.hip
+struct Options {
+    int gemm_big = 1;        // use gemm_big.hip where it applies
+    int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
+};
+Options& options();
 
 // Flash-style fused multi-head attention, head_dim 64.
 struct AttnParams {
-    const bf16_t* q; const bf16_t* k; const bf16_t* vt; long qkv_plane;  // as written by EPI_QKV
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; long qkv_plane;   // as written by EPI_QKV: [planes][B,H,npad,64]
     bf16_t* ctx; long ctx_plane;       // [planes][B*ntok][heads*64]
     float* lse;                        // optional [B,H,ntok] log2-domain log-sum-exp (for backward), may be null
     int B, heads, ntok, npad, planes;

@@ -88,6 +88,10 @@ enum { DINOSEG_PROF_PATCH = 0, DINOSEG_PROF_LN = 1, DINOSEG_PROF_QKV = 2, DINOSE
 int dinoseg_profile(dinoseg_handle* h, int32_t level);
 int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
 
+/* Process-wide tuning knobs (A/B testing of kernel variants).  Keys: "gemm_big" (1 = use the 256x384
+ * persistent GEMM where it applies [default], 0 = always the 128x128 kernel). */
+int dinoseg_set_option(const char* key, int32_t value);
+
 /* Bytes of library-owned device memory a (B, r) forward needs (activations + packed weights). */
 int64_t dinoseg_workspace_bytes(const dinoseg_handle* h, int32_t B, int32_t r);
 
@@ -103,15 +107,16 @@ int dinoseg_op_gemm(const void* A, int64_t a_plane, int32_t lda, const void* W, 
                     int32_t K, int32_t planes, int32_t epi, const float* bias, float* out_f32, void* out_bf16,
                     int64_t out_plane, int32_t ldo, void* stream);
 
-/* attn.qkv GEMM with the head-scatter epilogue (vision_transformer.py:82): Q [B,H,npad,64] (times qscale),
- * K [B,H,npad,64], V^T [B,H,64,npad]; M = B*ntok rows. */
+/* attn.qkv GEMM with the head-scatter epilogue (vision_transformer.py:82): Q (times qscale), K, V, each
+ * [planes][B,H,npad,64]; M = B*ntok rows. */
 int dinoseg_op_qkv_gemm(const void* A, int64_t a_plane, const void* W, int64_t w_plane, const float* bias, int32_t B,
                         int32_t ntok, int32_t npad, int32_t heads, int32_t planes, float qscale, void* q, void* k,
-                        void* vt, int64_t qkv_plane, void* stream);
+                        void* v, int64_t qkv_plane, void* stream);
 
 /* fused softmax(q k^T) v (vision_transformer.py:85,101,104); q must be pre-scaled by 64^-0.5 * log2(e).
- * ctx: bf16 planes [planes][B*ntok][heads*64]; lse (optional): fp32 [B,heads,ntok], log2 domain. */
-int dinoseg_op_attention(const void* q, const void* k, const void* vt, int64_t qkv_plane, void* ctx, int64_t ctx_plane,
+ * q, k, v: [planes][B,heads,npad,64] (rows >= ntok zero); ctx: bf16 planes [planes][B*ntok][heads*64];
+ * lse (optional): fp32 [B,heads,ntok], log2 domain. */
+int dinoseg_op_attention(const void* q, const void* k, const void* v, int64_t qkv_plane, void* ctx, int64_t ctx_plane,
                          float* lse, int32_t B, int32_t heads, int32_t ntok, int32_t npad, int32_t planes, void* stream);
 
 /* nn.LayerNorm over the last dim (vision_transformer.py:303).  out_bf16 / out_f32 may each be NULL. */

@@ -35,8 +35,12 @@ def test_pack_padding(cuda):
 
 
 @pytest.mark.parametrize("planes", [1, 2])
-@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (128, 128, 64), (1, 128, 384), (515, 384, 1536)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (128, 128, 64), (1, 128, 384), (515, 384, 1536),
+                                   (300, 384, 192), (1000, 768, 64), (25613, 1152, 96), (257, 384, 32)])
 def test_gemm_plain(cuda, planes, M, N, K):
+    # N % 384 == 0 with planes == 1 runs the 256x384 persistent kernel (gemm_big.hip), everything else gemm.hip
+    if planes == 2 and K % 64 != 0:
+        pytest.skip("the 128x128 kernel needs K % 64 == 0")
     # asymmetric operands: a transposed / permuted fragment map cannot pass
     A = seeded((M, K), 10 + M) + torch.arange(K, device="cuda", dtype=torch.float32)[None, :] * 1e-3
     W = seeded((N, K), 20 + N) * 0.1 + torch.arange(N, device="cuda", dtype=torch.float32)[:, None] * 1e-3
@@ -57,8 +61,9 @@ def test_gemm_plain(cuda, planes, M, N, K):
 
 
 @pytest.mark.parametrize("planes", [1, 2])
-def test_gemm_epilogues(cuda, planes):
-    M, N, K = 261, 256, 128
+@pytest.mark.parametrize("N", [256, 384])
+def test_gemm_epilogues(cuda, planes, N):
+    M, K = 261, 128
     A, W, bias = seeded((M, K), 1), seeded((N, K), 2) * 0.2, seeded((N,), 3)
     Ap, Wp = pack(A, planes), pack(W, planes)
     base = (quant_like(A, planes).double() @ quant_like(W, planes).double().t() + bias.double()).float()
@@ -81,15 +86,16 @@ def test_gemm_epilogues(cuda, planes):
 
 
 @pytest.mark.parametrize("planes", [1, 2])
-def test_qkv_gemm_layout(cuda, planes):
-    B, ntok, H = 2, 197, 2
-    D, npad = H * 64, 256
+@pytest.mark.parametrize("H,ntok", [(2, 197), (6, 197), (6, 65)])
+def test_qkv_gemm_layout(cuda, planes, H, ntok):
+    B = 2
+    D, npad = H * 64, (ntok + 63) // 64 * 64
     A, W, bias = seeded((B * ntok, D), 5), seeded((3 * D, D), 6) * 0.1, seeded((3 * D,), 7)
     Ap, Wp = pack(A, planes), pack(W, planes)
     plane = B * H * npad * 64
     q = torch.zeros((planes, B, H, npad, 64), dtype=torch.int16, device="cuda")
     k = torch.zeros_like(q)
-    vt = torch.zeros((planes, B, H, 64, npad), dtype=torch.int16, device="cuda")
+    vt = torch.zeros_like(q)
     qscale = 0.125 * LOG2E
     capi.check(capi.lib().dinoseg_op_qkv_gemm(Ap.data_ptr(), B * ntok * D, Wp.data_ptr(), 3 * D * D, bias.data_ptr(), B,
                                               ntok, npad, H, planes, qscale, q.data_ptr(), k.data_ptr(), vt.data_ptr(),
@@ -100,8 +106,8 @@ def test_qkv_gemm_layout(cuda, planes):
     gq, gk, gv = unpack(q), unpack(k), unpack(vt)
     assert float((gq[:, :, :ntok] - ref[0] * qscale).abs().max()) <= tol
     assert float((gk[:, :, :ntok] - ref[1]).abs().max()) <= tol
-    assert float((gv[:, :, :, :ntok] - ref[2].transpose(-1, -2)).abs().max()) <= tol
-    assert torch.all(gq[:, :, ntok:] == 0) and torch.all(gk[:, :, ntok:] == 0) and torch.all(gv[:, :, :, ntok:] == 0)
+    assert float((gv[:, :, :ntok] - ref[2]).abs().max()) <= tol
+    assert torch.all(gq[:, :, ntok:] == 0) and torch.all(gk[:, :, ntok:] == 0) and torch.all(gv[:, :, ntok:] == 0)
 
 
 def _attention_case(B, H, ntok, planes, seed, spike=False):
@@ -122,7 +128,7 @@ def _attention_case(B, H, ntok, planes, seed, spike=False):
 
     qp = planes_of(qs, (B, H, npad, 64))
     kp = planes_of(K, (B, H, npad, 64))
-    vp = planes_of(V.transpose(-1, -2).contiguous(), (B, H, 64, npad))
+    vp = planes_of(V, (B, H, npad, 64))
     ctx = torch.zeros((planes, B * ntok, H * 64), dtype=torch.int16, device="cuda")
     lse = torch.zeros((B, H, ntok), dtype=torch.float32, device="cuda")
     capi.check(capi.lib().dinoseg_op_attention(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), B * H * npad * 64,
@@ -132,7 +138,7 @@ def _attention_case(B, H, ntok, planes, seed, spike=False):
     # fp64 reference on the operands the kernel saw
     qq = unpack(qp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu() / LOG2E
     kk = unpack(kp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu()
-    vv = unpack(vp).reshape(B, H, 64, npad)[:, :, :, :ntok].double().cpu().transpose(-1, -2)
+    vv = unpack(vp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu()
     s = qq @ kk.transpose(-1, -2)
     p = torch.softmax(s, dim=-1)
     ref = (p @ vv).transpose(1, 2).reshape(B * ntok, H * 64).float()
@@ -148,7 +154,8 @@ def test_attention(cuda, planes, B, H, ntok):
     tol = 1.2e-2 if planes == 1 else 1e-4      # bf16 probabilities vs hi+lo split
     assert torch.isfinite(got).all()
     assert float((got - ref).abs().max()) <= tol
-    assert float((lse - ref_lse).abs().max()) <= 1e-3
+    # l is summed on the matrix core from the bf16(/hi+lo) probabilities: ~2^-9 (2^-16) relative on l
+    assert float((lse - ref_lse).abs().max()) <= (6e-3 if planes == 1 else 1e-4)
 
 
 @pytest.mark.parametrize("planes", [1, 2])
@@ -221,3 +228,20 @@ def test_head_final(cuda, C, K, ld):
     ref = torch.log_softmax(z, dim=1)
     assert float((logp.cpu() - ref).abs().max()) <= 2e-5
     assert torch.equal(am.cpu().long(), ref.argmax(dim=1))
+
+
+def test_gemm_big_matches_small_kernel(cuda):
+    """Same operands through both GEMM kernels (dinoseg_set_option('gemm_big', 0/1)): identical up to fp32 summation order."""
+    M, N, K = 3000, 1152, 384
+    A, W, bias = seeded((M, K), 31), seeded((N, K), 32) * 0.1, seeded((N,), 33)
+    Ap, Wp = pack(A, 1), pack(W, 1)
+    lib = capi.lib()
+    outs = []
+    for big in (0, 1):
+        capi.check(lib.dinoseg_set_option(b"gemm_big", big))
+        out = torch.zeros((M, N), device="cuda")
+        capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, 1, capi.EPI_PLAIN,
+                                       bias.data_ptr(), out.data_ptr(), None, 0, 0, S()))
+        outs.append(out)
+    capi.check(lib.dinoseg_set_option(b"gemm_big", 1))
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * float(outs[0].abs().max())

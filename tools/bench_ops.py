@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Operator micro-benchmarks on the GPU box (called through the C-ABI, timed with events on the launch stream).
+
+    python tools/bench_ops.py gemm      # the four DINOSeg GEMM shapes, both kernels, with timing ablations
+    python tools/bench_ops.py attn      # fused attention at the benchmark shape
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from dino_amd import capi  # noqa: E402
+
+LOG2E = 1.4426950408889634
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def rand_bf16(shape):
+    return (torch.randn(shape, device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
+
+
+def bench_gemm():
+    lib = capi.lib()
+    B, ntok, D = 32, 3601, 384
+    M = B * ntok
+    shapes = [("qkv", 3 * D, D, "qkv"), ("proj", D, D, capi.EPI_RESID), ("fc1", 4 * D, D, capi.EPI_GELU),
+              ("fc2", D, 4 * D, capi.EPI_RESID)]
+    npad = (ntok + 63) // 64 * 64
+    for name, N, K, epi in shapes:
+        A, W = rand_bf16((M, K)), rand_bf16((N, K))
+        bias = torch.randn(N, device="cuda")
+        X = torch.zeros((M, N), device="cuda") if epi == capi.EPI_RESID else None
+        O = torch.zeros((M, N), dtype=torch.int16, device="cuda") if epi == capi.EPI_GELU else None
+        if epi == "qkv":
+            q = torch.zeros((B, 6, npad, 64), dtype=torch.int16, device="cuda")
+            k, vt = torch.zeros_like(q), torch.zeros_like(q)
+        for big in (0, 1):
+            for dbg in (0, 1, 2, 3):
+                capi.check(lib.dinoseg_set_option(b"gemm_big", big))
+                capi.check(lib.dinoseg_set_option(b"gemm_dbg", dbg))
+
+                def run():
+                    if epi == "qkv":
+                        capi.check(lib.dinoseg_op_qkv_gemm(A.data_ptr(), M * K, W.data_ptr(), N * K, bias.data_ptr(), B, ntok,
+                                                           npad, 6, 1, 0.125 * LOG2E, q.data_ptr(), k.data_ptr(), vt.data_ptr(),
+                                                           B * 6 * npad * 64, capi.stream_ptr()))
+                    else:
+                        capi.check(lib.dinoseg_op_gemm(A.data_ptr(), M * K, K, W.data_ptr(), N * K, M, N, K, 1, epi,
+                                                       bias.data_ptr(), capi.ptr(X), capi.ptr(O), M * N, N, capi.stream_ptr()))
+                ms = timeit(run)
+                tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+                print(f"{name:5s} N={N:5d} K={K:5d} kernel={'big  ' if big else 'small'} dbg={dbg} "
+                      f"(skip epilogue={dbg & 1}, skip loads={(dbg >> 1) & 1}): {ms * 1e3:8.1f} us  {tf:7.1f} TFLOP/s", flush=True)
+    lib.dinoseg_set_option(b"gemm_big", 1)
+    lib.dinoseg_set_option(b"gemm_dbg", 0)
+
+
+def bench_attn():
+    lib = capi.lib()
+    B, H, ntok = 32, 6, 3601
+    npad = (ntok + 63) // 64 * 64
+    for planes in (1, 2):
+        q = rand_bf16((planes, B, H, npad, 64))
+        k = rand_bf16((planes, B, H, npad, 64))
+        vt = rand_bf16((planes, B, H, npad, 64))
+        vt[..., ntok:, :] = 0
+        ctx = torch.zeros((planes, B * ntok, H * 64), dtype=torch.int16, device="cuda")
+
+        def run():
+            capi.check(lib.dinoseg_op_attention(q.data_ptr(), k.data_ptr(), vt.data_ptr(), B * H * npad * 64, ctx.data_ptr(),
+                                                B * ntok * H * 64, None, B, H, ntok, npad, planes, capi.stream_ptr()))
+        ms = timeit(run)
+        fl = 4.0 * B * H * ntok * ntok * 64
+        print(f"attention planes={planes}: {ms * 1e3:8.1f} us  {fl / (ms * 1e-3) / 1e12:7.1f} TFLOP/s (algorithmic)", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
+    {"gemm": bench_gemm, "attn": bench_attn}[what]()

@@ -1,0 +1,22 @@
+#!/bin/bash
+# bash tools/pmc_ops.sh <tag> "<COUNTER ...>" <bench_ops.py args...>   (GPU box; counters in their own pass, kernel-trace only)
+set -o pipefail
+TAG=$1; CTRS=$2; shift 2
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT -o ops -- python3 $ROOT/tools/bench_ops.py "$@" > $OUT/run.log 2>&1 || { tail -20 $OUT/run.log; exit 1; }
+grep -v amdgpu $OUT/run.log | tail -5
+python3 - <<PY
+import csv, collections
+rows = list(csv.DictReader(open("$OUT/ops_counter_collection.csv")))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    if "dseg::" in r["Kernel_Name"]:
+        agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    print(k, {c: round(sum(v) / len(v)) for c, v in d.items()}, "n=%d" % len(next(iter(d.values()))))
+PY
+rm -f $OUT/ops_kernel_trace.csv
