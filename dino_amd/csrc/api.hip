@@ -9,9 +9,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/dinoseg.h"
-#include "common.h"
-#include "kernels.h"
+#include "handle.h"
 
 using namespace dseg;
 
@@ -27,76 +25,7 @@ extern "C" void dinoseg_set_error(const char* fmt, ...) {
 extern "C" const char* dinoseg_last_error(void) { return g_err; }
 extern "C" int dinoseg_version(void) { return 100; }
 
-#define DSEG_TRY(expr)            \
-    do {                          \
-        int _rc = (expr);         \
-        if (_rc != 0) return _rc; \
-    } while (0)
 
-// ------------------------------------------------------------------------------------------------ handle
-struct BoundTensor {
-    const float* ptr = nullptr;
-    std::vector<int64_t> shape;
-};
-
-struct PackedLinear {       // W[N,K] operand planes of one nn.Linear, padded to the GEMM tile
-    bf16_t* w = nullptr;
-    long plane = 0;
-    int n_pad = 0, k_pad = 0;
-    float* bias_pad = nullptr;   // only when N was padded (head layers); else the bound bias is used
-};
-
-struct dinoseg_handle {
-    dinoseg_config cfg;
-    int planes;
-    std::map<std::string, BoundTensor> bound;
-    std::map<std::string, std::vector<int64_t>> expected;
-    // packed weights (library-owned)
-    char* wbuf = nullptr;
-    size_t wbuf_bytes = 0;
-    std::map<std::string, PackedLinear> packed;
-    bool weights_ready = false;
-    // pos-embed cache
-    float* pos_cache = nullptr;
-    int pos_r = -1;
-    size_t pos_cap = 0;
-    // activation workspace (library-owned)
-    char* ws = nullptr;
-    size_t ws_bytes = 0;
-    int ws_B = -1, ws_r = -1;
-    // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
-    int prof_level = 0;                    // 0 off, 1 attention only, 2 every class
-    struct ProfRec { int cat; hipEvent_t a, b; };
-    std::vector<ProfRec> prof_recs;
-    std::vector<hipEvent_t> prof_pool;
-};
-
-static int prof_begin(dinoseg_handle* h, int cat, hipStream_t s) {
-    if (h->prof_level == 0 || (h->prof_level == 1 && cat != DINOSEG_PROF_ATTN)) return -1;
-    hipEvent_t ev[2];
-    for (int i = 0; i < 2; ++i) {
-        if (!h->prof_pool.empty()) {
-            ev[i] = h->prof_pool.back();
-            h->prof_pool.pop_back();
-        } else if (hipEventCreate(&ev[i]) != hipSuccess) {
-            return -1;
-        }
-    }
-    h->prof_recs.push_back({cat, ev[0], ev[1]});
-    (void)hipEventRecord(ev[0], s);
-    return (int)h->prof_recs.size() - 1;
-}
-static void prof_end(dinoseg_handle* h, int idx, hipStream_t s) {
-    if (idx >= 0) (void)hipEventRecord(h->prof_recs[idx].b, s);
-}
-#define DSEG_PROF(cat, stmt)                  \
-    do {                                      \
-        const int _pi = prof_begin(h, cat, s); \
-        stmt;                                 \
-        prof_end(h, _pi, s);                  \
-    } while (0)
-
-static int head_planes() { return 2; }   // the classifier head always runs in split precision (it is tiny)
 
 static void add_expected(dinoseg_handle* h) {
     const dinoseg_config& c = h->cfg;
@@ -162,6 +91,7 @@ extern "C" int dinoseg_destroy(dinoseg_handle* h) {
     if (h->wbuf) (void)hipFree(h->wbuf);
     if (h->pos_cache) (void)hipFree(h->pos_cache);
     if (h->ws) (void)hipFree(h->ws);
+    (void)dinoseg_train_release(h);
     for (auto& r : h->prof_recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -198,9 +128,7 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
     return 0;
 }
 
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static const float* W(const dinoseg_handle* h, const std::string& k) { return h->bound.at(k).ptr; }
 
 // names of every nn.Linear-shaped weight that feeds gemm.hip, with its logical [N, K] and padded [n_pad, k_pad]
 struct LinSpec {
@@ -365,16 +293,6 @@ static int ensure_workspace(dinoseg_handle* h, const WsLayout& L, int B, int r, 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-static const float kImagenetMean[3] = {0.485f, 0.456f, 0.406f};
-static const float kImagenetStd[3] = {0.229f, 0.224f, 0.225f};
-
-static void norm_consts(float mean255[3], float inv255[3]) {
-    for (int c = 0; c < 3; ++c) {
-        mean255[c] = kImagenetMean[c] * 255.0f;          // albumentations: mean * max_pixel_value (fp32)
-        inv255[c] = 1.0f / (kImagenetStd[c] * 255.0f);   // reciprocal of std * max_pixel_value (fp32)
-    }
-}
-
 extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
                                int32_t* argmax_out, int32_t tap_block, float* tap_out, void* stream) {
     if (!h || !x || B <= 0) {

@@ -81,6 +81,20 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (x >= 0.f ? 2.0f - pe : pe);
 }
 
+// d/dx of the exact GELU: Phi(x) + x * phi(x), same erfc approximation (shares the exponential).
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);   // exp(-x^2/2)
+    const float pe = pl * t * e;
+    const float cdf = x >= 0.f ? 1.0f - 0.5f * pe : 0.5f * pe;
+    return fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
 // XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch, speed only).
 // Gives every XCD a contiguous range of logical ids; bijective for any nwg.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

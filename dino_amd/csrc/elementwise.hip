@@ -31,6 +31,29 @@ int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long p
     return 0;
 }
 
+// transposed variant: dst[pl][c][r] = src[r][c]   (W^T operand planes for the input-gradient GEMMs)
+__global__ void pack_planes_t_kernel(const float* __restrict__ src, int rows, int cols, bf16_t* __restrict__ dst,
+                                     long plane, int rows_pad, int cols_pad, int planes) {
+    const long total = (long)rows_pad * cols_pad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i / rows_pad), r = (int)(i - (long)c * rows_pad);
+        const float v = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+        const uint32_t hi = pack_bf16x2(v, 0.f);
+        dst[i] = (bf16_t)(hi & 0xFFFF);
+        if (planes == 2) dst[plane + i] = (bf16_t)(pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
+    }
+}
+
+int launch_pack_planes_t(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,
+                         int planes, hipStream_t s) {
+    const long total = (long)rows_pad * cols_pad;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(pack_planes_t_kernel, dim3(grid), dim3(256), 0, s, src, rows, cols, dst, plane, rows_pad, cols_pad, planes);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm (nn.LayerNorm(D, eps=1e-6): vision_transformer.py:303; uses :114,:118,:183).
 // One wavefront per row; the row lives in registers (D/128 float2 per lane); mean, then the biased variance

@@ -64,14 +64,21 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = K / BK;
-    stage(0, 0);
+    const int nk_all = K / BK;
+    int kt_begin = 0, nk = nk_all;
+    if (p.ksplit > 1) {     // grid.y slices of the K loop (weight gradients: K = rows of the batch)
+        const int per = (nk_all + p.ksplit - 1) / p.ksplit;
+        kt_begin = blockIdx.y * per;
+        nk = nk_all - kt_begin < per ? nk_all - kt_begin : per;
+        if (nk <= 0) return;
+    }
+    stage(0, kt_begin);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk && !(p.dbg & 2)) stage(cur ^ 1, kt + 1);
+        if (kt + 1 < nk && !(p.dbg & 2)) stage(cur ^ 1, kt_begin + kt + 1);
         const char* sb = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -126,14 +133,49 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
             *reinterpret_cast<f32x4*>(p.out_f32 + (long)gm * p.ldo_f32 + gn) = v;
         } else if (EPI == EPI_RESID) {
             float* dst = p.out_f32 + (long)gm * p.ldo_f32 + gn;
-            f32x4 x = *reinterpret_cast<const f32x4*>(dst);
+            const float* src = p.resid ? p.resid + (long)gm * p.ldo_f32 + gn : dst;
+            f32x4 x = *reinterpret_cast<const f32x4*>(src);
             *reinterpret_cast<f32x4*>(dst) = x + v;
+        } else if (EPI == EPI_ATOMIC) {
+            float* dst = p.out_f32 + (long)gm * p.ldo_f32 + gn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (p.n_valid == 0 || gn + e < p.n_valid) atomicAdd(dst + e, v[e]);
+        } else if (EPI == EPI_BF16 || EPI == EPI_DGELU || EPI == EPI_DRELU) {
+            if (EPI != EPI_BF16) {
+                const bf16_t* ax = p.aux_in + (long)gm * p.ldo + gn;
+                const uint2 ah = *reinterpret_cast<const uint2*>(ax);
+                float a[4] = {bf16_lo_to_f32(ah.x), bf16_hi_to_f32(ah.x), bf16_lo_to_f32(ah.y), bf16_hi_to_f32(ah.y)};
+                if (PLANES == 2 && EPI == EPI_DGELU) {
+                    const uint2 al = *reinterpret_cast<const uint2*>(ax + p.aux_plane);
+                    a[0] += bf16_lo_to_f32(al.x);
+                    a[1] += bf16_hi_to_f32(al.x);
+                    a[2] += bf16_lo_to_f32(al.y);
+                    a[3] += bf16_hi_to_f32(al.y);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (EPI == EPI_DGELU) ? gelu_erf_grad(a[e]) : (a[e] > 0.f ? 1.f : 0.f);
+            }
+            bf16_t* dst = p.out_bf16 + (long)gm * p.ldo + gn;
+            uint2 hi, lo;
+            split_bf16x2(v[0], v[1], hi.x, lo.x);
+            split_bf16x2(v[2], v[3], hi.y, lo.y);
+            *reinterpret_cast<uint2*>(dst) = hi;
+            if (PLANES == 2) *reinterpret_cast<uint2*>(dst + p.out_plane) = lo;
         } else if (EPI == EPI_PATCH) {
             const int b = gm / p.n_patches, pi = gm - b * p.n_patches;
             const long xrow = (long)b * (p.n_patches + 1) + 1 + pi;
             f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (long)(1 + pi) * p.ldo_f32 + gn);
             *reinterpret_cast<f32x4*>(p.out_f32 + xrow * p.ldo_f32 + gn) = v + pe;
         } else if (EPI == EPI_GELU || EPI == EPI_RELU) {
+            if (EPI == EPI_GELU && p.aux_out) {        // training: keep the pre-activation for gelu'
+                bf16_t* ad = p.aux_out + (long)gm * p.ldo + gn;
+                uint2 ph, plo;
+                split_bf16x2(v[0], v[1], ph.x, plo.x);
+                split_bf16x2(v[2], v[3], ph.y, plo.y);
+                *reinterpret_cast<uint2*>(ad) = ph;
+                if (PLANES == 2) *reinterpret_cast<uint2*>(ad + p.aux_plane) = plo;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (EPI == EPI_GELU) ? gelu_erf(v[e]) : fmaxf(v[e], 0.f);
             bf16_t* dst = p.out_bf16 + (long)gm * p.ldo + gn;
@@ -169,7 +211,7 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<PLANES, EPI>), dim3(grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<PLANES, EPI>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3(256), lds, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -200,6 +242,10 @@ int launch_gemm_small(const GemmParams& p, hipStream_t s) {
     DSEG_CASE(1, EPI_RELU) DSEG_CASE(2, EPI_RELU)
     DSEG_CASE(1, EPI_QKV) DSEG_CASE(2, EPI_QKV)
     DSEG_CASE(1, EPI_PATCH) DSEG_CASE(2, EPI_PATCH)
+    DSEG_CASE(1, EPI_BF16) DSEG_CASE(2, EPI_BF16)
+    DSEG_CASE(1, EPI_ATOMIC) DSEG_CASE(2, EPI_ATOMIC)
+    DSEG_CASE(1, EPI_DGELU) DSEG_CASE(2, EPI_DGELU)
+    DSEG_CASE(1, EPI_DRELU) DSEG_CASE(2, EPI_DRELU)
 #undef DSEG_CASE
     dinoseg_set_error("gemm: bad planes/epilogue %d/%d", p.planes, p.epi);
     return -1;

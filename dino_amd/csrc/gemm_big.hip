@@ -268,7 +268,8 @@ static int launch_big_one(const GemmParams& p, hipStream_t s) {
 }
 
 bool gemm_big_supported(const GemmParams& p) {
-    return p.planes == 1 && p.bias != nullptr && p.epi != EPI_PATCH && p.N % big::BN == 0 && p.K % big::BK == 0 && p.lda % 8 == 0 && p.M >= 1 &&
+    return p.planes == 1 && p.bias != nullptr && p.epi <= EPI_QKV && p.resid == nullptr && p.aux_out == nullptr &&
+           p.ksplit <= 1 && p.N % big::BN == 0 && p.K % big::BK == 0 && p.lda % 8 == 0 && p.M >= 1 &&
            (p.epi != EPI_QKV || (p.dmodel % big::BN == 0 && p.N == 3 * p.dmodel));
 }
 

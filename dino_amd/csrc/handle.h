@@ -1,0 +1,100 @@
+// Internal: the handle behind the C-ABI (shared by api.hip and train_api.hip).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dinoseg.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace dseg;   // internal header: only included by the two API translation units
+
+#define DSEG_TRY(expr)            \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ handle
+struct BoundTensor {
+    const float* ptr = nullptr;
+    std::vector<int64_t> shape;
+};
+
+struct PackedLinear {       // W[N,K] operand planes of one nn.Linear, padded to the GEMM tile
+    bf16_t* w = nullptr;
+    long plane = 0;
+    int n_pad = 0, k_pad = 0;
+    float* bias_pad = nullptr;   // only when N was padded (head layers); else the bound bias is used
+};
+
+struct dinoseg_handle {
+    dinoseg_config cfg;
+    int planes;
+    std::map<std::string, BoundTensor> bound;
+    std::map<std::string, std::vector<int64_t>> expected;
+    // packed weights (library-owned)
+    char* wbuf = nullptr;
+    size_t wbuf_bytes = 0;
+    std::map<std::string, PackedLinear> packed;
+    bool weights_ready = false;
+    // pos-embed cache
+    float* pos_cache = nullptr;
+    int pos_r = -1;
+    size_t pos_cap = 0;
+    // activation workspace (library-owned)
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int ws_B = -1, ws_r = -1;
+    // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
+    // fine-tune step state (train_api.hip)
+    std::map<std::string, float*> grads;   // bound gradient buffers (absent / null = frozen tensor)
+    char* tws = nullptr;                   // training workspace: saved activations + backward scratch
+    size_t tws_bytes = 0;
+    int tws_B = -1, tws_r = -1;
+    char* twbuf = nullptr;                 // transposed packed weights for the input-gradient GEMMs
+    size_t twbuf_bytes = 0;
+    int prof_level = 0;                    // 0 off, 1 attention only, 2 every class
+    struct ProfRec { int cat; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+};
+
+static inline int prof_begin(dinoseg_handle* h, int cat, hipStream_t s) {
+    if (h->prof_level == 0 || (h->prof_level == 1 && cat != DINOSEG_PROF_ATTN)) return -1;
+    hipEvent_t ev[2];
+    for (int i = 0; i < 2; ++i) {
+        if (!h->prof_pool.empty()) {
+            ev[i] = h->prof_pool.back();
+            h->prof_pool.pop_back();
+        } else if (hipEventCreate(&ev[i]) != hipSuccess) {
+            return -1;
+        }
+    }
+    h->prof_recs.push_back({cat, ev[0], ev[1]});
+    (void)hipEventRecord(ev[0], s);
+    return (int)h->prof_recs.size() - 1;
+}
+static inline void prof_end(dinoseg_handle* h, int idx, hipStream_t s) {
+    if (idx >= 0) (void)hipEventRecord(h->prof_recs[idx].b, s);
+}
+#define DSEG_PROF(cat, stmt)                  \
+    do {                                      \
+        const int _pi = prof_begin(h, cat, s); \
+        stmt;                                 \
+        prof_end(h, _pi, s);                  \
+    } while (0)
+
+
+static inline int head_planes() { return 2; }   // the classifier head always runs in split precision (it is tiny)
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline const float* W(const dinoseg_handle* h, const std::string& k) { return h->bound.at(k).ptr; }
+static inline void norm_consts(float mean255[3], float inv255[3]) {
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c) {
+        mean255[c] = mean[c] * 255.0f;          // albumentations: mean * max_pixel_value (fp32)
+        inv255[c] = 1.0f / (sd[c] * 255.0f);    // reciprocal of std * max_pixel_value (fp32)
+    }
+}
+int dinoseg_train_release(dinoseg_handle* h);   // train_api.hip: frees the training workspace

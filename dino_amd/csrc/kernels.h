@@ -14,6 +14,11 @@ enum GemmEpilogue {
     EPI_RELU = 3,    // out_bf16 planes = relu(acc + bias)     (head layer_1 / layer_2)
     EPI_QKV = 4,     // scatter to Q (pre-scaled), K, V : each [B,H,Npad,64]
     EPI_PATCH = 5,   // token rows: X[b*(n+1)+1+p, :] = acc + bias + pos[1+p, :]
+    // --- backward / training (gemm.hip only) ---
+    EPI_BF16 = 6,    // out_bf16 planes = acc (+ bias)
+    EPI_ATOMIC = 7,  // out_f32 += acc by fp32 atomics (split-K weight gradients; out must be zeroed)
+    EPI_DGELU = 8,   // out_bf16 planes = acc * gelu'(aux_in)   (aux_in = saved fc1 pre-activation planes)
+    EPI_DRELU = 9,   // out_bf16 planes = acc * (aux_in > 0)    (aux_in = saved post-ReLU activation planes)
 };
 
 // C[M,N] = A[M,K] . W[N,K]^T  (both operands K-contiguous, bf16 hi(/lo) planes, fp32 accumulate)
@@ -22,6 +27,7 @@ struct GemmParams {
     const bf16_t* W; long w_plane;              // [planes][N][K]
     int M, N, K;
     int n_off;                                  // (gemm_big only) first output column / W row of this launch
+    int n_valid;                                // ATOMIC: only columns < n_valid are written (0 = all N)
     int dbg;                                    // timing-only ablations: bit0 skip epilogue stores, bit1 skip steady-state loads
     int planes;                                 // 1: bf16 ; 2: bf16 hi+lo split (3 MFMAs per product)
     int epi;
@@ -31,6 +37,10 @@ struct GemmParams {
     bf16_t* q; bf16_t* k; bf16_t* v; long qkv_plane;    // QKV
     int ntok, npad, heads, dmodel; float qscale;
     const float* pos; int n_patches;            // PATCH
+    const float* resid;                         // RESID: out = resid + acc + bias (null: in place on out_f32)
+    bf16_t* aux_out;                            // GELU: also save the pre-activation planes here (training), ld = ldo
+    const bf16_t* aux_in; long aux_plane;       // DGELU / DRELU operand planes [planes][M][ldo]; also plane stride of aux_out
+    int ksplit;                                 // >1: split the K loop over grid.y (use with EPI_ATOMIC)
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);       // dispatches between the two kernels below
 int launch_gemm_small(const GemmParams& p, hipStream_t s); // 128x128 tile, bf16 or bf16x3 (gemm.hip)
@@ -77,6 +87,30 @@ int launch_pos_resample(const float* pos_embed, int g, int D, int o, float* out,
 int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, const float* W, const float* b, int C,
                       float* logp, int32_t* argmax, hipStream_t s);
 
-int init_kernel_attributes();
+// ---- fine-tune step (train.hip, attention_bwd.hip) ----
+struct AttnBwdParams {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; long qkv_plane;   // forward operands [planes][B,H,npad,64]
+    const bf16_t* dO; const bf16_t* O; long dO_plane;                      // d ctx and ctx, [planes][B*ntok][H*64]
+    const float* lse;                                                      // forward log2-domain LSE [B,H,ntok]
+    float* neg_lse; float* neg_delta;                                      // scratch [B,H,npad] each
+    bf16_t* dqkv; long dqkv_plane;                                         // out: [planes][B*ntok][3*H*64]
+    int B, heads, ntok, npad, planes;
+};
+int launch_attention_bwd(const AttnBwdParams& p, hipStream_t s);
+
+int launch_transpose_planes(const float* src_f32, const bf16_t* src_pl, long src_plane, int ld_src, int M, int C,
+                            bf16_t* T, long t_plane, int c_pad, int m_pad, bf16_t* Nout, long n_plane, int ldn,
+                            float* colsum, int planes, int drop_cls, int ntok, hipStream_t s);
+int launch_nll_loss_grad(const float* logp, const int64_t* labels, int M, int C, float* loss, bf16_t* dz, long dz_plane,
+                         int ldz, hipStream_t s);
+int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int M, int D, float* dx,
+                         int accumulate, float* dgamma, float* dbeta, int drop_cls, int ntok, hipStream_t s);
+int launch_batch_sum_rows(const float* X, int B, int ntok, int D, float* out, hipStream_t s);
+int launch_pos_resample_bwd(const float* dpos, int g, int D, int o, float* dpe, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
+                int decoupled, int step, float gscale, hipStream_t s);
+// fp32 [rows, cols] -> TRANSPOSED bf16 planes [planes][cols_pad][rows_pad] (zero padded): W^T operands for dgrad
+int launch_pack_planes_t(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,
+                         int planes, hipStream_t s);
 
 }  // namespace dseg

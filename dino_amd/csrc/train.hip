@@ -1,0 +1,381 @@
+// Backward / optimiser helper kernels of the DINOSeg fine-tune step (gfx950).
+// Replaces autograd's nll_loss_backward / _log_softmax_backward_data / native_layer_norm_backward /
+// upsample_bicubic2d_backward / sum (bias grads) and the Adam(W) step (SURVEY.md §2.1 "bwd" row;
+// reference call sites pl_torch_modules.py:258-268).  The GEMM-shaped parts of the backward (dgrad / wgrad) run on
+// gemm.hip; weight gradients use operands transposed by transpose_planes_kernel so that the contraction over the
+// batch rows is K-contiguous for the same NT MFMA kernel (split-K + fp32 atomics).
+#include "common.h"
+#include "kernels.h"
+
+namespace dseg {
+
+// ------------------------------------------------------------------------------------------------
+// [M][C] (fp32, or bf16 hi/lo planes) -> transposed planes T[pl][c][m] with c < c_pad rows and m < m_pad columns
+// (zero filled beyond C / M), optionally also the row-major planes N[pl][m][c] and the column sums (bias gradients).
+// drop_cls: logical row j = b*(ntok-1)+t-1 is read from physical row b*ntok+t (t >= 1) of the source.
+__global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __restrict__ src_f32,
+                                                               const bf16_t* __restrict__ src_pl, long src_plane, int lds_,
+                                                               int M, int C, bf16_t* __restrict__ T, long t_plane, int m_pad,
+                                                               bf16_t* __restrict__ Nout, long n_plane, int ldn,
+                                                               float* __restrict__ colsum, int planes, int drop_cls, int ntok) {
+    __shared__ uint16_t th[64][66], tl[64][66];
+    __shared__ float cs[4][64];
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float csum = 0.f;
+    const int c = c0 + tx;
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+        const int ml = ty * 16 + rr, m = m0 + ml;
+        uint16_t hi = 0, lo = 0;
+        if (m < M && c < C) {
+            long prow = m;
+            if (drop_cls) {
+                const int b = m / (ntok - 1), t = m - b * (ntok - 1);
+                prow = (long)b * ntok + t + 1;
+            }
+            float v;
+            if (src_f32) {
+                v = src_f32[prow * lds_ + c];
+                const uint32_t h2 = pack_bf16x2(v, 0.f);
+                hi = (uint16_t)(h2 & 0xFFFF);
+                lo = (uint16_t)(pack_bf16x2(v - bf16_lo_to_f32(h2), 0.f) & 0xFFFF);
+            } else {
+                hi = src_pl[prow * lds_ + c];
+                v = bf16_to_f32(hi);
+                if (planes == 2) {
+                    lo = src_pl[src_plane + prow * lds_ + c];
+                    v += bf16_to_f32(lo);
+                }
+            }
+            csum += v;
+            if (Nout) {
+                Nout[(long)m * ldn + c] = hi;
+                if (planes == 2) Nout[n_plane + (long)m * ldn + c] = lo;
+            }
+        }
+        th[ml][tx] = hi;
+        tl[ml][tx] = lo;
+    }
+    if (colsum) cs[ty][tx] = csum;
+    __syncthreads();
+    if (colsum && ty == 0 && c < C) {
+        const float s = cs[0][tx] + cs[1][tx] + cs[2][tx] + cs[3][tx];
+        if (s != 0.f) atomicAdd(colsum + c, s);
+    }
+    if (T) {
+#pragma unroll 4
+        for (int cc = 0; cc < 16; ++cc) {
+            const int cl = ty * 16 + cc;
+            const long o = (long)(c0 + cl) * m_pad + m0 + tx;
+            T[o] = th[tx][cl];
+            if (planes == 2) T[t_plane + o] = tl[tx][cl];
+        }
+    }
+}
+
+int launch_transpose_planes(const float* src_f32, const bf16_t* src_pl, long src_plane, int ld_src, int M, int C,
+                            bf16_t* T, long t_plane, int c_pad, int m_pad, bf16_t* Nout, long n_plane, int ldn,
+                            float* colsum, int planes, int drop_cls, int ntok, hipStream_t s) {
+    if (m_pad % 64 != 0 || c_pad % 64 != 0 || m_pad < M || c_pad < C) {
+        dinoseg_set_error("transpose_planes: bad padding (M=%d C=%d m_pad=%d c_pad=%d)", M, C, m_pad, c_pad);
+        return -1;
+    }
+    hipLaunchKernelGGL(transpose_planes_kernel, dim3(m_pad / 64, c_pad / 64), dim3(256), 0, s, src_f32, src_pl, src_plane,
+                       ld_src, M, C, T, t_plane, m_pad, Nout, n_plane, ldn, colsum, planes, drop_cls, ntok);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss = mean_m -logp[m][y_m]  (F.nll_loss, pl_torch_modules.py:265) and its gradient through log_softmax:
+// dz[m][c] = (exp(logp[m][c]) - [c == y_m]) / M, written as hi/lo planes [2][M][ldz] (zero padded columns).
+__global__ __launch_bounds__(256) void nll_loss_grad_kernel(const float* __restrict__ logp, const int64_t* __restrict__ labels,
+                                                            int M, int C, float* __restrict__ loss,
+                                                            bf16_t* __restrict__ dz, long dz_plane, int ldz) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.f;
+    if (m < M) {
+        const int y = (int)labels[m];
+        const float invM = 1.0f / (float)M;
+        for (int c = 0; c < ldz; ++c) {
+            float g = 0.f;
+            if (c < C) {
+                const float lp = logp[(long)m * C + c];
+                g = (expf(lp) - (c == y ? 1.f : 0.f)) * invM;
+                if (c == y) l = -lp * invM;
+            }
+            const uint32_t hi = pack_bf16x2(g, 0.f);
+            dz[(long)m * ldz + c] = (bf16_t)(hi & 0xFFFF);
+            dz[dz_plane + (long)m * ldz + c] = (bf16_t)(pack_bf16x2(g - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
+        }
+    }
+    l = wave_sum(l);
+    if ((threadIdx.x & 63) == 0 && l != 0.f) atomicAdd(loss, l);
+}
+
+int launch_nll_loss_grad(const float* logp, const int64_t* labels, int M, int C, float* loss, bf16_t* dz, long dz_plane,
+                         int ldz, hipStream_t s) {
+    hipLaunchKernelGGL(nll_loss_grad_kernel, dim3((M + 255) / 256), dim3(256), 0, s, logp, labels, M, C, loss, dz, dz_plane, ldz);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward (native_layer_norm_backward).  One wavefront per row; x is the saved LN input.
+//   g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dgamma += dy * xhat;  dbeta += dy
+// dx is added to (accumulate = 1) or written to (0) the residual-stream gradient.  drop_cls: dy has no CLS rows.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, float eps, int M,
+                                                            float* __restrict__ dx, int accumulate,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int drop_cls, int ntok) {
+    constexpr int D = 128 * NV;
+    __shared__ float red[2][4][D];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wid = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
+    f32x2 g[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g[i] = *reinterpret_cast<const f32x2*>(gamma + i * 128 + lane * 2);
+        dg[i] = f32x2{0.f, 0.f};
+        db[i] = f32x2{0.f, 0.f};
+    }
+    for (int m = wid; m < M; m += nw) {
+        long drow = m;
+        bool has_dy = true;
+        if (drop_cls) {
+            const int b = m / ntok, t = m - b * ntok;
+            has_dy = t != 0;
+            drow = (long)b * (ntok - 1) + t - 1;
+        }
+        float* dxr = dx + (long)m * D;
+        if (!has_dy) {
+            if (!accumulate) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x2*>(dxr + i * 128 + lane * 2) = f32x2{0.f, 0.f};
+            }
+            continue;
+        }
+        const float* xr = x + (long)m * D;
+        const float* dyr = dy + drow * D;
+        f32x2 xv[NV], dv[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            xv[i] = *reinterpret_cast<const f32x2*>(xr + i * 128 + lane * 2);
+            dv[i] = *reinterpret_cast<const f32x2*>(dyr + i * 128 + lane * 2);
+            s += xv[i][0] + xv[i][1];
+        }
+        const float mean = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            xv[i][0] -= mean;
+            xv[i][1] -= mean;
+            q += xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1];
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float xh = xv[i][e] * rstd;
+                const float ge = dv[i][e] * g[i][e];
+                dg[i][e] += dv[i][e] * xh;
+                db[i][e] += dv[i][e];
+                sg += ge;
+                sgx += ge * xh;
+                xv[i][e] = xh;      // keep xhat
+                dv[i][e] = ge;      // keep g
+            }
+        }
+        sg = wave_sum(sg) * (1.0f / D);
+        sgx = wave_sum(sgx) * (1.0f / D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f32x2 r;
+            r[0] = rstd * (dv[i][0] - sg - xv[i][0] * sgx);
+            r[1] = rstd * (dv[i][1] - sg - xv[i][1] * sgx);
+            f32x2* dst = reinterpret_cast<f32x2*>(dxr + i * 128 + lane * 2);
+            if (accumulate) r += *dst;
+            *dst = r;
+        }
+    }
+    // block-level reduction of the parameter gradients, then one atomic per column per block
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        red[0][wv][i * 128 + lane * 2] = dg[i][0];
+        red[0][wv][i * 128 + lane * 2 + 1] = dg[i][1];
+        red[1][wv][i * 128 + lane * 2] = db[i][0];
+        red[1][wv][i * 128 + lane * 2 + 1] = db[i][1];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        if (dgamma) atomicAdd(dgamma + c, a);
+        if (dbeta) atomicAdd(dbeta + c, b);
+    }
+}
+
+int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int M, int D, float* dx,
+                         int accumulate, float* dgamma, float* dbeta, int drop_cls, int ntok, hipStream_t s) {
+    if (D % 128 != 0 || D > 1024) {
+        dinoseg_set_error("layernorm_bwd: D=%d must be a multiple of 128 and <= 1024", D);
+        return -1;
+    }
+    int grid = (M + 3) / 4;
+    if (grid > 1024) grid = 1024;
+#define DSEG_LNB(NV)                                                                                                  \
+    case NV:                                                                                                          \
+        hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(grid), dim3(256), 0, s, dy, x, gamma, eps, M, dx, accumulate, \
+                           dgamma, dbeta, drop_cls, ntok);                                                            \
+        break;
+    switch (D / 128) { DSEG_LNB(1) DSEG_LNB(2) DSEG_LNB(3) DSEG_LNB(4) DSEG_LNB(5) DSEG_LNB(6) DSEG_LNB(7) DSEG_LNB(8) }
+#undef DSEG_LNB
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[t][d] = sum_b X[b*ntok + t][d]   (gradient of the broadcast pos-embed add; row 0 is also d cls_token)
+__global__ void batch_sum_rows_kernel(const float* __restrict__ X, int B, int ntok, int D, float* __restrict__ out) {
+    const long total = (long)ntok * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += X[(long)b * total + i];
+        out[i] = s;
+    }
+}
+
+int launch_batch_sum_rows(const float* X, int B, int ntok, int D, float* out, hipStream_t s) {
+    const long total = (long)ntok * D;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(batch_sum_rows_kernel, dim3(grid), dim3(256), 0, s, X, B, ntok, D, out);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Transpose of pos_resample_kernel (upsample_bicubic2d_backward): scatter each resampled-grid gradient to its
+// 16 clamped taps of the stored [g*g+1, D] pos-embed gradient (fp32 atomics; accumulates into dpe).
+__device__ __forceinline__ void cubic_w_bwd(float t, float w[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+__global__ void pos_resample_bwd_kernel(const float* __restrict__ dpos, int g, int D, int o, float scale,
+                                        float* __restrict__ dpe) {
+    const long total = ((long)o * o + 1) * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const long tokn = i / D;
+        const float gv = dpos[i];
+        if (tokn == 0 || o == g) {
+            atomicAdd(dpe + i, gv);      // class pos / identity grid: same index
+            continue;
+        }
+        const int y = (int)((tokn - 1) / o), x = (int)((tokn - 1) % o);
+        const float sy = (y + 0.5f) * scale - 0.5f, sx = (x + 0.5f) * scale - 0.5f;
+        const float fy = floorf(sy), fx = floorf(sx);
+        float wy[4], wx[4];
+        cubic_w_bwd(sy - fy, wy);
+        cubic_w_bwd(sx - fx, wx);
+        const int iy = (int)fy, ix = (int)fx;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int yy = iy - 1 + a;
+            yy = yy < 0 ? 0 : (yy > g - 1 ? g - 1 : yy);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int xx = ix - 1 + c;
+                xx = xx < 0 ? 0 : (xx > g - 1 ? g - 1 : xx);
+                atomicAdd(dpe + (1 + (long)yy * g + xx) * D + d, gv * wy[a] * wx[c]);
+            }
+        }
+    }
+}
+
+int launch_pos_resample_bwd(const float* dpos, int g, int D, int o, float* dpe, hipStream_t s) {
+    const long total = ((long)o * o + 1) * D;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    const float scale = (float)(1.0 / (((double)o + 0.1) / (double)g));
+    hipLaunchKernelGGL(pos_resample_bwd_kernel, dim3(grid), dim3(256), 0, s, dpos, g, D, o, scale, dpe);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// delta[pair][q] = sum_d dO[row(q)][head*64+d] * O[row(q)][head*64+d]   (flash-attention backward row term)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
+                                                         long plane, int planes, int B, int heads, int ntok,
+                                                         float* __restrict__ delta) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long total = (long)B * ntok * heads;      // one wavefront per (row, head): 64 lanes = 64 d
+    if (wid >= total) return;
+    const long row = wid / heads;
+    const int head = (int)(wid - row * heads);
+    const long off = row * (heads * 64) + head * 64 + lane;
+    float a = bf16_to_f32(dO[off]), b = bf16_to_f32(O[off]);
+    if (planes == 2) {
+        a += bf16_to_f32(dO[plane + off]);
+        b += bf16_to_f32(O[plane + off]);
+    }
+    const float s = wave_sum(a * b);
+    if (lane == 0) {
+        const long bidx = row / ntok, q = row - bidx * ntok;
+        delta[(bidx * heads + head) * ntok + q] = s;
+    }
+}
+
+int launch_attn_delta(const bf16_t* dO, const bf16_t* O, long plane, int planes, int B, int heads, int ntok, float* delta,
+                      hipStream_t s) {
+    const long total = (long)B * ntok * heads;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, dO, O, plane, planes, B, heads,
+                       ntok, delta);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused Adam / AdamW step on one tensor (torch.optim semantics; pl_torch_modules.py:258-259).
+//   decoupled = 1 (AdamW): p *= 1 - lr*wd;   decoupled = 0 (Adam): g += wd*p
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr, float b1, float b2, float eps, float wd, int decoupled, float bc1, float bc2s,
+                            float gscale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float pi = p[i], gi = g[i] * gscale;
+        if (decoupled) pi *= 1.0f - lr * wd;
+        else if (wd != 0.f) gi += wd * pi;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2s + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
+                int decoupled, int step, float gscale, hipStream_t s) {
+    if (n <= 0) return 0;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    const float bc1 = 1.0f - powf(b1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(b2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, bc1, bc2s, gscale);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dseg

@@ -1,0 +1,522 @@
+// Fine-tune step of the DINOSeg hot path: forward with saved activations, backward, gradients
+// written into caller-bound fp32 buffers.  Replaces DINOSeg.training_step + autograd.backward
+// (pl_torch_modules.py:261-268) for one data-parallel rank; the cross-rank gradient mean is done by the caller
+// (torch.distributed all_reduce over RCCL, dino_amd/parallel.py).  Host code only.
+//
+// Backward of y = act(x W^T + b), given dY (activation derivative already applied):
+//   dX = dY . W          -> gemm.hip NT kernel with the transposed packed weight W^T[K][N] as the "W" operand
+//   dW = dY^T . X        -> both operands transposed to [*, rows] planes (transpose_planes_kernel), same NT kernel
+//                           with the batch rows as the contraction, split over grid.y, fp32 atomics into dW
+//   db = column sums of dY (by-product of the transpose kernel)
+#include <string.h>
+
+#include "handle.h"
+
+namespace {
+
+struct TrainLayout {
+    int n, ntok, npad, M, Mp, Mpad, Mppad, Cmax;
+    // per block (offsets are for block 0; block l adds l * blk_stride)
+    size_t Xin, A1, Q, K, V, LSE, CTX, Xmid, A2, HPRE, HB, blk_stride;
+    size_t Xfin, PATCH, FEAT, H1, H2, LOGP, DZ;
+    size_t dX, dA, dXp, G, dCTX, T1, T2, NLSE, NDEL, DPOS, SINK;
+    size_t zero_begin, zero_end;      // Q/K/V of every block (pad rows must be zero)
+    size_t total;
+    long a_plane, qkv_plane, f_plane, feat_plane, h1_plane, h2_plane, dz_plane, patch_plane, g_plane, t_plane;
+};
+
+TrainLayout make_train_layout(const dinoseg_handle* h, int B, int r) {
+    const dinoseg_config& c = h->cfg;
+    const int D = c.embed_dim, F = D * c.mlp_ratio, P = h->planes, HP = head_planes();
+    TrainLayout L;
+    memset(&L, 0, sizeof(L));
+    L.n = (r / 8) * (r / 8);
+    L.ntok = L.n + 1;
+    L.npad = (L.ntok + 63) / 64 * 64;
+    L.M = B * L.ntok;
+    L.Mp = B * L.n;
+    L.Mpad = (L.M + 63) / 64 * 64;
+    L.Mppad = (L.Mp + 63) / 64 * 64;
+    L.Cmax = 3 * D > F ? 3 * D : F;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    L.a_plane = (long)L.M * D;
+    L.qkv_plane = (long)B * c.num_heads * L.npad * 64;
+    L.f_plane = (long)L.M * F;
+    // block 0
+    const size_t b0 = off;
+    L.Xin = take((size_t)L.M * D * 4);
+    L.A1 = take((size_t)P * L.a_plane * 2);
+    L.Q = take((size_t)P * L.qkv_plane * 2);
+    L.K = take((size_t)P * L.qkv_plane * 2);
+    L.V = take((size_t)P * L.qkv_plane * 2);
+    L.LSE = take((size_t)B * c.num_heads * L.ntok * 4);
+    L.CTX = take((size_t)P * L.a_plane * 2);
+    L.Xmid = take((size_t)L.M * D * 4);
+    L.A2 = take((size_t)P * L.a_plane * 2);
+    L.HPRE = take((size_t)P * L.f_plane * 2);
+    L.HB = take((size_t)P * L.f_plane * 2);
+    L.blk_stride = off - b0;
+    off = b0 + L.blk_stride * (c.n_blocks > 0 ? c.n_blocks : 1);
+    L.Xfin = take((size_t)L.M * D * 4);
+    L.patch_plane = (long)L.Mp * 192;
+    L.PATCH = take((size_t)P * L.patch_plane * 2);
+    L.feat_plane = (long)L.Mp * D;
+    L.FEAT = take((size_t)HP * L.feat_plane * 2);
+    L.h1_plane = (long)L.Mp * 256;
+    L.H1 = take((size_t)HP * L.h1_plane * 2);
+    L.h2_plane = (long)L.Mp * 128;
+    L.H2 = take((size_t)HP * L.h2_plane * 2);
+    L.LOGP = take((size_t)L.Mp * c.n_classes * 4);
+    L.dz_plane = (long)L.Mp * 64;
+    L.DZ = take((size_t)HP * L.dz_plane * 2);
+    // backward scratch
+    L.dX = take((size_t)L.M * D * 4);
+    L.dA = take((size_t)L.M * D * 4);
+    L.dXp = take((size_t)2 * L.a_plane * 2);
+    L.g_plane = (long)L.M * L.Cmax;
+    L.G = take((size_t)2 * L.g_plane * 2);
+    {   // d ctx planes [M, D]; also hosts the head's d h1 planes [Mp, 256]
+        const size_t e = (size_t)L.a_plane > (size_t)L.Mp * 256 ? (size_t)L.a_plane : (size_t)L.Mp * 256;
+        L.dCTX = take(2 * e * 2);
+    }
+    L.t_plane = (long)L.Cmax * L.Mpad;
+    L.T1 = take((size_t)2 * L.t_plane * 2);
+    L.T2 = take((size_t)2 * L.t_plane * 2);
+    L.NLSE = take((size_t)B * c.num_heads * L.npad * 4);
+    L.NDEL = take((size_t)B * c.num_heads * L.npad * 4);
+    L.DPOS = take((size_t)L.ntok * D * 4);
+    L.SINK = take((size_t)4 * 1024 * 4);
+    L.total = off;
+    return L;
+}
+
+struct TLin {
+    std::string wname;
+    int N, K, n_pad, k_pad, planes;     // W is [N][K]; W^T planes are [k_pad][n_pad]
+};
+
+std::vector<TLin> transposed_specs(const dinoseg_handle* h) {
+    const dinoseg_config& c = h->cfg;
+    const int D = c.embed_dim, F = D * c.mlp_ratio, P = h->planes, HP = head_planes(), C = c.n_classes;
+    std::vector<TLin> v;
+    for (int i = 0; i < c.n_blocks; ++i) {
+        const std::string b = "dino.blocks." + std::to_string(i) + ".";
+        v.push_back({b + "attn.qkv.weight", 3 * D, D, 3 * D, D, P});
+        v.push_back({b + "attn.proj.weight", D, D, D, D, P});
+        v.push_back({b + "mlp.fc1.weight", F, D, F, D, P});
+        v.push_back({b + "mlp.fc2.weight", D, F, D, F, P});
+    }
+    if (c.head_kind == DINOSEG_HEAD_MLP) {
+        v.push_back({"clf.layer_1.weight", 200, D, 256, D, HP});
+        v.push_back({"clf.layer_2.weight", 100, 200, 128, 256, HP});
+        v.push_back({"clf.layer_3.weight", C, 100, 64, 128, HP});
+    } else {
+        v.push_back({"clf.layer_1.weight", C, D, 64, D, HP});
+    }
+    return v;
+}
+
+struct TW {
+    bf16_t* w;
+    long plane;
+};
+
+}  // namespace
+
+int dinoseg_train_release(dinoseg_handle* h) {
+    if (h->tws) (void)hipFree(h->tws);
+    if (h->twbuf) (void)hipFree(h->twbuf);
+    h->tws = nullptr;
+    h->twbuf = nullptr;
+    h->tws_bytes = h->twbuf_bytes = 0;
+    return 0;
+}
+
+extern "C" int dinoseg_bind_grad(dinoseg_handle* h, const char* name, float* dev_ptr) {
+    if (!h || !name) {
+        dinoseg_set_error("dinoseg_bind_grad: null argument");
+        return -1;
+    }
+    if (!h->expected.count(name)) {
+        dinoseg_set_error("dinoseg_bind_grad: unexpected key '%s'", name);
+        return -1;
+    }
+    if (dev_ptr) h->grads[name] = dev_ptr;
+    else h->grads.erase(name);
+    return 0;
+}
+
+extern "C" int dinoseg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, int32_t decoupled, int32_t step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || step < 1) {
+        dinoseg_set_error("dinoseg_adam_step: bad argument");
+        return -1;
+    }
+    return launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, decoupled, step, grad_scale,
+                       reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_attention_bwd(const void* q, const void* k, const void* v, int64_t qkv_plane, const void* dO,
+                                        const void* O, int64_t o_plane, const float* lse, float* scratch, void* dqkv,
+                                        int64_t dqkv_plane, int32_t B, int32_t heads, int32_t ntok, int32_t npad,
+                                        int32_t planes, void* stream) {
+    AttnBwdParams a = {};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.qkv_plane = qkv_plane;
+    a.dO = (const bf16_t*)dO; a.O = (const bf16_t*)O; a.dO_plane = o_plane; a.lse = lse;
+    a.neg_lse = scratch; a.neg_delta = scratch + (size_t)B * heads * npad;
+    a.dqkv = (bf16_t*)dqkv; a.dqkv_plane = dqkv_plane;
+    a.B = B; a.heads = heads; a.ntok = ntok; a.npad = npad; a.planes = planes;
+    return launch_attention_bwd(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int32_t M, int32_t D,
+                                        float* dx, int32_t accumulate, float* dgamma, float* dbeta, int32_t drop_cls,
+                                        int32_t ntok, void* stream) {
+    return launch_layernorm_bwd(dy, x, gamma, eps, M, D, dx, accumulate, dgamma, dbeta, drop_cls, ntok,
+                                reinterpret_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ the step
+extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r,
+                                  const int64_t* labels, float* loss_out, float* logp_out, void* stream) {
+    if (!h || !x || !labels || !loss_out || B <= 0) {
+        dinoseg_set_error("dinoseg_train_step: bad argument");
+        return -1;
+    }
+    if (r <= 0 || r % 8 != 0) {
+        dinoseg_set_error("Resolution should be a multiple of 8.");
+        return -1;
+    }
+    if (!h->weights_ready) {
+        dinoseg_set_error("dinoseg_train_step: weights not packed (call dinoseg_refresh_weights after binding)");
+        return -3;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DSEG_TRY(dinoseg_prepare_resolution(h, r, stream));
+    const dinoseg_config& c = h->cfg;
+    const int D = c.embed_dim, F = D * c.mlp_ratio, P = h->planes, HP = head_planes(), H = c.num_heads, C = c.n_classes;
+    const int NB = c.n_blocks;
+    const bool mlp_head = c.head_kind == DINOSEG_HEAD_MLP;
+    const TrainLayout L = make_train_layout(h, B, r);
+
+    // ---- workspace
+    if (L.total > h->tws_bytes) {
+        if (h->tws) {
+            DSEG_CHECK_HIP(hipStreamSynchronize(s));
+            DSEG_CHECK_HIP(hipFree(h->tws));
+        }
+        h->tws = nullptr;
+        h->tws_bytes = 0;
+        DSEG_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&h->tws), L.total));
+        h->tws_bytes = L.total;
+        h->tws_B = -1;
+    }
+    char* ws = h->tws;
+    if (h->tws_B != B || h->tws_r != r) {
+        for (int l = 0; l < NB; ++l)   // Q/K/V pad rows must be zero (never written afterwards)
+            DSEG_CHECK_HIP(hipMemsetAsync(ws + L.Q + l * L.blk_stride, 0, L.LSE - L.Q, s));
+        h->tws_B = B;
+        h->tws_r = r;
+    }
+    auto F32 = [&](size_t o) { return reinterpret_cast<float*>(ws + o); };
+    auto B16 = [&](size_t o) { return reinterpret_cast<bf16_t*>(ws + o); };
+
+    // ---- transposed packed weights for dX = dY . W  (weights change every optimiser step: repack)
+    const std::vector<TLin> tspecs = transposed_specs(h);
+    std::map<std::string, TW> tw;
+    {
+        size_t total = 0;
+        for (const TLin& t : tspecs) total += align_up((size_t)t.planes * t.k_pad * t.n_pad * 2, 256);
+        if (total > h->twbuf_bytes) {
+            if (h->twbuf) {
+                DSEG_CHECK_HIP(hipStreamSynchronize(s));
+                DSEG_CHECK_HIP(hipFree(h->twbuf));
+            }
+            h->twbuf = nullptr;
+            DSEG_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&h->twbuf), total));
+            h->twbuf_bytes = total;
+        }
+        size_t off = 0;
+        for (const TLin& t : tspecs) {
+            TW e;
+            e.w = reinterpret_cast<bf16_t*>(h->twbuf + off);
+            e.plane = (long)t.k_pad * t.n_pad;
+            off += align_up((size_t)t.planes * t.k_pad * t.n_pad * 2, 256);
+            // W [N][K] fp32 -> W^T planes [k_pad][n_pad]: "rows" of the source are N, transposed destination rows are K
+            DSEG_TRY(launch_pack_planes_t(W(h, t.wname), t.N, t.K, e.w, e.plane, t.n_pad, t.k_pad, t.planes, s));
+            tw[t.wname] = e;
+        }
+    }
+
+    auto grad = [&](const std::string& name) -> float* {
+        auto it = h->grads.find(name);
+        return it == h->grads.end() ? nullptr : it->second;
+    };
+    auto numel = [&](const std::string& name) {
+        size_t n = 1;
+        for (int64_t d : h->expected.at(name)) n *= (size_t)d;
+        return n;
+    };
+    bool backbone = false;
+    for (auto& kv : h->grads) {
+        DSEG_CHECK_HIP(hipMemsetAsync(kv.second, 0, numel(kv.first) * sizeof(float), s));
+        if (kv.first.rfind("dino.", 0) == 0) backbone = true;
+    }
+    DSEG_CHECK_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), s));
+
+    // =============================================================== forward (activations kept)
+    float mean255[3], inv255[3];
+    norm_consts(mean255, inv255);
+    bf16_t* PATCH = B16(L.PATCH);
+    DSEG_TRY(launch_patch_gather(x, x_kind, B, r, mean255, inv255, PATCH, L.patch_plane, P, s));
+    float* X0 = NB > 0 ? F32(L.Xin) : F32(L.Xfin);
+    {
+        const PackedLinear& pk = h->packed.at("dino.patch_embed.proj.weight");
+        GemmParams g = {};
+        g.A = PATCH; g.a_plane = L.patch_plane; g.lda = 192;
+        g.W = pk.w; g.w_plane = pk.plane;
+        g.M = L.Mp; g.N = D; g.K = 192; g.planes = P; g.epi = EPI_PATCH;
+        g.bias = W(h, "dino.patch_embed.proj.bias");
+        g.out_f32 = X0; g.ldo_f32 = D;
+        g.pos = h->pos_cache; g.n_patches = L.n;
+        DSEG_TRY(launch_gemm(g, s));
+    }
+    DSEG_TRY(launch_cls_rows(X0, W(h, "dino.cls_token"), h->pos_cache, B, L.ntok, D, s));
+    const float qscale = 0.125f * 1.44269504088896340736f;
+
+    for (int l = 0; l < NB; ++l) {
+        const std::string b = "dino.blocks." + std::to_string(l) + ".";
+        const size_t o = l * L.blk_stride;
+        float* Xin = F32(L.Xin + o);
+        float* Xmid = F32(L.Xmid + o);
+        float* Xout = l + 1 < NB ? F32(L.Xin + o + L.blk_stride) : F32(L.Xfin);
+        bf16_t *A1 = B16(L.A1 + o), *Q = B16(L.Q + o), *Kb = B16(L.K + o), *V = B16(L.V + o), *CTX = B16(L.CTX + o);
+        bf16_t *A2 = B16(L.A2 + o), *HPRE = B16(L.HPRE + o), *HB = B16(L.HB + o);
+        DSEG_TRY(launch_layernorm(Xin, W(h, b + "norm1.weight"), W(h, b + "norm1.bias"), c.ln_eps, L.M, D, A1, L.a_plane, P,
+                                  nullptr, 0, L.ntok, s));
+        {
+            const PackedLinear& pk = h->packed.at(b + "attn.qkv.weight");
+            GemmParams g = {};
+            g.A = A1; g.a_plane = L.a_plane; g.lda = D; g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.M; g.N = 3 * D; g.K = D; g.planes = P; g.epi = EPI_QKV; g.bias = W(h, b + "attn.qkv.bias");
+            g.q = Q; g.k = Kb; g.v = V; g.qkv_plane = L.qkv_plane;
+            g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+        {
+            AttnParams a = {};
+            a.q = Q; a.k = Kb; a.v = V; a.qkv_plane = L.qkv_plane; a.ctx = CTX; a.ctx_plane = L.a_plane;
+            a.lse = F32(L.LSE + o);
+            a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P;
+            DSEG_TRY(launch_attention(a, s));
+        }
+        {
+            const PackedLinear& pk = h->packed.at(b + "attn.proj.weight");
+            GemmParams g = {};
+            g.A = CTX; g.a_plane = L.a_plane; g.lda = D; g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.M; g.N = D; g.K = D; g.planes = P; g.epi = EPI_RESID; g.bias = W(h, b + "attn.proj.bias");
+            g.resid = Xin; g.out_f32 = Xmid; g.ldo_f32 = D;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+        DSEG_TRY(launch_layernorm(Xmid, W(h, b + "norm2.weight"), W(h, b + "norm2.bias"), c.ln_eps, L.M, D, A2, L.a_plane, P,
+                                  nullptr, 0, L.ntok, s));
+        {
+            const PackedLinear& pk = h->packed.at(b + "mlp.fc1.weight");
+            GemmParams g = {};
+            g.A = A2; g.a_plane = L.a_plane; g.lda = D; g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.M; g.N = F; g.K = D; g.planes = P; g.epi = EPI_GELU; g.bias = W(h, b + "mlp.fc1.bias");
+            g.out_bf16 = HB; g.out_plane = L.f_plane; g.ldo = F; g.aux_out = HPRE; g.aux_plane = L.f_plane;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+        {
+            const PackedLinear& pk = h->packed.at(b + "mlp.fc2.weight");
+            GemmParams g = {};
+            g.A = HB; g.a_plane = L.f_plane; g.lda = F; g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.M; g.N = D; g.K = F; g.planes = P; g.epi = EPI_RESID; g.bias = W(h, b + "mlp.fc2.bias");
+            g.resid = Xmid; g.out_f32 = Xout; g.ldo_f32 = D;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+    }
+    float* Xfin = F32(L.Xfin);
+    bf16_t *FEAT = B16(L.FEAT), *H1 = B16(L.H1), *H2 = B16(L.H2), *DZ = B16(L.DZ);
+    float* LOGP = F32(L.LOGP);
+    DSEG_TRY(launch_layernorm(Xfin, W(h, "dino.norm.weight"), W(h, "dino.norm.bias"), c.ln_eps, L.M, D, FEAT, L.feat_plane, HP,
+                              nullptr, 1, L.ntok, s));
+    if (mlp_head) {
+        {
+            const PackedLinear& pk = h->packed.at("clf.layer_1.weight");
+            GemmParams g = {};
+            g.A = FEAT; g.a_plane = L.feat_plane; g.lda = D; g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.Mp; g.N = 256; g.K = D; g.planes = HP; g.epi = EPI_RELU; g.bias = pk.bias_pad;
+            g.out_bf16 = H1; g.out_plane = L.h1_plane; g.ldo = 256;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+        {
+            const PackedLinear& pk = h->packed.at("clf.layer_2.weight");
+            GemmParams g = {};
+            g.A = H1; g.a_plane = L.h1_plane; g.lda = 256; g.W = pk.w; g.w_plane = pk.plane;
+            g.M = L.Mp; g.N = 128; g.K = 256; g.planes = HP; g.epi = EPI_RELU; g.bias = pk.bias_pad;
+            g.out_bf16 = H2; g.out_plane = L.h2_plane; g.ldo = 128;
+            DSEG_TRY(launch_gemm(g, s));
+        }
+        DSEG_TRY(launch_head_final(H2, L.h2_plane, 128, L.Mp, 100, W(h, "clf.layer_3.weight"), W(h, "clf.layer_3.bias"), C, LOGP,
+                                   nullptr, s));
+    } else {
+        DSEG_TRY(launch_head_final(FEAT, L.feat_plane, D, L.Mp, D, W(h, "clf.layer_1.weight"), W(h, "clf.layer_1.bias"), C, LOGP,
+                                   nullptr, s));
+    }
+    if (logp_out) DSEG_CHECK_HIP(hipMemcpyAsync(logp_out, LOGP, (size_t)L.Mp * C * 4, hipMemcpyDeviceToDevice, s));
+
+    // =============================================================== backward
+    float* sink = F32(L.SINK);
+    bf16_t *T1 = B16(L.T1), *T2 = B16(L.T2);
+
+    // dX[M_, Kin] = dY[M_, Ncols] . W   with optional activation-derivative epilogue
+    auto dgrad = [&](const bf16_t* dY, long dy_plane, int ld, int M_, int n_contract, const TW& wt, int k_out, int planes, int epi,
+                     float* out_f32, bf16_t* out_bf16, long out_plane, const bf16_t* aux, long aux_plane) -> int {
+        GemmParams g = {};
+        g.A = dY; g.a_plane = dy_plane; g.lda = ld; g.W = wt.w; g.w_plane = wt.plane;
+        g.M = M_; g.N = k_out; g.K = n_contract; g.planes = planes; g.epi = epi;
+        g.out_f32 = out_f32; g.ldo_f32 = k_out;
+        g.out_bf16 = out_bf16; g.out_plane = out_plane; g.ldo = k_out; g.aux_in = aux; g.aux_plane = aux_plane;
+        return launch_gemm_small(g, s);
+    };
+    // dW[n_rows, k_cols] += dY^T . X  from transposed planes T_dy [n_pad][m_pad], T_x [k_pad128][m_pad]
+    auto wgrad = [&](const bf16_t* Tdy, const bf16_t* Tx, long tplane, int m_pad, int n_rows, int k_pad128, int k_cols, int planes,
+                     float* dW) -> int {
+        if (!dW) return 0;
+        GemmParams g = {};
+        g.A = Tdy; g.a_plane = tplane; g.lda = m_pad; g.W = Tx; g.w_plane = tplane;
+        g.M = n_rows; g.N = k_pad128; g.K = m_pad; g.planes = planes; g.epi = EPI_ATOMIC;
+        g.out_f32 = dW; g.ldo_f32 = k_cols; g.n_valid = k_cols;
+        const int tiles = ((n_rows + 127) / 128) * (k_pad128 / 128), nk = m_pad / 64;
+        int ks = 768 / tiles;
+        if (ks > nk / 2) ks = nk / 2;
+        if (ks < 1) ks = 1;
+        g.ksplit = ks;
+        return launch_gemm_small(g, s);
+    };
+    auto pad128 = [](int v) { return (v + 127) / 128 * 128; };
+
+    // ---- loss and d logits (pl_torch_modules.py:264-265)
+    DSEG_TRY(launch_nll_loss_grad(LOGP, labels, L.Mp, C, loss_out, DZ, L.dz_plane, 64, s));
+    const long tpl = L.t_plane;
+    float* dX = F32(L.dX);
+    float* dA = F32(L.dA);
+    bf16_t* G = B16(L.G);
+    if (mlp_head) {
+        // layer_3: z = h2 W3^T + b3
+        DSEG_TRY(launch_transpose_planes(nullptr, DZ, L.dz_plane, 64, L.Mp, C, T1, tpl, 128, L.Mppad, nullptr, 0, 0,
+                                         grad("clf.layer_3.bias") ? grad("clf.layer_3.bias") : nullptr, HP, 0, 0, s));
+        DSEG_TRY(launch_transpose_planes(nullptr, H2, L.h2_plane, 128, L.Mp, 128, T2, tpl, 128, L.Mppad, nullptr, 0, 0, nullptr, HP, 0, 0, s));
+        DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, C, 128, 100, HP, grad("clf.layer_3.weight")));
+        bf16_t* dH2 = G;                         // [HP][Mp][128]
+        const long dh2_plane = (long)L.Mp * 128;
+        DSEG_TRY(dgrad(DZ, L.dz_plane, 64, L.Mp, 64, tw.at("clf.layer_3.weight"), 128, HP, EPI_DRELU, nullptr, dH2, dh2_plane, H2, L.h2_plane));
+        // layer_2
+        DSEG_TRY(launch_transpose_planes(nullptr, dH2, dh2_plane, 128, L.Mp, 100, T1, tpl, 128, L.Mppad, nullptr, 0, 0,
+                                         grad("clf.layer_2.bias"), HP, 0, 0, s));
+        DSEG_TRY(launch_transpose_planes(nullptr, H1, L.h1_plane, 256, L.Mp, 256, T2, tpl, 256, L.Mppad, nullptr, 0, 0, nullptr, HP, 0, 0, s));
+        DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, 100, 256, 200, HP, grad("clf.layer_2.weight")));
+        bf16_t* dH1 = B16(L.dCTX);               // [HP][Mp][256] fits: Mp*256 <= M*D
+        const long dh1_plane = (long)L.Mp * 256;
+        DSEG_TRY(dgrad(dH2, dh2_plane, 128, L.Mp, 128, tw.at("clf.layer_2.weight"), 256, HP, EPI_DRELU, nullptr, dH1, dh1_plane, H1, L.h1_plane));
+        // layer_1
+        DSEG_TRY(launch_transpose_planes(nullptr, dH1, dh1_plane, 256, L.Mp, 200, T1, tpl, 256, L.Mppad, nullptr, 0, 0,
+                                         grad("clf.layer_1.bias"), HP, 0, 0, s));
+        DSEG_TRY(launch_transpose_planes(nullptr, FEAT, L.feat_plane, D, L.Mp, D, T2, tpl, pad128(D), L.Mppad, nullptr, 0, 0, nullptr, HP, 0, 0, s));
+        DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, 200, pad128(D), D, HP, grad("clf.layer_1.weight")));
+        if (backbone)
+            DSEG_TRY(dgrad(dH1, dh1_plane, 256, L.Mp, 256, tw.at("clf.layer_1.weight"), D, HP, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
+    } else {
+        DSEG_TRY(launch_transpose_planes(nullptr, DZ, L.dz_plane, 64, L.Mp, C, T1, tpl, 128, L.Mppad, nullptr, 0, 0,
+                                         grad("clf.layer_1.bias"), HP, 0, 0, s));
+        DSEG_TRY(launch_transpose_planes(nullptr, FEAT, L.feat_plane, D, L.Mp, D, T2, tpl, pad128(D), L.Mppad, nullptr, 0, 0, nullptr, HP, 0, 0, s));
+        DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, C, pad128(D), D, HP, grad("clf.layer_1.weight")));
+        if (backbone)
+            DSEG_TRY(dgrad(DZ, L.dz_plane, 64, L.Mp, 64, tw.at("clf.layer_1.weight"), D, HP, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
+    }
+    if (!backbone) return 0;      // frozen backbone (freeze_bb, pl_torch_modules.py:434-436): only the head trains
+
+    // ---- final norm (CLS rows get no gradient from the head)
+    auto gsink = [&](const std::string& name) { float* g = grad(name); return g ? g : sink; };
+    DSEG_TRY(launch_layernorm_bwd(dA, Xfin, W(h, "dino.norm.weight"), c.ln_eps, L.M, D, dX, 0, gsink("dino.norm.weight"),
+                                  gsink("dino.norm.bias"), 1, L.ntok, s));
+
+    bf16_t* dXp = B16(L.dXp);
+    bf16_t* dCTX = B16(L.dCTX);
+    for (int l = NB - 1; l >= 0; --l) {
+        const std::string b = "dino.blocks." + std::to_string(l) + ".";
+        const size_t o = l * L.blk_stride;
+        bf16_t *A1 = B16(L.A1 + o), *Q = B16(L.Q + o), *Kb = B16(L.K + o), *V = B16(L.V + o), *CTX = B16(L.CTX + o);
+        bf16_t *A2 = B16(L.A2 + o), *HPRE = B16(L.HPRE + o), *HB = B16(L.HB + o);
+        // ---- mlp.fc2 : X_out = X_mid + H W2^T + b
+        DSEG_TRY(launch_transpose_planes(dX, nullptr, 0, D, L.M, D, T1, tpl, pad128(D), L.Mpad, dXp, L.a_plane, D, grad(b + "mlp.fc2.bias"),
+                                         P, 0, 0, s));
+        if (grad(b + "mlp.fc2.weight")) {
+            DSEG_TRY(launch_transpose_planes(nullptr, HB, L.f_plane, F, L.M, F, T2, tpl, pad128(F), L.Mpad, nullptr, 0, 0, nullptr, P, 0, 0, s));
+            DSEG_TRY(wgrad(T1, T2, tpl, L.Mpad, D, pad128(F), F, P, grad(b + "mlp.fc2.weight")));
+        }
+        // dHpre = (dX . W2) * gelu'(Hpre)
+        DSEG_TRY(dgrad(dXp, L.a_plane, D, L.M, D, tw.at(b + "mlp.fc2.weight"), F, P, EPI_DGELU, nullptr, G, (long)L.M * F, HPRE, L.f_plane));
+        // ---- mlp.fc1 : Hpre = A2 W1^T + b
+        DSEG_TRY(launch_transpose_planes(nullptr, G, (long)L.M * F, F, L.M, F, T1, tpl, pad128(F), L.Mpad, nullptr, 0, 0,
+                                         grad(b + "mlp.fc1.bias"), P, 0, 0, s));
+        if (grad(b + "mlp.fc1.weight")) {
+            DSEG_TRY(launch_transpose_planes(nullptr, A2, L.a_plane, D, L.M, D, T2, tpl, pad128(D), L.Mpad, nullptr, 0, 0, nullptr, P, 0, 0, s));
+            DSEG_TRY(wgrad(T1, T2, tpl, L.Mpad, F, pad128(D), D, P, grad(b + "mlp.fc1.weight")));
+        }
+        DSEG_TRY(dgrad(G, (long)L.M * F, F, L.M, F, tw.at(b + "mlp.fc1.weight"), D, P, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
+        // ---- norm2 (input X_mid); the residual branch keeps dX
+        DSEG_TRY(launch_layernorm_bwd(dA, F32(L.Xmid + o), W(h, b + "norm2.weight"), c.ln_eps, L.M, D, dX, 1, gsink(b + "norm2.weight"),
+                                      gsink(b + "norm2.bias"), 0, L.ntok, s));
+        // ---- attn.proj : X_mid = X_in + ctx Wp^T + b
+        DSEG_TRY(launch_transpose_planes(dX, nullptr, 0, D, L.M, D, T1, tpl, pad128(D), L.Mpad, dXp, L.a_plane, D, grad(b + "attn.proj.bias"),
+                                         P, 0, 0, s));
+        if (grad(b + "attn.proj.weight")) {
+            DSEG_TRY(launch_transpose_planes(nullptr, CTX, L.a_plane, D, L.M, D, T2, tpl, pad128(D), L.Mpad, nullptr, 0, 0, nullptr, P, 0, 0, s));
+            DSEG_TRY(wgrad(T1, T2, tpl, L.Mpad, D, pad128(D), D, P, grad(b + "attn.proj.weight")));
+        }
+        DSEG_TRY(dgrad(dXp, L.a_plane, D, L.M, D, tw.at(b + "attn.proj.weight"), D, P, EPI_BF16, nullptr, dCTX, L.a_plane, nullptr, 0));
+        // ---- attention
+        {
+            AttnBwdParams a = {};
+            a.q = Q; a.k = Kb; a.v = V; a.qkv_plane = L.qkv_plane;
+            a.dO = dCTX; a.O = CTX; a.dO_plane = L.a_plane; a.lse = F32(L.LSE + o);
+            a.neg_lse = F32(L.NLSE); a.neg_delta = F32(L.NDEL);
+            a.dqkv = G; a.dqkv_plane = (long)L.M * 3 * D;
+            a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P;
+            DSEG_TRY(launch_attention_bwd(a, s));
+        }
+        // ---- attn.qkv : qkv = A1 Wqkv^T + b
+        DSEG_TRY(launch_transpose_planes(nullptr, G, (long)L.M * 3 * D, 3 * D, L.M, 3 * D, T1, tpl, pad128(3 * D), L.Mpad, nullptr, 0, 0,
+                                         grad(b + "attn.qkv.bias"), P, 0, 0, s));
+        if (grad(b + "attn.qkv.weight")) {
+            DSEG_TRY(launch_transpose_planes(nullptr, A1, L.a_plane, D, L.M, D, T2, tpl, pad128(D), L.Mpad, nullptr, 0, 0, nullptr, P, 0, 0, s));
+            DSEG_TRY(wgrad(T1, T2, tpl, L.Mpad, 3 * D, pad128(D), D, P, grad(b + "attn.qkv.weight")));
+        }
+        DSEG_TRY(dgrad(G, (long)L.M * 3 * D, 3 * D, L.M, 3 * D, tw.at(b + "attn.qkv.weight"), D, P, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
+        // ---- norm1 (input X_in)
+        DSEG_TRY(launch_layernorm_bwd(dA, F32(L.Xin + o), W(h, b + "norm1.weight"), c.ln_eps, L.M, D, dX, 1, gsink(b + "norm1.weight"),
+                                      gsink(b + "norm1.bias"), 0, L.ntok, s));
+    }
+
+    // ---- embeddings: tokens = [cls ; conv(patches)] + pos   (vision_transformer.py:224-235)
+    float* dpos = F32(L.DPOS);
+    DSEG_TRY(launch_batch_sum_rows(dX, B, L.ntok, D, dpos, s));
+    if (grad("dino.cls_token"))
+        DSEG_CHECK_HIP(hipMemcpyAsync(grad("dino.cls_token"), dpos, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+    if (grad("dino.pos_embed")) DSEG_TRY(launch_pos_resample_bwd(dpos, c.pos_grid, D, r / 8, grad("dino.pos_embed"), s));
+    DSEG_TRY(launch_transpose_planes(dX, nullptr, 0, D, L.Mp, D, T1, tpl, pad128(D), L.Mppad, nullptr, 0, 0,
+                                     grad("dino.patch_embed.proj.bias"), P, 1, L.ntok, s));
+    if (grad("dino.patch_embed.proj.weight")) {
+        DSEG_TRY(launch_transpose_planes(nullptr, PATCH, L.patch_plane, 192, L.Mp, 192, T2, tpl, 256, L.Mppad, nullptr, 0, 0, nullptr, P, 0, 0, s));
+        DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, D, 256, 192, P, grad("dino.patch_embed.proj.weight")));
+    }
+    return 0;
+}

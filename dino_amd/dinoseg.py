@@ -238,6 +238,7 @@ class DINOSeg(nn.Module):
             capi.lib().dinoseg_destroy(self._handle)
             self._handle = None
             self._bound_sig = None
+            self._grad_sig = None
 
     def __del__(self):
         try:
@@ -321,6 +322,73 @@ class DINOSeg(nn.Module):
         ms, cnt = (C.c_float * n)(), (C.c_int32 * n)()
         capi.check(capi.lib().dinoseg_profile_read(self._handle, ms, cnt))
         return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(capi.PROF_CLASSES)}
+
+    # ---- fine-tune step --------------------------------------------------------------------------
+    def _sync_grads(self) -> None:
+        """Bind every trainable parameter's .grad buffer to the native handle (allocating it on first use);
+        parameters with requires_grad=False are unbound = frozen (freeze_bb / unfreeze_bb)."""
+        lib = capi.lib()
+        sig = []
+        for name, p in self.named_parameters():
+            if p.requires_grad:
+                if p.grad is None or p.grad.data_ptr() == 0:
+                    p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                sig.append((name, p.grad.data_ptr()))
+            else:
+                sig.append((name, None))
+        sig = tuple(sig)
+        if sig == getattr(self, "_grad_sig", None):
+            return
+        for name, ptr in sig:
+            capi.check(lib.dinoseg_bind_grad(self._handle, name.encode(), ptr))
+        self._grad_sig = sig
+
+    def training_step(self, batch, batch_idx=0):
+        """Reference semantics (pl_torch_modules.py:261-268): probs = self(x); loss = F.nll_loss(probs, y.reshape(-1)).
+        Forward and backward both run in the native library; on return every trainable parameter's ``.grad`` holds
+        d loss / d parameter of THIS call (overwritten, like zero_grad + backward), so any torch optimiser -- or
+        ``fused_adam_step`` -- can follow.  x: fp32 [B,3,r,r] (normalised) or uint8 [B,r,r,3]; y: int [B, (r/8)^2]."""
+        x, y = batch
+        self._require_gpu()
+        self._sync_weights()
+        self._sync_grads()
+        dev = self.device
+        if x.dtype == torch.uint8:
+            kind, B, r = capi.INPUT_U8_HWC, x.shape[0], x.shape[1]
+            x = x.to(dev).contiguous()
+        else:
+            kind, B, r = capi.INPUT_F32_CHW, x.shape[0], x.shape[2]
+            x = x.to(device=dev, dtype=torch.float32).contiguous()
+        n = (r // 8) ** 2
+        y = y.to(dev).reshape(-1).long().contiguous()
+        if y.numel() != B * n:
+            raise ValueError(f"labels must have B*(r/8)^2 = {B * n} entries, got {y.numel()}")
+        loss = torch.zeros((), dtype=torch.float32, device=dev)
+        logp = torch.empty((B * n, self.cfg.n_classes), dtype=torch.float32, device=dev)
+        capi.check(capi.lib().dinoseg_train_step(self._handle, x.data_ptr(), kind, B, r, y.data_ptr(), loss.data_ptr(),
+                                                 logp.data_ptr(), capi.stream_ptr()))
+        return {"loss": loss, "pred": logp.argmax(dim=-1).detach(), "gt": y, "probs": logp}
+
+    def fused_adam_step(self, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=None, grad_scale=1.0) -> None:
+        """Fused Adam / AdamW update of every trainable parameter from its .grad (torch.optim semantics; the
+        flavour follows self.optimizer: AdamW -> decoupled decay 0.01 by default, Adam -> none)."""
+        decoupled = 1 if self.optimizer is torch.optim.AdamW else 0
+        if weight_decay is None:
+            weight_decay = 0.01 if decoupled else 0.0
+        lr = self.lr if lr is None else lr
+        state = self.__dict__.setdefault("_adam_state", {})
+        self._adam_t = getattr(self, "_adam_t", 0) + 1
+        lib = capi.lib()
+        for name, p in self.named_parameters():
+            if not p.requires_grad or p.grad is None:
+                continue
+            if name not in state or state[name][0].data_ptr() == 0 or state[name][0].device != p.device:
+                state[name] = (torch.zeros_like(p), torch.zeros_like(p))
+            m, v = state[name]
+            capi.check(lib.dinoseg_adam_step(p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr,
+                                             betas[0], betas[1], eps, weight_decay, decoupled, self._adam_t, grad_scale,
+                                             capi.stream_ptr()))
+        self._bound_sig = None      # weights changed: re-pack on the next forward / training_step
 
     def freeze_bb(self):
         for p in self.dino.parameters():

@@ -79,6 +79,25 @@ int dinoseg_prepare_resolution(dinoseg_handle* h, int32_t r, void* stream);
 int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
                     int32_t* argmax_out, int32_t tap_block, float* tap_out, void* stream);
 
+/* ---- fine-tune step (replaces DINOSeg.training_step + autograd + optimizer.step, pl_torch_modules.py:258-268) ---- */
+
+/* Bind (or, with NULL, unbind) the fp32 gradient buffer of a parameter, same shape as the bound weight.  A parameter
+ * without a bound gradient is frozen; with no "dino.*" gradient bound the backward stops at the head
+ * (freeze_bb, pl_torch_modules.py:434-436). */
+int dinoseg_bind_grad(dinoseg_handle* h, const char* name, float* dev_ptr);
+
+/* One training step on this rank's B frames: forward with saved activations, loss = F.nll_loss(log_probs, labels)
+ * (mean over B*(r/8)^2 patches; labels int64 on device), backward.  Every bound gradient buffer is OVERWRITTEN with
+ * d loss / d parameter; *loss_out (device float) receives the loss; logp_out (optional) the log-probabilities.
+ * Call dinoseg_refresh_weights() after the optimiser changed the parameters. */
+int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, const int64_t* labels,
+                       float* loss_out, float* logp_out, void* stream);
+
+/* Fused Adam (decoupled = 0: torch.optim.Adam, weight decay added to the gradient) / AdamW (decoupled = 1) update of
+ * one tensor; step counts from 1; grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+int dinoseg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int32_t decoupled, int32_t step, float grad_scale, void* stream);
+
 /* Per-kernel-class timing with HIP events recorded on the forward's stream (used by bench.py for the
  * roofline leg).  level 0 = off, 1 = the dominant kernel only (fused attention), 2 = every class.
  * dinoseg_profile_read() waits for the recorded events, writes the summed milliseconds and launch counts
@@ -134,6 +153,17 @@ int dinoseg_op_patch_gather(const void* x, int32_t x_kind, int32_t B, int32_t r,
 /* last Linear + log_softmax + argmax (pl_torch_modules.py:122-123,:294); in: hi/lo planes [2][M][ld] */
 int dinoseg_op_head_final(const void* in, int64_t in_plane, int32_t ld, int32_t M, int32_t K, const float* W,
                           const float* b, int32_t C, float* logp, int32_t* argmax, void* stream);
+
+/* flash-attention backward: q,k,v as the forward; dO, O: ctx-layout planes [planes][B*ntok][heads*64]; lse from the
+ * forward; scratch: 2*B*heads*npad floats; dqkv out: planes [planes][B*ntok][3*heads*64] (gradient of the qkv
+ * projection output, Q|K|V columns). */
+int dinoseg_op_attention_bwd(const void* q, const void* k, const void* v, int64_t qkv_plane, const void* dO, const void* O,
+                             int64_t o_plane, const float* lse, float* scratch, void* dqkv, int64_t dqkv_plane, int32_t B,
+                             int32_t heads, int32_t ntok, int32_t npad, int32_t planes, void* stream);
+
+/* native_layer_norm_backward: dx (+)= ..., dgamma += ..., dbeta += ... (atomics; zero them first) */
+int dinoseg_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int32_t M, int32_t D, float* dx,
+                             int32_t accumulate, float* dgamma, float* dbeta, int32_t drop_cls, int32_t ntok, void* stream);
 
 #ifdef __cplusplus
 }

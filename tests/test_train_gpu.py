@@ -1,0 +1,190 @@
+"""Fine-tune step parity (-m gpu): native forward+backward+Adam (through the C-ABI) against the gradient goldens
+captured from the reference ViT + torch autograd (G6) and against the CPU oracle's autograd."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dino_amd import DINOSeg, ViTConfig, capi, procedural_state_dict
+from dino_amd.weights import synthetic_frames, synthetic_labels
+from oracle import dinoseg_oracle as O
+from tests.gpu_util import pack, seeded, unpack
+
+pytestmark = pytest.mark.gpu
+S = capi.stream_ptr
+TINY = ViTConfig(embed_dim=128, num_heads=2, n_blocks=2)
+LOG2E = 1.4426950408889634
+
+
+def build(cfg, precision="bf16x3", optimizer=torch.optim.Adam, lr=1e-3):
+    sd = procedural_state_dict(cfg)
+    m = DINOSeg(head=cfg.head, n_blocks=cfg.n_blocks, n_classes=cfg.n_classes, precision=precision, arch=cfg,
+                optimizer=optimizer, lr=lr)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.to("cuda:0"), sd
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.mark.parametrize("D", [128, 384])
+def test_layernorm_bwd(cuda, D):
+    M, ntok = 3 * 29, 29
+    x = (seeded((M, D), 1) * 2 + 0.3).cpu().requires_grad_(True)
+    g = (1 + 0.2 * seeded((D,), 2)).cpu().requires_grad_(True)
+    b = (0.1 * seeded((D,), 3)).cpu().requires_grad_(True)
+    dy = seeded((M, D), 4).cpu()
+    y = O.layer_norm(x, g, b, 1e-6)
+    y.backward(dy)
+    dx0 = seeded((M, D), 5)
+    dx = dx0.clone()
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dyc, xc, gc = dy.cuda(), x.detach().cuda(), g.detach().cuda()     # keep the device tensors alive across the call
+    capi.check(capi.lib().dinoseg_op_layernorm_bwd(dyc.data_ptr(), xc.data_ptr(), gc.data_ptr(), 1e-6, M, D, dx.data_ptr(), 1,
+                                                   dg.data_ptr(), db.data_ptr(), 0, ntok, S()))
+    assert float((dx.cpu() - dx0.cpu() - x.grad).abs().max()) <= 2e-5
+    assert float((dg.cpu() - g.grad).abs().max()) <= 2e-4 and float((db.cpu() - b.grad).abs().max()) <= 2e-4
+
+
+def _attn_bwd_case(B, H, ntok, planes, seed):
+    npad = (ntok + 63) // 64 * 64
+    g = np.random.default_rng(seed)
+    Q = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32))
+    K = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32))
+    V = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32))
+    dO = torch.from_numpy(g.standard_normal((B * ntok, H * 64)).astype(np.float32)) * 0.1
+
+    def planes_of(x, shape_pad):
+        full = torch.zeros(shape_pad, dtype=torch.float32)
+        full[tuple(slice(0, s) for s in x.shape)] = x
+        return pack(full.reshape(-1, shape_pad[-1]).cuda(), planes)
+
+    qp = planes_of(Q * (0.125 * LOG2E), (B, H, npad, 64))
+    kp, vp = planes_of(K, (B, H, npad, 64)), planes_of(V, (B, H, npad, 64))
+    dop = pack(dO.cuda(), planes)
+    lib = capi.lib()
+    ctx = torch.zeros((planes, B * ntok, H * 64), dtype=torch.int16, device="cuda")
+    lse = torch.zeros((B, H, ntok), dtype=torch.float32, device="cuda")
+    plane = B * H * npad * 64
+    capi.check(lib.dinoseg_op_attention(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), plane, ctx.data_ptr(), B * ntok * H * 64,
+                                        lse.data_ptr(), B, H, ntok, npad, planes, S()))
+    scratch = torch.zeros(2 * B * H * npad, device="cuda")
+    dqkv = torch.zeros((planes, B * ntok, 3 * H * 64), dtype=torch.int16, device="cuda")
+    capi.check(lib.dinoseg_op_attention_bwd(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), plane, dop.data_ptr(), ctx.data_ptr(),
+                                            B * ntok * H * 64, lse.data_ptr(), scratch.data_ptr(), dqkv.data_ptr(),
+                                            B * ntok * 3 * H * 64, B, H, ntok, npad, planes, S()))
+    torch.cuda.synchronize()
+    # fp64 autograd reference on the operands the kernels saw (gradient w.r.t. the UNSCALED q)
+    qd = (unpack(qp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu() / (0.125 * LOG2E)).requires_grad_(True)
+    kd = unpack(kp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu().requires_grad_(True)
+    vd = unpack(vp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu().requires_grad_(True)
+    p = torch.softmax((qd @ kd.transpose(-1, -2)) * 0.125, dim=-1)
+    out = (p @ vd).transpose(1, 2).reshape(B * ntok, H * 64)
+    out.backward(unpack(dop).double().cpu())
+    got = unpack(dqkv).cpu().reshape(B, ntok, 3, H, 64).permute(2, 0, 3, 1, 4)
+    return got, (qd.grad.float(), kd.grad.float(), vd.grad.float())
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+@pytest.mark.parametrize("B,H,ntok", [(1, 1, 64), (2, 2, 197), (1, 2, 65), (1, 1, 901)])
+def test_attention_bwd(cuda, planes, B, H, ntok):
+    got, ref = _attn_bwd_case(B, H, ntok, planes, seed=3 * ntok + planes)
+    for i, name in enumerate("qkv"):
+        scale = float(ref[i].abs().max())
+        err = float((got[i] - ref[i]).abs().max())
+        assert err <= (2e-2 if planes == 1 else 2e-4) * scale, (name, err, scale)
+
+
+def _check_grads(model, g, tag, sd, rel):
+    for k, p in model.named_parameters():
+        gn = float(g[f"{tag}|gnorm|{k}"])
+        gv = p.grad.detach().cpu().reshape(-1)
+        assert torch.isfinite(gv).all(), k
+        assert abs(float(gv.norm()) - gn) <= rel * gn + 1e-7, (k, float(gv.norm()), gn)
+        idx = torch.from_numpy(g[f"{tag}|gidx|{k}"])
+        assert float((gv[idx] - torch.from_numpy(g[f"{tag}|gval|{k}"])).abs().max()) <= rel * gn + 1e-7, k
+
+
+@pytest.mark.parametrize("tag,cfg", [("tiny_r64_B2", TINY), ("vits8_L3_r64_B2", ViTConfig(n_blocks=3))])
+def test_train_step_matches_reference_gradients(cuda, golden_dir, tag, cfg):
+    """G6: loss and gradients of the reference ViT + head under F.nll_loss, B=2 frames at 64x64, all 48 tensors."""
+    g = load(golden_dir, "g6_finetune")
+    m, sd = build(cfg)
+    m.unfreeze_bb()
+    frames = torch.from_numpy(synthetic_frames(2, 64, seed=61)).cuda()
+    labels = torch.from_numpy(synthetic_labels(2, 64, cfg.n_classes, seed=62)).cuda()
+    out = m.training_step((frames, labels), 0)
+    assert abs(float(out["loss"]) - float(g[f"{tag}|loss"])) <= 2e-4
+    _check_grads(m, g, tag, sd, rel=2e-3)
+    # the fp32 CHW entry gives the same gradients as the uint8 entry
+    x = O.preprocess(frames.cpu().numpy()).cuda()
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+    out2 = m.training_step((x, labels), 0)
+    assert abs(float(out2["loss"]) - float(out["loss"])) <= 1e-6
+    for k, p in m.named_parameters():
+        assert float((p.grad - ref[k]).abs().max()) <= 1e-5 * (float(ref[k].abs().max()) + 1e-6), k
+
+
+def test_frozen_backbone_trains_only_the_head(cuda, golden_dir):
+    g = load(golden_dir, "g6_finetune")
+    cfg = ViTConfig(n_blocks=3)
+    m, sd = build(cfg)
+    m.freeze_bb()
+    frames = torch.from_numpy(synthetic_frames(2, 64, seed=61)).cuda()
+    labels = torch.from_numpy(synthetic_labels(2, 64, 7, seed=62)).cuda()
+    out = m.training_step((frames, labels), 0)
+    assert abs(float(out["loss"]) - float(g["vits8_L3_r64_B2|loss"])) <= 2e-4
+    with_grad = [k for k, p in m.named_parameters() if p.grad is not None]
+    assert sorted(with_grad) == sorted(k for k in sd if k.startswith("clf."))      # 6 tensors, as the reference (G9)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            gn = float(g[f"vits8_L3_r64_B2|gnorm|{k}"])
+            assert abs(float(p.grad.norm()) - gn) <= 2e-3 * gn
+
+
+@pytest.mark.parametrize("oname,opt,lr", [("adam", torch.optim.Adam, 1e-3), ("adamw", torch.optim.AdamW, 1e-6)])
+def test_two_optimizer_steps_match_reference(cuda, golden_dir, oname, opt, lr):
+    g = load(golden_dir, "g6_finetune")
+    tag, cfg = "tiny_r64_B2", TINY
+    m, sd = build(cfg, optimizer=opt, lr=lr)
+    m.unfreeze_bb()
+    frames = torch.from_numpy(synthetic_frames(2, 64, seed=61)).cuda()
+    labels = torch.from_numpy(synthetic_labels(2, 64, cfg.n_classes, seed=62)).cuda()
+    losses = []
+    for _ in range(2):
+        out = m.training_step((frames, labels), 0)
+        losses.append(float(out["loss"]))
+        m.fused_adam_step()
+    want = g[f"{tag}|{oname}|losses"]
+    assert abs(losses[0] - want[0]) <= 2e-4 and abs(losses[1] - want[1]) <= 5e-3
+    for i, (k, p) in enumerate(m.named_parameters()):
+        d = (p.detach().cpu() - torch.from_numpy(sd[k])).reshape(-1)
+        idx = torch.from_numpy(np.sort(np.random.default_rng(i).choice(d.numel(), size=min(64, d.numel()), replace=False)))
+        ref = torch.from_numpy(g[f"{tag}|{oname}|delta|{k}"])
+        # Adam's first steps are ~ +-lr per element (sign of the gradient).  Elements whose reference gradient is
+        # numerical noise (e.g. the K bias: softmax is invariant to it) have a random sign in the reference too.
+        gval = torch.from_numpy(g[f"{tag}|gval|{k}"]).abs()
+        rms = float(g[f"{tag}|gnorm|{k}"]) / np.sqrt(d.numel())
+        sig = gval > 0.05 * rms
+        assert int(sig.sum()) >= min(8, d.numel() // 4), k
+        err = (d[idx] - ref).abs()[sig]
+        assert float(err.max()) <= 0.25 * 2 * lr + 1e-9, k
+        assert float(err.mean()) <= 0.03 * 2 * lr + 1e-9, k
+
+
+def test_train_step_linear_head_vs_oracle_autograd(cuda):
+    cfg = ViTConfig(n_blocks=1, head="linear")
+    m, sd = build(cfg)
+    m.unfreeze_bb()
+    frames = synthetic_frames(2, 96, seed=8)
+    labels = synthetic_labels(2, 144, 7, seed=9)
+    out = m.training_step((torch.from_numpy(frames).cuda(), torch.from_numpy(labels).cuda()), 0)
+    W = O.to_torch(sd, requires_grad=True)
+    loss = O.nll_loss(O.dinoseg_forward(O.preprocess(frames), W, cfg.num_heads), torch.from_numpy(labels))
+    loss.backward()
+    assert abs(float(out["loss"]) - float(loss)) <= 2e-4
+    for k, p in m.named_parameters():
+        gn = float(W[k].grad.norm())
+        assert float((p.grad.cpu() - W[k].grad).abs().max()) <= 3e-3 * gn + 1e-7, k
