@@ -73,6 +73,63 @@ def cpu_baseline(cfg, sd, r, budget_s=20.0):
                       f"(first = warm-up), best {best * 1e3:.0f} ms, torch {torch.__version__} CPU threads={cores}"}
 
 
+def bench_finetune(a, world, rank, dev):
+    """Fine-tune step throughput: ViT-S/8 truncated to 3 blocks + MLP head, all 48 tensors trainable, Adam lr 1e-3
+    (run_experiment.py:135-136), 480x480 frames, batch 8 per GPU (global 64 at 8 GPUs), parity precision (bf16x3)
+    unless --precision bf16.  One step = forward + backward + gradient all-reduce + fused Adam."""
+    import torch
+    import torch.distributed as dist
+    from dino_amd import DINOSeg, ViTConfig, procedural_state_dict
+    from dino_amd.parallel import DataParallelFineTuner
+    from dino_amd.weights import synthetic_frames, synthetic_labels
+    blocks = 3 if a.blocks == 12 else a.blocks
+    per_gpu = 8 if a.batch == 32 else a.batch
+    cfg = ViTConfig(n_blocks=blocks)
+    sd = procedural_state_dict(cfg)
+    model = DINOSeg(head="mlp", n_blocks=blocks, precision=a.precision, arch=cfg, optimizer=torch.optim.Adam, lr=1e-3)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.to(dev)
+    model.unfreeze_bb()
+    n = (a.res // 8) ** 2
+    frames = torch.from_numpy(synthetic_frames(per_gpu * world, a.res, seed=7)).to(dev)
+    labels = torch.from_numpy(synthetic_labels(per_gpu * world, n, 7, seed=8)).to(dev)
+    tuner = DataParallelFineTuner(model, fused_optimizer=True)
+    for _ in range(a.warmup):
+        tuner.step(frames, labels)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tuner.step(frames, labels)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fl = flops_per_frame(cfg.embed_dim, cfg.num_heads, blocks, a.res)
+    fps = per_gpu * world * a.steps / elapsed
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/sec (480x480, ViT-S/8 x3 blocks) DINOSeg fine-tune step", "value": round(fps, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic", "final_loss": round(float(loss), 5),
+            "config": {"workload": f"fine-tune step: ViT-S/8 x{blocks} blocks + MLP head unfrozen (48 tensors), fwd+bwd+"
+                                   f"grad all-reduce+fused Adam, {a.res}x{a.res}, batch {per_gpu}/GPU", "blocks": blocks,
+                       "batch_per_gpu": per_gpu, "global_batch": per_gpu * world, "resolution": a.res,
+                       "precision": a.precision, "parallelism": f"dp{world} (RCCL gradient all-reduce, 22.1 MiB fp32)"},
+            "model_mfma_frac": round(fps / world * 3 * fl["total"] / 1e12 / MFMA_PEAK_TFLOPS[a.precision], 4),
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +143,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class (adds event overhead)")
     ap.add_argument("--option", action="append", default=[], help="library tuning knob key=int (dinoseg_set_option)")
+    ap.add_argument("--mode", default="infer", choices=["infer", "finetune"],
+                    help="infer: the headline metric; finetune: BASELINE configs[3] (3-block unfrozen step, batch 8/GPU, "
+                         "gradient all-reduce over RCCL, fused Adam)")
     a = ap.parse_args()
 
     import numpy as np
@@ -111,6 +171,8 @@ def main():
     for kv in a.option:
         key, val = kv.split("=")
         capi.check(capi.lib().dinoseg_set_option(key.encode(), int(val)))
+    if a.mode == "finetune":
+        return bench_finetune(a, world, rank, dev)
     base = VIT_S8 if a.arch == "vit_small" else VIT_B8
     cfg = ViTConfig(embed_dim=base.embed_dim, num_heads=base.num_heads, n_blocks=a.blocks)
     sd = procedural_state_dict(cfg)
