@@ -118,6 +118,88 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
                 C[(wr * 64 + i * 32 + acc_row(r, lh)) * 128 + wc * 64 + j * 32 + lr] = acc[i][j][r];
     __syncthreads();
 
+    // ---- bf16-plane outputs: 8 columns per thread -> one 16-byte store per plane (8-byte stores were
+    //      store-issue bound: ~2.4 TB/s of output against 4-6 TB/s for the 16-byte fp32 epilogues)
+    constexpr bool BF16_OUT = (EPI == EPI_GELU || EPI == EPI_RELU || EPI == EPI_QKV || EPI == EPI_BF16 ||
+                               EPI == EPI_DGELU || EPI == EPI_DRELU);
+    if (BF16_OUT) {
+        const int c8 = tid & 15, rb16 = tid >> 4;
+        const int gn = n0 + c8 * 8;
+        float b8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[e] = p.bias ? p.bias[gn + e] : 0.f;
+        // QKV scatter: a 128-column tile lies inside one of Q / K / V, an 8-column group inside one head
+        const int which = (EPI == EPI_QKV) ? n0 / p.dmodel : 0;
+        const int hcol = (EPI == EPI_QKV) ? n0 % p.dmodel + c8 * 8 : 0;
+        bf16_t* qkv_base = (EPI == EPI_QKV) ? (which == 0 ? p.q : (which == 1 ? p.k : p.v)) : nullptr;
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 16 + rb16;
+            const int gm = m0 + row;
+            if (gm >= M) break;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(C + row * 128 + c8 * 8);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(C + row * 128 + c8 * 8 + 4);
+            float v[8] = {v0[0] + b8[0], v0[1] + b8[1], v0[2] + b8[2], v0[3] + b8[3],
+                          v1[0] + b8[4], v1[1] + b8[5], v1[2] + b8[6], v1[3] + b8[7]};
+            if (EPI == EPI_GELU && p.aux_out) {        // training: keep the pre-activation for gelu'
+                bf16_t* ad = p.aux_out + (long)gm * p.ldo + gn;
+                uint4 ph, plo;
+                split_bf16x2(v[0], v[1], ph.x, plo.x);
+                split_bf16x2(v[2], v[3], ph.y, plo.y);
+                split_bf16x2(v[4], v[5], ph.z, plo.z);
+                split_bf16x2(v[6], v[7], ph.w, plo.w);
+                *reinterpret_cast<uint4*>(ad) = ph;
+                if (PLANES == 2) *reinterpret_cast<uint4*>(ad + p.aux_plane) = plo;
+            }
+            if (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+                const bf16_t* ax = p.aux_in + (long)gm * p.ldo + gn;
+                const uint4 ah = *reinterpret_cast<const uint4*>(ax);
+                const uint32_t aw[4] = {ah.x, ah.y, ah.z, ah.w};
+                float a[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[2 * e] = bf16_lo_to_f32(aw[e]);
+                    a[2 * e + 1] = bf16_hi_to_f32(aw[e]);
+                }
+                if (PLANES == 2 && EPI == EPI_DGELU) {
+                    const uint4 al = *reinterpret_cast<const uint4*>(ax + p.aux_plane);
+                    const uint32_t lw[4] = {al.x, al.y, al.z, al.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[2 * e] += bf16_lo_to_f32(lw[e]);
+                        a[2 * e + 1] += bf16_hi_to_f32(lw[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= (EPI == EPI_DGELU) ? gelu_erf_grad(a[e]) : (a[e] > 0.f ? 1.f : 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (EPI == EPI_GELU) v[e] = gelu_erf(v[e]);
+                if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+                if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
+            }
+            uint4 hi, lo;
+            split_bf16x2(v[0], v[1], hi.x, lo.x);
+            split_bf16x2(v[2], v[3], hi.y, lo.y);
+            split_bf16x2(v[4], v[5], hi.z, lo.z);
+            split_bf16x2(v[6], v[7], hi.w, lo.w);
+            bf16_t* dst;
+            long plane_stride;
+            if (EPI == EPI_QKV) {
+                const int b = gm / p.ntok, tok = gm - b * p.ntok;
+                dst = qkv_base + ((long)(b * p.heads + (hcol >> 6)) * p.npad + tok) * 64 + (hcol & 63);
+                plane_stride = p.qkv_plane;
+            } else {
+                dst = p.out_bf16 + (long)gm * p.ldo + gn;
+                plane_stride = p.out_plane;
+            }
+            *reinterpret_cast<uint4*>(dst) = hi;
+            if (PLANES == 2) *reinterpret_cast<uint4*>(dst + plane_stride) = lo;
+        }
+        return;
+    }
+
     const int c4 = tid & 31, rb = tid >> 5;
     const int gn = n0 + c4 * 4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -141,61 +223,11 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (p.n_valid == 0 || gn + e < p.n_valid) atomicAdd(dst + e, v[e]);
-        } else if (EPI == EPI_BF16 || EPI == EPI_DGELU || EPI == EPI_DRELU) {
-            if (EPI != EPI_BF16) {
-                const bf16_t* ax = p.aux_in + (long)gm * p.ldo + gn;
-                const uint2 ah = *reinterpret_cast<const uint2*>(ax);
-                float a[4] = {bf16_lo_to_f32(ah.x), bf16_hi_to_f32(ah.x), bf16_lo_to_f32(ah.y), bf16_hi_to_f32(ah.y)};
-                if (PLANES == 2 && EPI == EPI_DGELU) {
-                    const uint2 al = *reinterpret_cast<const uint2*>(ax + p.aux_plane);
-                    a[0] += bf16_lo_to_f32(al.x);
-                    a[1] += bf16_hi_to_f32(al.x);
-                    a[2] += bf16_lo_to_f32(al.y);
-                    a[3] += bf16_hi_to_f32(al.y);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= (EPI == EPI_DGELU) ? gelu_erf_grad(a[e]) : (a[e] > 0.f ? 1.f : 0.f);
-            }
-            bf16_t* dst = p.out_bf16 + (long)gm * p.ldo + gn;
-            uint2 hi, lo;
-            split_bf16x2(v[0], v[1], hi.x, lo.x);
-            split_bf16x2(v[2], v[3], hi.y, lo.y);
-            *reinterpret_cast<uint2*>(dst) = hi;
-            if (PLANES == 2) *reinterpret_cast<uint2*>(dst + p.out_plane) = lo;
         } else if (EPI == EPI_PATCH) {
             const int b = gm / p.n_patches, pi = gm - b * p.n_patches;
             const long xrow = (long)b * (p.n_patches + 1) + 1 + pi;
             f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (long)(1 + pi) * p.ldo_f32 + gn);
             *reinterpret_cast<f32x4*>(p.out_f32 + xrow * p.ldo_f32 + gn) = v + pe;
-        } else if (EPI == EPI_GELU || EPI == EPI_RELU) {
-            if (EPI == EPI_GELU && p.aux_out) {        // training: keep the pre-activation for gelu'
-                bf16_t* ad = p.aux_out + (long)gm * p.ldo + gn;
-                uint2 ph, plo;
-                split_bf16x2(v[0], v[1], ph.x, plo.x);
-                split_bf16x2(v[2], v[3], ph.y, plo.y);
-                *reinterpret_cast<uint2*>(ad) = ph;
-                if (PLANES == 2) *reinterpret_cast<uint2*>(ad + p.aux_plane) = plo;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (EPI == EPI_GELU) ? gelu_erf(v[e]) : fmaxf(v[e], 0.f);
-            bf16_t* dst = p.out_bf16 + (long)gm * p.ldo + gn;
-            uint2 hi, lo;
-            split_bf16x2(v[0], v[1], hi.x, lo.x);
-            split_bf16x2(v[2], v[3], hi.y, lo.y);
-            *reinterpret_cast<uint2*>(dst) = hi;
-            if (PLANES == 2) *reinterpret_cast<uint2*>(dst + p.out_plane) = lo;
-        } else if (EPI == EPI_QKV) {
-            const int which = n0 / p.dmodel;               // 0: Q, 1: K, 2: V  (block-uniform)
-            const int hcol = n0 % p.dmodel + c4 * 4;
-            const int head = hcol >> 6, d = hcol & 63;
-            const int b = gm / p.ntok, tok = gm - b * p.ntok;
-            if (which == 0) v *= p.qscale;
-            bf16_t* dst = (which == 0 ? p.q : (which == 1 ? p.k : p.v)) + ((long)(b * p.heads + head) * p.npad + tok) * 64 + d;
-            uint2 hi, lo;
-            split_bf16x2(v[0], v[1], hi.x, lo.x);
-            split_bf16x2(v[2], v[3], hi.y, lo.y);
-            *reinterpret_cast<uint2*>(dst) = hi;
-            if (PLANES == 2) *reinterpret_cast<uint2*>(dst + p.qkv_plane) = lo;
         }
     }
 }

@@ -6,41 +6,54 @@
 //   * 256 x 384 output tile per 512-thread workgroup (8 waves as 2(M) x 4(N), wave tile 128 x 96 =
 //     4 x 3 v_mfma_f32_32x32x16_bf16 accumulators = 192 registers) -> 154 FLOP per staged byte;
 //     every N of the model (384, 1152, 1536; ViT-B 768, 2304, 3072) is a multiple of 384.
-//   * BK = 32 k-slabs ([256][32] + [384][32] bf16 = 40 KiB) in a 4-slot LDS ring = all 160 KiB of the CU,
-//     filled by LDS-DMA with a counted `s_waitcnt vmcnt(N)` + raw `s_barrier` per slab, so 2-3 slabs (80-120 KiB)
+//   * BK = 32 k-slabs ([256][32] + [384][32] bf16 = 40 KiB) in a 3-slot LDS ring (120 KiB),
+//     filled by LDS-DMA with a counted `s_waitcnt vmcnt(N)` + raw `s_barrier` per slab, so up to 2 slabs (80 KiB)
 //     are in flight while one is being multiplied.
 //   * persistent: one workgroup per CU walks its tiles; the ring runs continuously across tile boundaries, so
 //     the next tile's first slabs land while the current tile's epilogue drains from registers.
 //   * XCD-aware tile walk: the column tiles of one A row panel are taken by workgroups of one XCD back-to-back.
-//   * epilogue straight from registers (the ring owns all of LDS): in the 32x32 accumulator a register's 32 lanes
-//     are 32 consecutive columns of one row, so fp32 stores are whole 128-byte row segments; bf16 outputs pair
-//     adjacent lanes with one DPP move and store 64-byte row segments.  (A first version with 4 columns per lane
-//     and 16-byte accesses touched 32 rows per instruction and cost 4x the main loop.)
+//   * epilogue through wave-private 4 KiB LDS patches: every global access is 16 bytes per lane on whole 64/128-byte
+//     row segments.  (Two earlier versions -- 4 columns per lane touching 32 rows per instruction, and 4-byte
+//     row-segment stores straight from the accumulators -- cost 1-4x the main loop: store-issue bound.)
 #include "common.h"
 #include "kernels.h"
 
 namespace dseg {
 
 namespace big {
-constexpr int BM = 256, BN = 384, BK = 32, STAGES = 4;
-constexpr int A_BYTES = BM * BK * 2;           // 16 KiB
-constexpr int W_BYTES = BN * BK * 2;           // 24 KiB
-constexpr int STAGE_BYTES = A_BYTES + W_BYTES; // 40 KiB
-constexpr int PIECES_PER_WAVE = (STAGE_BYTES / 1024) / 8;   // 5 LDS-DMA instructions per wave per slab
+constexpr int BK = 32;
+// WM x WN waves, each MI x NI accumulators of 32x32; STAGES ring slots; WGS = persistent workgroups per CU
+template <int WM_, int WN_, int MI_, int NI_, int STAGES_, int WGS_>
+struct Cfg {
+    static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, STAGES = STAGES_, WGS = WGS_;
+    static constexpr int NWAVES = WM * WN, THREADS = NWAVES * 64;
+    static constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int A_PIECES = A_BYTES / 1024;
+    static constexpr int PIECES_PER_WAVE = (STAGE_BYTES / 1024) / NWAVES;
+    static_assert((STAGE_BYTES / 1024) % NWAVES == 0, "LDS-DMA pieces must divide evenly over the waves");
+    static constexpr int WAVES_PER_SIMD = (NWAVES * WGS + 3) / 4;
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES + NWAVES * 4096;   // ring + one 32x32 fp32 patch per wave
+};
+using Cfg256x384 = Cfg<2, 4, 4, 3, 3, 1>;   // 120 KiB ring + 32 KiB epilogue patches, 1 workgroup / CU, 154 FLOP per staged byte
+using Cfg128x128 = Cfg<2, 2, 2, 2, 2, 3>;   // 32 KiB ring + 16 KiB patches, 3 workgroups / CU (phases of different tiles overlap)
+using Cfg128x192 = Cfg<2, 2, 2, 3, 2, 3>;   // 40 KiB ring + 16 KiB patches, 3 workgroups / CU (BN = 192: fewer bytes per FLOP than 128x128)
 
 // 64-byte rows (4 chunks of 16 B): XOR the chunk with (row>>2)&3 -> the 16 rows of a ds_read_b128 lane group
 // fall on 16 distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int off64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 }  // namespace big
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
+template <int EPI, class C>
+__global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel(GemmParams p) {
     using namespace big;
+    constexpr int BM = C::BM, BN = C::BN, STAGES = C::STAGES, STAGE_BYTES = C::STAGE_BYTES, A_BYTES = C::A_BYTES;
+    constexpr int PIECES_PER_WAVE = C::PIECES_PER_WAVE, MI = C::MI, NI = C::NI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;         // 2 x 4 waves
+    const int wr = wave / C::WN, wc = wave % C::WN;
     const int lr = lane & 31, lh = lane >> 5;
 
     const int M = p.M, K = p.K;
@@ -69,16 +82,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         const int prow = lane >> 2;                         // row inside a 16-row piece
 #pragma unroll
         for (int i = 0; i < PIECES_PER_WAVE; ++i) {
-            const int piece = wave * PIECES_PER_WAVE + i;   // 0..15: A rows, 16..39: W rows
+            const int piece = wave * PIECES_PER_WAVE + i;   // first A_PIECES pieces: A rows, then W rows
             const bf16_t* src;
-            if (piece < 16) {
+            if (piece < C::A_PIECES) {
                 const int row = piece * 16 + prow;
                 const int c = (lane & 3) ^ ((row >> 2) & 3);
                 int gm = bm * BM + row;
                 gm = gm < M ? gm : M - 1;
                 src = p.A + (long)gm * p.lda + kt * BK + c * 8;
             } else {
-                const int row = (piece - 16) * 16 + prow;
+                const int row = (piece - C::A_PIECES) * 16 + prow;
                 const int c = (lane & 3) ^ ((row >> 2) & 3);
                 src = p.W + (long)(p.n_off + bn * BN + row) * K + kt * BK + c * 8;
             }
@@ -86,12 +99,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         }
     };
 
-    f32x16 acc[4][3];
+    f32x16 acc[MI][NI];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
@@ -122,15 +135,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         tile_of(ti, bm, bn);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], wf[3];
+            bf16x8 af[MI], wf[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = lds_frag(sa + off64(wr * 128 + i * 32 + lr, kk * 2 + lh));
+            for (int i = 0; i < MI; ++i) af[i] = lds_frag(sa + off64(wr * MI * 32 + i * 32 + lr, kk * 2 + lh));
 #pragma unroll
-            for (int j = 0; j < 3; ++j) wf[j] = lds_frag(sw + off64(wc * 96 + j * 32 + lr, kk * 2 + lh));
+            for (int j = 0; j < NI; ++j) wf[j] = lds_frag(sw + off64(wc * NI * 32 + j * 32 + lr, kk * 2 + lh));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);   // lane: column n, registers: rows m
+                for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);   // lane: column n, registers: rows m
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -138,101 +151,77 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
             // ================= epilogue from registers =================
             kt = 0;
             ++ti;
-            const int m0 = bm * BM + wr * 128, n0 = p.n_off + bn * BN + wc * 96;
+            const int m0 = bm * BM + wr * MI * 32, n0 = p.n_off + bn * BN + wc * NI * 32;
             const bool skip_epi = (p.dbg & 1) && acc[0][0][0] != 12345.678f;   // ablation (keeps accumulators live)
             if (!skip_epi) {
-            // acc[i][j][r] = C[m0 + i*32 + acc_row(r, lh)][n0 + j*32 + lr]: for a fixed register the 32 lanes of a
-            // half-wave hold 32 consecutive columns of one row -> every store instruction writes whole 64/128-byte
-            // row segments (2 rows x 128 B for fp32; 4 rows x 64 B for bf16 after pairing adjacent lanes by DPP).
-            float bv[3];
+            // Each 32x32 accumulator goes through a wave-private 4 KiB LDS patch (no workgroup barrier: LDS requests of
+            // one wave complete in order) and leaves as 16-byte-per-lane row segments: 8 rows x 128 B per fp32 store
+            // instruction, 16 rows x 64 B per bf16 one.  (Narrower stores were store-issue bound: 4-byte stores straight
+            // from the accumulators cost as much as the main loop.)
+            float* st = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES + wave * 4096);
+            constexpr bool F32_OUT = (EPI == EPI_PLAIN || EPI == EPI_RESID || EPI == EPI_PATCH);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) bv[j] = p.bias[n0 + j * 32 + lr];
-            const int odd = lane & 1;
+            for (int j = 0; j < NI; ++j) {
+                const int cg = F32_OUT ? (lane & 7) : (lane & 3);
+                const int gn = n0 + j * 32 + cg * (F32_OUT ? 4 : 8);
+                float bb[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int mrow0 = m0 + i * 32 + 4 * lh;            // row of register 0; register r adds (r&3) + 8*(r>>2)
-                if (EPI == EPI_PLAIN || EPI == EPI_RESID || EPI == EPI_PATCH) {
+                for (int e = 0; e < (F32_OUT ? 4 : 8); ++e) bb[e] = p.bias[gn + e];
+                int which = 0, hcol = 0;
+                bf16_t* qkv_base = nullptr;
+                if (EPI == EPI_QKV) {
+                    which = gn / p.dmodel;
+                    hcol = gn - which * p.dmodel;
+                    qkv_base = which == 0 ? p.q : (which == 1 ? p.k : p.v);
+                }
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int gn = n0 + j * 32 + lr;
+                for (int i = 0; i < MI; ++i) {
 #pragma unroll
-                        for (int half = 0; half < 2; ++half) {       // batches of 8 rows: loads issued ahead of the stores
-                            float x[8];
-                            if (EPI == EPI_RESID || EPI == EPI_PATCH) {
+                    for (int r = 0; r < 16; ++r) st[acc_row(r, lh) * 32 + lr] = acc[i][j][r];
+                    if (F32_OUT) {
 #pragma unroll
-                                for (int rr = 0; rr < 8; ++rr) {
-                                    const int r = half * 8 + rr;
-                                    int gm = mrow0 + (r & 3) + 8 * (r >> 2);
-                                    gm = gm < M ? gm : M - 1;
-                                    if (EPI == EPI_RESID) {
-                                        x[rr] = p.out_f32[(long)gm * p.ldo_f32 + gn];
-                                    } else {
-                                        const int tok = gm % p.n_patches;
-                                        x[rr] = p.pos[(long)(1 + tok) * p.ldo_f32 + gn];
-                                    }
-                                }
-                            }
-#pragma unroll
-                            for (int rr = 0; rr < 8; ++rr) {
-                                const int r = half * 8 + rr;
-                                const int gm = mrow0 + (r & 3) + 8 * (r >> 2);
-                                if (gm < M) {
-                                    float v = acc[i][j][r] + bv[j];
-                                    long orow = gm;
-                                    if (EPI == EPI_RESID) v += x[rr];
-                                    if (EPI == EPI_PATCH) {
-                                        v += x[rr];
-                                        orow = gm + gm / p.n_patches + 1;       // b*(n+1) + 1 + tok
-                                    }
-                                    p.out_f32[orow * p.ldo_f32 + gn] = v;
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const int row = (lane >> 3) + 8 * ps;
+                            const int gm = m0 + i * 32 + row;
+                            f32x4 v = *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 4);
+                            v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3];
+                            if (gm < M) {
+                                if (EPI == EPI_PLAIN) {
+                                    *reinterpret_cast<f32x4*>(p.out_f32 + (long)gm * p.ldo_f32 + gn) = v;
+                                } else if (EPI == EPI_RESID) {
+                                    float* dst = p.out_f32 + (long)gm * p.ldo_f32 + gn;
+                                    *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + v;
+                                } else {
+                                    const int bq = gm / p.n_patches, tok = gm - bq * p.n_patches;
+                                    const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (long)(1 + tok) * p.ldo_f32 + gn);
+                                    *reinterpret_cast<f32x4*>(p.out_f32 + ((long)gm + bq + 1) * p.ldo_f32 + gn) = v + pe;
                                 }
                             }
                         }
-                    }
-                } else {
-                    // bf16 outputs: even lane stores (col n, n+1) of row A, odd lane (col n-1, n) of row A+1
+                    } else {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int ra = 2 * u, rb = 2 * u + 1;
-                        const int gmA = mrow0 + (ra & 3) + 8 * (ra >> 2);
-                        const int gm = gmA + odd;
-                        long rowbase = 0;
-                        if (EPI == EPI_QKV) {
-                            int b = gm / p.ntok;
-                            const int tok = gm - b * p.ntok;
-                            rowbase = ((long)b * p.heads * p.npad + tok) * 64;
-                        } else {
-                            rowbase = (long)gm * p.ldo;
-                        }
+                        for (int ps = 0; ps < 2; ++ps) {
+                            const int row = (lane >> 2) + 16 * ps;
+                            const int gm = m0 + i * 32 + row;
+                            const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 8);
+                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 8 + 4);
+                            float v[8] = {v0[0] + bb[0], v0[1] + bb[1], v0[2] + bb[2], v0[3] + bb[3],
+                                          v1[0] + bb[4], v1[1] + bb[5], v1[2] + bb[6], v1[3] + bb[7]};
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            float va = acc[i][j][ra] + bv[j], vb = acc[i][j][rb] + bv[j];
-                            const int gn = n0 + j * 32 + lr;
-                            if (EPI == EPI_GELU) {
-                                va = gelu_erf(va);
-                                vb = gelu_erf(vb);
-                            } else if (EPI == EPI_RELU) {
-                                va = fmaxf(va, 0.f);
-                                vb = fmaxf(vb, 0.f);
-                            } else if (EPI == EPI_QKV) {
-                                if (gn < p.dmodel) {       // Q columns (uniform per j: 32 | dmodel)
-                                    va *= p.qscale;
-                                    vb *= p.qscale;
-                                }
+                            for (int e = 0; e < 8; ++e) {
+                                if (EPI == EPI_GELU) v[e] = gelu_erf(v[e]);
+                                if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+                                if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
                             }
-                            const float send = odd ? va : vb;
-                            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                                0, __builtin_bit_cast(int, send), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
-                            const uint32_t packed = odd ? pack_bf16x2(recv, vb) : pack_bf16x2(va, recv);
-                            const int gc = gn - odd;           // first of the two columns this lane stores
+                            const uint4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                             pack_bf16x2(v[6], v[7])};
                             if (gm < M) {
                                 if (EPI == EPI_QKV) {
-                                    const int which = gc / p.dmodel;
-                                    const int hcol = gc - which * p.dmodel;
-                                    bf16_t* basep = which == 0 ? p.q : (which == 1 ? p.k : p.v);
-                                    *reinterpret_cast<uint32_t*>(basep + rowbase + (long)(hcol >> 6) * p.npad * 64 + (hcol & 63)) = packed;
+                                    const int bq = gm / p.ntok, tok = gm - bq * p.ntok;
+                                    *reinterpret_cast<uint4*>(qkv_base + ((long)(bq * p.heads + (hcol >> 6)) * p.npad + tok) * 64 +
+                                                              (hcol & 63)) = o;
                                 } else {
-                                    *reinterpret_cast<uint32_t*>(p.out_bf16 + rowbase + gc) = packed;
+                                    *reinterpret_cast<uint4*>(p.out_bf16 + (long)gm * p.ldo + gn) = o;
                                 }
                             }
                         }
@@ -245,32 +234,40 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     }
 }
 
-template <int EPI>
-static int launch_big_one(const GemmParams& p, hipStream_t s) {
+template <int EPI, class C>
+static int launch_big_cfg(const GemmParams& p, hipStream_t s) {
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
         DSEG_CHECK_HIP(hipGetDevice(&dev));
         DSEG_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, big::STAGES * big::STAGE_BYTES));
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<EPI, C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     }
-    const int nbn = p.N / big::BN, nbm = (p.M + big::BM - 1) / big::BM;
-    // one persistent workgroup per CU, a multiple of the 8 XCDs; no more per XCD than it has (panel, bn) pairs
-    int per_xcd = ncu / 8;
+    const int nbn = p.N / C::BN, nbm = (p.M + C::BM - 1) / C::BM;
+    // persistent workgroups: WGS per CU, a multiple of the 8 XCDs; no more per XCD than it has (panel, bn) pairs
+    int per_xcd = ncu / 8 * C::WGS;
     const int pairs_per_xcd = ((nbm + 7) / 8) * nbn;
     if (per_xcd > pairs_per_xcd) per_xcd = pairs_per_xcd;
     if (per_xcd < 1) per_xcd = 1;
     const int grid = per_xcd * 8;
-    hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(grid), dim3(512), big::STAGES * big::STAGE_BYTES, s, p);
+    hipLaunchKernelGGL((gemm_big_kernel<EPI, C>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
+template <int EPI>
+static int launch_big_one(const GemmParams& p, hipStream_t s) {
+    const int variant = options().gemm_big;     // 1: 256x384, 2: 128x128 x3/CU, 3: 128x192 x4/CU
+    if (variant == 2 && p.N % big::Cfg128x128::BN == 0) return launch_big_cfg<EPI, big::Cfg128x128>(p, s);
+    if (variant == 3 && p.N % big::Cfg128x192::BN == 0) return launch_big_cfg<EPI, big::Cfg128x192>(p, s);
+    return launch_big_cfg<EPI, big::Cfg256x384>(p, s);
+}
+
 bool gemm_big_supported(const GemmParams& p) {
     return p.planes == 1 && p.bias != nullptr && p.epi <= EPI_QKV && p.resid == nullptr && p.aux_out == nullptr &&
-           p.ksplit <= 1 && p.N % big::BN == 0 && p.K % big::BK == 0 && p.lda % 8 == 0 && p.M >= 1 &&
-           (p.epi != EPI_QKV || (p.dmodel % big::BN == 0 && p.N == 3 * p.dmodel));
+           p.ksplit <= 1 && p.N % big::Cfg256x384::BN == 0 && p.K % big::BK == 0 && p.lda % 8 == 0 && p.M >= 1 &&
+           (p.epi != EPI_QKV || (p.dmodel % big::Cfg256x384::BN == 0 && p.N == 3 * p.dmodel));
 }
 
 int launch_gemm_big(const GemmParams& p, hipStream_t s) {

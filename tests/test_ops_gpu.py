@@ -237,11 +237,22 @@ def test_gemm_big_matches_small_kernel(cuda):
     Ap, Wp = pack(A, 1), pack(W, 1)
     lib = capi.lib()
     outs = []
-    for big in (0, 1):
+    X0 = seeded((M, N), 34)
+    for big in (0, 1, 2, 3):          # 0: 128x128 kernel; 1/2/3: persistent 256x384, 128x128 x3/CU, 128x192 x4/CU
         capi.check(lib.dinoseg_set_option(b"gemm_big", big))
         out = torch.zeros((M, N), device="cuda")
         capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, 1, capi.EPI_PLAIN,
                                        bias.data_ptr(), out.data_ptr(), None, 0, 0, S()))
-        outs.append(out)
+        X = X0.clone()
+        capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, 1, capi.EPI_RESID,
+                                       bias.data_ptr(), X.data_ptr(), None, 0, 0, S()))
+        g = torch.zeros((1, M, N), dtype=torch.int16, device="cuda")
+        capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, 1, capi.EPI_GELU,
+                                       bias.data_ptr(), None, g.data_ptr(), M * N, N, S()))
+        outs.append((out, X, unpack(g)))
     capi.check(lib.dinoseg_set_option(b"gemm_big", 1))
-    assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * float(outs[0].abs().max())
+    scale = float(outs[0][0].abs().max())
+    for big in (1, 2, 3):
+        assert float((outs[0][0] - outs[big][0]).abs().max()) <= 2e-5 * scale, big
+        assert float((outs[0][1] - outs[big][1]).abs().max()) <= 2e-5 * scale, big
+        assert float((outs[0][2] - outs[big][2]).abs().max()) <= 2.0 ** -7 * float(outs[0][2].abs().max()), big

@@ -32,7 +32,7 @@ def rand_bf16(shape):
     return (torch.randn(shape, device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
 
 
-def bench_gemm():
+def bench_gemm(quick=True):
     lib = capi.lib()
     B, ntok, D = 32, 3601, 384
     M = B * ntok
@@ -47,8 +47,8 @@ def bench_gemm():
         if epi == "qkv":
             q = torch.zeros((B, 6, npad, 64), dtype=torch.int16, device="cuda")
             k, vt = torch.zeros_like(q), torch.zeros_like(q)
-        for big in (0, 1):
-            for dbg in (0, 1, 2, 3):
+        for big in (0, 1, 2, 3):
+            for dbg in ((0, 1) if quick else (0, 1, 2, 3)):
                 capi.check(lib.dinoseg_set_option(b"gemm_big", big))
                 capi.check(lib.dinoseg_set_option(b"gemm_dbg", dbg))
 
@@ -62,7 +62,7 @@ def bench_gemm():
                                                        bias.data_ptr(), capi.ptr(X), capi.ptr(O), M * N, N, capi.stream_ptr()))
                 ms = timeit(run)
                 tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-                print(f"{name:5s} N={N:5d} K={K:5d} kernel={'big  ' if big else 'small'} dbg={dbg} "
+                print(f"{name:5s} N={N:5d} K={K:5d} kernel={('small', '256x384', '128x128p', '128x192p')[big]:8s} dbg={dbg} "
                       f"(skip epilogue={dbg & 1}, skip loads={(dbg >> 1) & 1}): {ms * 1e3:8.1f} us  {tf:7.1f} TFLOP/s", flush=True)
     lib.dinoseg_set_option(b"gemm_big", 1)
     lib.dinoseg_set_option(b"gemm_dbg", 0)
