@@ -463,6 +463,18 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().gemm_dbg = value;
         return 0;
     }
+    if (strcmp(key, "attn_waves") == 0) {
+        if (value != 4 && value != 6 && value != 8) {
+            dinoseg_set_error("dinoseg_set_option: attn_waves must be 4, 6 or 8");
+            return -1;
+        }
+        dseg::options().attn_waves = value;
+        return 0;
+    }
+    if (strcmp(key, "attn_dbg") == 0) {
+        dseg::options().attn_dbg = value;
+        return 0;
+    }
     dinoseg_set_error("dinoseg_set_option: unknown key '%s'", key);
     return -1;
 }

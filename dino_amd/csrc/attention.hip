@@ -26,7 +26,6 @@
 namespace dseg {
 
 constexpr int QW = 32;          // query rows per wave
-constexpr int QB = 128;         // query rows per workgroup (4 waves)
 constexpr int KB = 64;          // keys per tile
 constexpr int KV_TILE = 64 * 128;   // [64][64] bf16 slab = 8 KiB
 constexpr int ATTN_NSTAGE = 2;       // LDS ring slots for the K/V tiles
@@ -51,8 +50,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int PLANES>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+template <int PLANES, int NW, bool DBG>     // NW waves per workgroup, each 32 query rows; all share the K/V tiles
+__global__ __launch_bounds__(NW * 64, (NW == 6 ? 3 : 2)) void attn_fwd_kernel(AttnParams p) {
+    constexpr int QB = NW * QW;
+    const int dbg = DBG ? p.dbg : 0;        // timing ablations are compiled out of the production instantiation
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = PLANES * 2 * KV_TILE;   // per plane: K slab + V slab
     constexpr int NSTAGE = ATTN_NSTAGE;
@@ -90,12 +91,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int piece = wave * 4 + i;               // 0..7: K rows, 8..15: V rows
-                const int row = (piece & 7) * 8 + (lane >> 3);
-                const int c = swz2(row, lane & 7);
-                const bf16_t* src = (piece < 8 ? Kg : Vg) + pl * p.qkv_plane + (long)(key0 + row) * 64 + c * 8;
-                glds16(src, sbase + pl * 2 * KV_TILE + piece * 1024);
+            for (int i = 0; i < (16 + NW - 1) / NW; ++i) {
+                const int piece = wave + i * NW;              // 0..7: K rows, 8..15: V rows
+                if (piece < 16) {
+                    const int row = (piece & 7) * 8 + (lane >> 3);
+                    const int c = swz2(row, lane & 7);
+                    const bf16_t* src = (piece < 8 ? Kg : Vg) + pl * p.qkv_plane + (long)(key0 + row) * 64 + c * 8;
+                    glds16(src, sbase + pl * 2 * KV_TILE + piece * 1024);
+                }
             }
         }
     };
@@ -133,12 +136,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     for (int t = 0; t < ntiles; ++t) {
         // tile t landed (this wave's pieces); the one issued after it may still be in flight
         if (NSTAGE > 2 && t + 1 < ntiles) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PLANES) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((16 + NW - 1) / NW) * PLANES) : "memory");   // exact only when NW divides 16
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();      // everyone's pieces of tile t landed; everyone is done reading slot (t-1)%NSTAGE
-        if (t + NSTAGE - 1 < ntiles) stage((t + NSTAGE - 1) % NSTAGE, (t + NSTAGE - 1) * KB);
+        if (t + NSTAGE - 1 < ntiles && !(dbg & 2)) stage((t + NSTAGE - 1) % NSTAGE, (t + NSTAGE - 1) * KB);
         const char* sb = smem + (t % NSTAGE) * STAGE_BYTES;
 
         // ---- S^T[key][q] = K . Q^T ----
@@ -172,11 +175,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 
         // ---- online softmax (log2 domain), deferred rescale ----
         float mx = sacc[0][0];
+        if (!(dbg & 1)) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+        }
         if (t == 0 || __any(mx > RESCALE_THR)) {
             // everything still measured against the old reference is rescaled exactly once: S', O, l and negm
             const float delta = (t == 0) ? mx : fmaxf(mx, 0.f);
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = __builtin_amdgcn_exp2f(sacc[kb][r]);
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = (dbg & 1) ? sacc[kb][r] * 0.01f : __builtin_amdgcn_exp2f(sacc[kb][r]);
 
         // ---- P fragments (B operand: k = key, col = query): registers 8*s2..8*s2+7 of sacc[kb] ----
         bf16x8 pf[PLANES][4];
@@ -228,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         }
 
         // ---- O^T[d][q] += V^T . P^T  (V^T fragments by transposing LDS reads) ----
+        if (!(dbg & 4))
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
 #pragma unroll
@@ -271,30 +277,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
-template <int PLANES>
+template <int PLANES, int NW, bool DBG>
 static int launch_attn(const AttnParams& p, hipStream_t s) {
-    const int nq = (p.ntok + QB - 1) / QB;
+    const int nq = (p.ntok + NW * QW - 1) / (NW * QW);
     const int npairs = p.B * p.heads;
     const int grid = ((npairs + 7) / 8) * 8 * nq;
     const size_t lds = (size_t)ATTN_NSTAGE * PLANES * 2 * KV_TILE;
     static bool attr_done = false;
     if (!attr_done) {
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<PLANES>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<PLANES, NW, DBG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<PLANES>), dim3(grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<PLANES, NW, DBG>), dim3(grid), dim3(NW * 64), lds, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_attention(const AttnParams& p, hipStream_t s) {
+int launch_attention(const AttnParams& p0, hipStream_t s) {
+    AttnParams p = p0;
+    p.dbg = options().attn_dbg;
     if (p.npad % KB != 0 || p.npad < p.ntok) {
         dinoseg_set_error("attention: npad=%d must be a multiple of 64 and >= ntok=%d", p.npad, p.ntok);
         return -1;
     }
-    if (p.planes == 1) return launch_attn<1>(p, s);
-    if (p.planes == 2) return launch_attn<2>(p, s);
+    const int nw = options().attn_waves;        // query rows per workgroup = 32 * waves (K/V bytes per FLOP ~ 1 / waves)
+    if (p.dbg != 0 && p.planes == 1) {          // ablation build (tools/bench_ops.py)
+        if (nw == 8) return launch_attn<1, 8, true>(p, s);
+        return launch_attn<1, 4, true>(p, s);
+    }
+    if (p.planes == 1) {
+        if (nw == 6) return launch_attn<1, 6, false>(p, s);
+        if (nw == 8) return launch_attn<1, 8, false>(p, s);
+        return launch_attn<1, 4, false>(p, s);
+    }
+    if (p.planes == 2) {
+        if (nw == 6) return launch_attn<2, 6, false>(p, s);
+        if (nw == 8) return launch_attn<2, 8, false>(p, s);
+        return launch_attn<2, 4, false>(p, s);
+    }
     dinoseg_set_error("attention: planes must be 1 or 2");
     return -1;
 }

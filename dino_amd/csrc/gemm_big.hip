@@ -11,6 +11,9 @@
 //     are in flight while one is being multiplied.
 //   * persistent: one workgroup per CU walks its tiles; the ring runs continuously across tile boundaries, so
 //     the next tile's first slabs land while the current tile's epilogue drains from registers.
+//   * smaller persistent tiles with 2-3 workgroups per CU (128x128, 128x192, and 128x384 with the second workgroup
+//     started half a tile late) were measured and are slower on every DINOSeg shape: the epilogue is VALU/store-issue
+//     work that does not overlap another workgroup's MFMA phase in practice, and the main loop loses intensity.
 //   * XCD-aware tile walk: the column tiles of one A row panel are taken by workgroups of one XCD back-to-back.
 //   * epilogue through wave-private 4 KiB LDS patches: every global access is 16 bytes per lane on whole 64/128-byte
 //     row segments.  (Two earlier versions -- 4 columns per lane touching 32 rows per instruction, and 4-byte

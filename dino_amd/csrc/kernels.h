@@ -51,6 +51,8 @@ int launch_gemm_big(const GemmParams& p, hipStream_t s);   // 256x384 persistent
 struct Options {
     int gemm_big = 1;        // use gemm_big.hip where it applies
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
+    int attn_dbg = 0;        // same for AttnParams::dbg
+    int attn_waves = 4;      // waves (x 32 query rows) per attention-forward workgroup: 4, 6 or 8
 };
 Options& options();
 
@@ -60,6 +62,7 @@ struct AttnParams {
     bf16_t* ctx; long ctx_plane;       // [planes][B*ntok][heads*64]
     float* lse;                        // optional [B,H,ntok] log2-domain log-sum-exp (for backward), may be null
     int B, heads, ntok, npad, planes;
+    int dbg;                           // timing-only ablations: bit0 skip max/exp, bit1 skip steady-state loads, bit2 skip PV
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
 

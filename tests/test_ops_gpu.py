@@ -238,7 +238,7 @@ def test_gemm_big_matches_small_kernel(cuda):
     lib = capi.lib()
     outs = []
     X0 = seeded((M, N), 34)
-    for big in (0, 1, 2, 3):          # 0: 128x128 kernel; 1/2/3: persistent 256x384, 128x128 x3/CU, 128x192 x4/CU
+    for big in (0, 1, 2, 3):          # 0: 128x128 kernel; 1: auto (256x384 persistent here); 2/3: persistent 128x128 / 128x192 x3/CU
         capi.check(lib.dinoseg_set_option(b"gemm_big", big))
         out = torch.zeros((M, N), device="cuda")
         capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, 1, capi.EPI_PLAIN,

@@ -62,7 +62,7 @@ def bench_gemm(quick=True):
                                                        bias.data_ptr(), capi.ptr(X), capi.ptr(O), M * N, N, capi.stream_ptr()))
                 ms = timeit(run)
                 tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-                print(f"{name:5s} N={N:5d} K={K:5d} kernel={('small', '256x384', '128x128p', '128x192p')[big]:8s} dbg={dbg} "
+                print(f"{name:5s} N={N:5d} K={K:5d} kernel={('small', 'auto', '128x128p', '128x192p')[big]:8s} dbg={dbg} "
                       f"(skip epilogue={dbg & 1}, skip loads={(dbg >> 1) & 1}): {ms * 1e3:8.1f} us  {tf:7.1f} TFLOP/s", flush=True)
     lib.dinoseg_set_option(b"gemm_big", 1)
     lib.dinoseg_set_option(b"gemm_dbg", 0)
@@ -82,9 +82,15 @@ def bench_attn():
         def run():
             capi.check(lib.dinoseg_op_attention(q.data_ptr(), k.data_ptr(), vt.data_ptr(), B * H * npad * 64, ctx.data_ptr(),
                                                 B * ntok * H * 64, None, B, H, ntok, npad, planes, capi.stream_ptr()))
-        ms = timeit(run)
-        fl = 4.0 * B * H * ntok * ntok * 64
-        print(f"attention planes={planes}: {ms * 1e3:8.1f} us  {fl / (ms * 1e-3) / 1e12:7.1f} TFLOP/s (algorithmic)", flush=True)
+        for nw, dbg in (((4, 0), (6, 0), (8, 0), (4, 2), (8, 2)) if planes == 1 else ((4, 0), (6, 0), (8, 0))):
+            capi.check(lib.dinoseg_set_option(b"attn_waves", nw))
+            capi.check(lib.dinoseg_set_option(b"attn_dbg", dbg))
+            ms = timeit(run)
+            fl = 4.0 * B * H * ntok * ntok * 64
+            print(f"attention planes={planes} waves={nw} dbg={dbg} (skip max/exp={dbg & 1}, skip loads={(dbg >> 1) & 1}, skip PV={(dbg >> 2) & 1}): "
+                  f"{ms * 1e3:8.1f} us  {fl / (ms * 1e-3) / 1e12:7.1f} TFLOP/s (algorithmic)", flush=True)
+        lib.dinoseg_set_option(b"attn_dbg", 0)
+        lib.dinoseg_set_option(b"attn_waves", 4)
 
 
 if __name__ == "__main__":
