@@ -464,11 +464,19 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         return 0;
     }
     if (strcmp(key, "attn_waves") == 0) {
-        if (value != 4 && value != 6 && value != 8) {
-            dinoseg_set_error("dinoseg_set_option: attn_waves must be 4, 6 or 8");
+        if (value != 4 && value != 8) {
+            dinoseg_set_error("dinoseg_set_option: attn_waves must be 4 or 8");
             return -1;
         }
         dseg::options().attn_waves = value;
+        return 0;
+    }
+    if (strcmp(key, "attn_stages") == 0) {
+        dseg::options().attn_stages = value;
+        return 0;
+    }
+    if (strcmp(key, "attn_regstage") == 0) {
+        dseg::options().attn_regstage = value;
         return 0;
     }
     if (strcmp(key, "attn_dbg") == 0) {

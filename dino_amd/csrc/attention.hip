@@ -28,7 +28,6 @@ namespace dseg {
 constexpr int QW = 32;          // query rows per wave
 constexpr int KB = 64;          // keys per tile
 constexpr int KV_TILE = 64 * 128;   // [64][64] bf16 slab = 8 KiB
-constexpr int ATTN_NSTAGE = 2;       // LDS ring slots for the K/V tiles
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
@@ -50,13 +49,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int PLANES, int NW, bool DBG>     // NW waves per workgroup, each 32 query rows; all share the K/V tiles
-__global__ __launch_bounds__(NW * 64, (NW == 6 ? 3 : 2)) void attn_fwd_kernel(AttnParams p) {
+template <int PLANES, int NW, bool DBG, bool REGSTAGE, int NST>     // NW waves per workgroup, each 32 query rows; all share the K/V tiles
+__device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
     constexpr int QB = NW * QW;
     const int dbg = DBG ? p.dbg : 0;        // timing ablations are compiled out of the production instantiation
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = PLANES * 2 * KV_TILE;   // per plane: K slab + V slab
-    constexpr int NSTAGE = ATTN_NSTAGE;
+    constexpr int NSTAGE = REGSTAGE ? 2 : NST;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,6 +102,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 6 ? 3 : 2)) void attn_fwd_kernel(At
         }
     };
 
+    // Register staging (REGSTAGE): global_load_dwordx4 -> VGPR issued before the tile's MFMA work, ds_write_b128 after
+    // it.  An LDS-DMA piece costs 60-185 issue cycles beside MFMAs (MI355X_MICROARCH.md cycle table) against ~20 for a
+    // load + LDS-write pair; with 4 pieces per wave and tile that was a quarter of the loop (ablation: -24 % w/o loads).
+    uint4 sr[PLANES][4];
+#define DSEG_STAGE_LOAD(KEY0)                                                                                          \
+    _Pragma("unroll") for (int pl = 0; pl < PLANES; ++pl) _Pragma("unroll") for (int i = 0; i < 4; ++i) {              \
+        const int piece = wave + i * NW;                                                                               \
+        const int row = (piece & 7) * 8 + (lane >> 3);                                                                 \
+        sr[pl][i] = *reinterpret_cast<const uint4*>((piece < 8 ? Kg : Vg) + pl * p.qkv_plane + (long)((KEY0) + row) * 64 + \
+                                                    swz2(row, lane & 7) * 8);                                          \
+    }
+#define DSEG_STAGE_WRITE(ST)                                                                                           \
+    _Pragma("unroll") for (int pl = 0; pl < PLANES; ++pl) _Pragma("unroll") for (int i = 0; i < 4; ++i)                \
+        *reinterpret_cast<uint4*>(smem + (ST) * STAGE_BYTES + pl * 2 * KV_TILE + (wave + i * NW) * 1024 + lane * 16) = sr[pl][i];
+
     f32x16 o[2];
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -124,8 +138,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 6 ? 3 : 2)) void attn_fwd_kernel(At
     // vmcnt).  Measured: 3 slots are 5 % SLOWER than 2 at this shape (742 -> 775 us; LDS 48 KiB per workgroup and a
     // dynamic slot index), so the loop is not bound by the LDS-DMA round trip; 2 slots are the default.
     const int ntiles = (ntok + KB - 1) / KB;
-    stage(0, 0);
-    if (NSTAGE > 2 && ntiles > 1) stage(1, KB);
+    if (REGSTAGE) {
+        DSEG_STAGE_LOAD(0)
+        DSEG_STAGE_WRITE(0)
+        __syncthreads();
+    } else {
+        stage(0, 0);
+        if (NSTAGE > 2 && ntiles > 1) stage(1, KB);
+    }
 
     const int krow_perm = sigma23(lr);
     // transposed V read (ds_read_b64_tr_b16): within each 16-lane group, lane 4q+p addresses key row q, d columns
@@ -134,6 +154,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 6 ? 3 : 2)) void attn_fwd_kernel(At
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_gl = (lane >> 4) & 1;
 
     for (int t = 0; t < ntiles; ++t) {
+        if (REGSTAGE) {
+            if (t + 1 < ntiles) { DSEG_STAGE_LOAD((t + 1) * KB) }      // in flight during this tile's MFMA work
+        } else {
         // tile t landed (this wave's pieces); the one issued after it may still be in flight
         if (NSTAGE > 2 && t + 1 < ntiles) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((16 + NW - 1) / NW) * PLANES) : "memory");   // exact only when NW divides 16
@@ -142,7 +165,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 6 ? 3 : 2)) void attn_fwd_kernel(At
         }
         __builtin_amdgcn_s_barrier();      // everyone's pieces of tile t landed; everyone is done reading slot (t-1)%NSTAGE
         if (t + NSTAGE - 1 < ntiles && !(dbg & 2)) stage((t + NSTAGE - 1) % NSTAGE, (t + NSTAGE - 1) * KB);
-        const char* sb = smem + (t % NSTAGE) * STAGE_BYTES;
+        }
+        const char* sb = smem + (REGSTAGE ? (t & 1) : (t % NSTAGE)) * STAGE_BYTES;
 
         // ---- S^T[key][q] = K . Q^T ----
         f32x16 sacc[2];
@@ -252,7 +276,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 6 ? 3 : 2)) void attn_fwd_kernel(At
             }
         }
 
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of tile t are complete
+        if (REGSTAGE) {
+            if (t + 1 < ntiles) { DSEG_STAGE_WRITE((t + 1) & 1) }      // slot last read in iteration t-1 (barrier below t-1)
+            __syncthreads();
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of tile t are complete
+        }
     }
 
     // ---- normalise and write ctx[b*ntok + q][head*64 + d] ----
@@ -277,19 +306,39 @@ __global__ __launch_bounds__(NW * 64, (NW == 6 ? 3 : 2)) void attn_fwd_kernel(At
     }
 }
 
-template <int PLANES, int NW, bool DBG>
+template <int PLANES, int NW, bool DBG, bool REGSTAGE, int NST>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
+    attn_fwd_body<PLANES, NW, DBG, REGSTAGE, NST>(p);
+}
+// register-staged variant: 16 / 32 more live registers -> pin 2 waves per SIMD instead of spilling for 3
+template <int PLANES, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_regstage_kernel(AttnParams p) {
+    attn_fwd_body<PLANES, NW, false, true, 2>(p);
+}
+
+template <int PLANES, int NW, bool DBG, bool REGSTAGE, int NST>
 static int launch_attn(const AttnParams& p, hipStream_t s) {
     const int nq = (p.ntok + NW * QW - 1) / (NW * QW);
     const int npairs = p.B * p.heads;
     const int grid = ((npairs + 7) / 8) * 8 * nq;
-    const size_t lds = (size_t)ATTN_NSTAGE * PLANES * 2 * KV_TILE;
+    const size_t lds = (size_t)(REGSTAGE ? 2 : NST) * PLANES * 2 * KV_TILE;
     static bool attr_done = false;
     if (!attr_done) {
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<PLANES, NW, DBG>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<PLANES, NW, DBG, REGSTAGE, NST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<PLANES, NW, DBG>), dim3(grid), dim3(NW * 64), lds, s, p);
+    if (REGSTAGE) {
+        static bool rs_attr = false;
+        if (!rs_attr) {
+            DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_regstage_kernel<PLANES, NW>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            rs_attr = true;
+        }
+        hipLaunchKernelGGL((attn_fwd_regstage_kernel<PLANES, NW>), dim3(grid), dim3(NW * 64), lds, s, p);
+    } else {
+        hipLaunchKernelGGL((attn_fwd_kernel<PLANES, NW, DBG, REGSTAGE, NST>), dim3(grid), dim3(NW * 64), lds, s, p);
+    }
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -302,19 +351,18 @@ int launch_attention(const AttnParams& p0, hipStream_t s) {
         return -1;
     }
     const int nw = options().attn_waves;        // query rows per workgroup = 32 * waves (K/V bytes per FLOP ~ 1 / waves)
-    if (p.dbg != 0 && p.planes == 1) {          // ablation build (tools/bench_ops.py)
-        if (nw == 8) return launch_attn<1, 8, true>(p, s);
-        return launch_attn<1, 4, true>(p, s);
-    }
+    const bool rs = options().attn_regstage != 0;
+    const int nst = options().attn_stages;
+    if (p.dbg != 0 && p.planes == 1) return launch_attn<1, 4, true, false, 2>(p, s);      // ablation build (tools/bench_ops.py)
     if (p.planes == 1) {
-        if (nw == 6) return launch_attn<1, 6, false>(p, s);
-        if (nw == 8) return launch_attn<1, 8, false>(p, s);
-        return launch_attn<1, 4, false>(p, s);
+        if (nw == 8) return launch_attn<1, 8, false, false, 2>(p, s);
+        if (rs) return launch_attn<1, 4, false, true, 2>(p, s);
+        return nst == 3 ? launch_attn<1, 4, false, false, 3>(p, s) : launch_attn<1, 4, false, false, 2>(p, s);
     }
     if (p.planes == 2) {
-        if (nw == 6) return launch_attn<2, 6, false>(p, s);
-        if (nw == 8) return launch_attn<2, 8, false>(p, s);
-        return launch_attn<2, 4, false>(p, s);
+        if (nw == 8) return launch_attn<2, 8, false, false, 2>(p, s);
+        if (rs) return launch_attn<2, 4, false, true, 2>(p, s);
+        return nst == 3 ? launch_attn<2, 4, false, false, 3>(p, s) : launch_attn<2, 4, false, false, 2>(p, s);
     }
     dinoseg_set_error("attention: planes must be 1 or 2");
     return -1;

@@ -52,7 +52,9 @@ struct Options {
     int gemm_big = 1;        // use gemm_big.hip where it applies
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
     int attn_dbg = 0;        // same for AttnParams::dbg
-    int attn_waves = 4;      // waves (x 32 query rows) per attention-forward workgroup: 4, 6 or 8
+    int attn_waves = 4;      // waves (x 32 query rows) per attention-forward workgroup: 4 or 8
+    int attn_regstage = 0;   // 1: K/V tiles staged through registers, 0: LDS-DMA
+    int attn_stages = 2;     // LDS ring slots of the LDS-DMA variant: 2 or 3
 };
 Options& options();
 

@@ -69,9 +69,14 @@ def bench_gemm(quick=True):
 
 
 def bench_attn():
+    """Interleaved A/B rounds in one process (clocks drift by +-10 % between back-to-back measurements)."""
     lib = capi.lib()
     B, H, ntok = 32, 6, 3601
     npad = (ntok + 63) // 64 * 64
+    variants = [("ldsdma-2slot", dict(attn_waves=4, attn_regstage=0, attn_stages=2)),
+                ("ldsdma-3slot", dict(attn_waves=4, attn_regstage=0, attn_stages=3)),
+                ("8-wave WG", dict(attn_waves=8, attn_regstage=0, attn_stages=2)),
+                ("reg-staged", dict(attn_waves=4, attn_regstage=1, attn_stages=2))]
     for planes in (1, 2):
         q = rand_bf16((planes, B, H, npad, 64))
         k = rand_bf16((planes, B, H, npad, 64))
@@ -82,15 +87,19 @@ def bench_attn():
         def run():
             capi.check(lib.dinoseg_op_attention(q.data_ptr(), k.data_ptr(), vt.data_ptr(), B * H * npad * 64, ctx.data_ptr(),
                                                 B * ntok * H * 64, None, B, H, ntok, npad, planes, capi.stream_ptr()))
-        for nw, dbg in (((4, 0), (6, 0), (8, 0), (4, 2), (8, 2)) if planes == 1 else ((4, 0), (6, 0), (8, 0))):
-            capi.check(lib.dinoseg_set_option(b"attn_waves", nw))
-            capi.check(lib.dinoseg_set_option(b"attn_dbg", dbg))
-            ms = timeit(run)
-            fl = 4.0 * B * H * ntok * ntok * 64
-            print(f"attention planes={planes} waves={nw} dbg={dbg} (skip max/exp={dbg & 1}, skip loads={(dbg >> 1) & 1}, skip PV={(dbg >> 2) & 1}): "
-                  f"{ms * 1e3:8.1f} us  {fl / (ms * 1e-3) / 1e12:7.1f} TFLOP/s (algorithmic)", flush=True)
-        lib.dinoseg_set_option(b"attn_dbg", 0)
-        lib.dinoseg_set_option(b"attn_waves", 4)
+        times = {name: [] for name, _ in variants}
+        for rnd in range(6):
+            for name, opts in variants:
+                for kk, vv in opts.items():
+                    capi.check(lib.dinoseg_set_option(kk.encode(), vv))
+                times[name].append(timeit(run, iters=8, warm=2))
+        fl = 4.0 * B * H * ntok * ntok * 64
+        for name, _ in variants:
+            t = sorted(times[name][1:])
+            print(f"attention planes={planes} {name:14s}: min {t[0] * 1e3:7.1f} us  median {t[len(t) // 2] * 1e3:7.1f} us  "
+                  f"{fl / (t[len(t) // 2] * 1e-3) / 1e12:6.1f} TFLOP/s", flush=True)
+    for kk, vv in dict(attn_waves=4, attn_regstage=0, attn_stages=2).items():
+        lib.dinoseg_set_option(kk.encode(), vv)
 
 
 if __name__ == "__main__":
