@@ -293,8 +293,8 @@ static int ensure_workspace(dinoseg_handle* h, const WsLayout& L, int B, int r, 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
-                               int32_t* argmax_out, int32_t tap_block, float* tap_out, void* stream) {
+static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
+                        int32_t* argmax_out, int32_t tap_block, float* tap_out, float* attn_out, void* stream) {
     if (!h || !x || B <= 0) {
         dinoseg_set_error("dinoseg_forward: bad argument");
         return -1;
@@ -368,6 +368,8 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
             g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
             DSEG_PROF(DINOSEG_PROF_QKV, DSEG_TRY(launch_gemm(g, s)));
         }
+        if (attn_out && i == c.n_blocks - 1)      // get_last_selfattention: probabilities of the last block, then stop
+            return launch_attn_probs(Q, Kb, L.qkv_plane, P, B, H, L.ntok, L.npad, attn_out, s);
         {
             AttnParams a = {};
             a.q = Q; a.k = Kb; a.v = V; a.qkv_plane = L.qkv_plane;
@@ -443,6 +445,24 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
                                    c.n_classes, logp_out ? logp_out : reinterpret_cast<float*>(ws + L.HB), argmax_out, s)));
     }
     return 0;
+}
+
+extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
+                               int32_t* argmax_out, int32_t tap_block, float* tap_out, void* stream) {
+    return forward_impl(h, x, x_kind, B, r, logp_out, argmax_out, tap_block, tap_out, nullptr, stream);
+}
+
+extern "C" int dinoseg_last_selfattention(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* attn_out,
+                                          void* stream) {
+    if (!attn_out || !h || h->cfg.n_blocks < 1) {
+        dinoseg_set_error("dinoseg_last_selfattention: needs an output buffer and at least one block");
+        return -1;
+    }
+    return forward_impl(h, x, x_kind, B, r, nullptr, nullptr, -1, nullptr, attn_out, stream);
+}
+
+extern "C" int dinoseg_op_confusion(const int32_t* pred, const int64_t* gt, int64_t n, int32_t n_classes, int64_t* cm, void* stream) {
+    return launch_confusion(pred, gt, n, n_classes, cm, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------------------ options

@@ -355,4 +355,110 @@ int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, con
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Materialised attention probabilities of one block (VisionTransformer.get_last_selfattention,
+// vision_transformer.py:273-280 -> Attention.forward :85,:101; caller visualize_attention.py:46).
+// Not on the inference hot path (the fused kernel never writes the N x N matrix); used for visualisation only.
+// grid (ceil(ntok/16), B*H): scores of 16 queries against all keys (Q~ is pre-scaled by scale*log2e, so the
+// softmax is exp2-based), then the same workgroup normalises its 16 rows in place.
+__global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, long plane,
+                                                         int planes, int ntok, int npad, float* __restrict__ out) {
+    __shared__ float qs[16][64];
+    const int pair = blockIdx.y, q0 = blockIdx.x * 16, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bf16_t* Qg = q + (long)pair * npad * 64;
+    const bf16_t* Kg = k + (long)pair * npad * 64;
+    for (int i = tid; i < 16 * 64; i += 256) {
+        const int r = i >> 6, d = i & 63;
+        const int qr = q0 + r < ntok ? q0 + r : ntok - 1;
+        float v = bf16_to_f32(Qg[(long)qr * 64 + d]);
+        if (planes == 2) v += bf16_to_f32(Qg[plane + (long)qr * 64 + d]);
+        qs[r][d] = v;
+    }
+    __syncthreads();
+    float* orow = out + ((long)pair * ntok + q0) * ntok;
+    for (int key = tid; key < ntok; key += 256) {
+        float kv[64];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint4 h = *reinterpret_cast<const uint4*>(Kg + (long)key * 64 + c * 8);
+            const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kv[c * 8 + 2 * e] = bf16_lo_to_f32(hw[e]);
+                kv[c * 8 + 2 * e + 1] = bf16_hi_to_f32(hw[e]);
+            }
+            if (planes == 2) {
+                const uint4 l = *reinterpret_cast<const uint4*>(Kg + plane + (long)key * 64 + c * 8);
+                const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    kv[c * 8 + 2 * e] += bf16_lo_to_f32(lw[e]);
+                    kv[c * 8 + 2 * e + 1] += bf16_hi_to_f32(lw[e]);
+                }
+            }
+        }
+        for (int r = 0; r < 16; ++r) {
+            if (q0 + r >= ntok) break;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) s = fmaf(qs[r][d], kv[d], s);
+            orow[(long)r * ntok + key] = s;
+        }
+    }
+    __syncthreads();
+    for (int r = wv; r < 16; r += 4) {      // one wavefront per row: max, sum, normalise
+        if (q0 + r >= ntok) break;
+        float* row = orow + (long)r * ntok;
+        float m = -INFINITY;
+        for (int j = lane; j < ntok; j += 64) m = fmaxf(m, row[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+        for (int j = lane; j < ntok; j += 64) {
+            const float e = __builtin_amdgcn_exp2f(row[j] - m);
+            row[j] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / wave_sum(sum);
+        for (int j = lane; j < ntok; j += 64) row[j] *= inv;
+    }
+}
+
+int launch_attn_probs(const bf16_t* q, const bf16_t* k, long plane, int planes, int B, int heads, int ntok, int npad, float* out,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(attn_probs_kernel, dim3((ntok + 15) / 16, B * heads), dim3(256), 0, s, q, k, plane, planes, ntok, npad, out);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Confusion matrix for the validation metrics (validation_epoch_end, pl_torch_modules.py:310-332):
+// cm[gt][pred] += 1 (int64), block-private histogram in LDS first.
+__global__ __launch_bounds__(256) void confusion_kernel(const int32_t* __restrict__ pred, const int64_t* __restrict__ gt, long n,
+                                                        int C, unsigned long long* __restrict__ cm) {
+    __shared__ unsigned int h[32 * 32];
+    for (int i = threadIdx.x; i < C * C; i += 256) h[i] = 0;
+    __syncthreads();
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int g = (int)gt[i], pr = pred[i];
+        if (g >= 0 && g < C && pr >= 0 && pr < C) atomicAdd(&h[g * C + pr], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += 256)
+        if (h[i]) atomicAdd(cm + i, (unsigned long long)h[i]);
+}
+
+int launch_confusion(const int32_t* pred, const int64_t* gt, long n, int C, int64_t* cm, hipStream_t s) {
+    if (C < 1 || C > 32) {
+        dinoseg_set_error("confusion: need 1 <= C <= 32");
+        return -1;
+    }
+    int grid = (int)((n + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(confusion_kernel, dim3(grid), dim3(256), 0, s, pred, gt, n, C, reinterpret_cast<unsigned long long*>(cm));
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace dseg

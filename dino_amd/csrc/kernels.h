@@ -92,6 +92,12 @@ int launch_pos_resample(const float* pos_embed, int g, int D, int o, float* out,
 int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, const float* W, const float* b, int C,
                       float* logp, int32_t* argmax, hipStream_t s);
 
+// materialised softmax(q k^T) of one block, fp32 [B,H,ntok,ntok] (get_last_selfattention; visualisation only)
+int launch_attn_probs(const bf16_t* q, const bf16_t* k, long plane, int planes, int B, int heads, int ntok, int npad, float* out,
+                      hipStream_t s);
+// cm[gt][pred] += 1 over n patches (int64 [C,C], accumulates)
+int launch_confusion(const int32_t* pred, const int64_t* gt, long n, int C, int64_t* cm, hipStream_t s);
+
 // ---- fine-tune step (train.hip, attention_bwd.hip) ----
 struct AttnBwdParams {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; long qkv_plane;   // forward operands [planes][B,H,npad,64]

@@ -68,6 +68,21 @@ def get_transforms(resolution: int = 480) -> _Transforms:
     return _Transforms(resolution)
 
 
+def metrics_from_confusion(cm: np.ndarray, prefix: str = "val") -> Dict[str, float]:
+    """cm[gt][pred] counts -> {prefix_acc (balanced accuracy), prefix_iou (macro Jaccard), prefix_F1 (macro F1)}."""
+    tp = np.diag(cm)
+    support = cm.sum(axis=1)          # per true class
+    predicted = cm.sum(axis=0)        # per predicted class
+    present = support > 0
+    acc = float(np.mean(tp[present] / support[present])) if present.any() else 0.0
+    labels = (support + predicted) > 0                       # sklearn: union of the labels seen in y_true and y_pred
+    denom_f1 = 2 * tp + (predicted - tp) + (support - tp)
+    denom_iou = tp + (predicted - tp) + (support - tp)
+    f1 = float(np.mean(np.where(denom_f1[labels] > 0, 2 * tp[labels] / np.maximum(denom_f1[labels], 1), 0.0))) if labels.any() else 0.0
+    iou = float(np.mean(np.where(denom_iou[labels] > 0, tp[labels] / np.maximum(denom_iou[labels], 1), 0.0))) if labels.any() else 0.0
+    return {prefix + "_acc": acc, prefix + "_iou": iou, prefix + "_F1": f1}
+
+
 # --------------------------------------------------------------------------- parameter containers
 class _Attn(nn.Module):
     def __init__(self, D):
@@ -186,6 +201,11 @@ class DINOSeg(nn.Module):
         self.dino = _ViTParams(self.cfg)
         self.clf = (_MLPHead(self.cfg.n_classes, self.cfg.embed_dim) if head == "mlp"
                     else _LinearHead(self.cfg.n_classes, self.cfg.embed_dim))
+
+        import weakref
+        owner = weakref.ref(self)
+        # reference call site: mlp_dino.dino.get_last_selfattention(x)  (visualize_attention.py:46)
+        self.dino.get_last_selfattention = lambda x: owner().get_last_selfattention(x)
 
         self._handle: Optional[C.c_void_p] = None
         self._bound_sig = None
@@ -310,6 +330,50 @@ class DINOSeg(nn.Module):
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         _, _, tap = self._run(x, capi.INPUT_F32_CHW, x.shape[0], x.shape[2], tap_block=block)
         return tap.reshape(x.shape[0], -1, self.cfg.embed_dim)
+
+    def get_last_selfattention(self, x: torch.Tensor) -> torch.Tensor:
+        """Attention probabilities [B, heads, N, N] of the last block (reference: ``model.dino.get_last_selfattention(x)``,
+        vision_transformer.py:273-280; used by visualize_attention.py:46).  x: fp32 [B,3,r,r]."""
+        self._require_gpu()
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3] or x.shape[2] % 8 != 0:
+            raise ValueError(f"expected [B,3,r,r] with r % 8 == 0, got {tuple(x.shape)}")
+        self._sync_weights()
+        B, r = x.shape[0], x.shape[2]
+        N = (r // 8) ** 2 + 1
+        out = torch.empty((B, self.cfg.num_heads, N, N), dtype=torch.float32, device=x.device)
+        capi.check(capi.lib().dinoseg_last_selfattention(self._handle, x.data_ptr(), capi.INPUT_F32_CHW, B, r, out.data_ptr(),
+                                                         capi.stream_ptr()))
+        return out
+
+    # ---- validation metrics (pl_torch_modules.py:302-345) ------------------------------------------
+    def validation_step(self, batch, batch_idx=0):
+        """Reference: probs = self(x); pred = argmax.  Here the per-batch confusion matrix is accumulated on device."""
+        x, y = batch
+        with torch.no_grad():
+            if x.dtype == torch.uint8:
+                logp, amax = self.forward_frames(x)
+            else:
+                logp = self.forward(x)
+                amax = logp.argmax(dim=-1).to(torch.int32)
+            y = y.to(self.device).reshape(-1).long().contiguous()
+            cm = torch.zeros((self.cfg.n_classes, self.cfg.n_classes), dtype=torch.int64, device=self.device)
+            capi.check(capi.lib().dinoseg_op_confusion(amax.data_ptr(), y.data_ptr(), y.numel(), self.cfg.n_classes,
+                                                       cm.data_ptr(), capi.stream_ptr()))
+        return {"pred": amax, "gt": y, "probs": logp, "confusion": cm}
+
+    def validation_epoch_end(self, outputs, prefix="val"):
+        """Balanced accuracy, macro F1 and macro IoU over all patches of the split, from the summed confusion matrices
+        (same definitions as sklearn's balanced_accuracy_score / f1_score(macro) / jaccard_score(macro), which the
+        reference calls on the concatenated predictions, pl_torch_modules.py:317-319)."""
+        cm = torch.stack([o["confusion"] for o in outputs]).sum(0).cpu().numpy().astype(np.float64)
+        return metrics_from_confusion(cm, prefix)
+
+    def test_step(self, batch, batch_idx=0):
+        return self.validation_step(batch, batch_idx)
+
+    def test_epoch_end(self, outputs):
+        return self.validation_epoch_end(outputs, prefix="test")
 
     def profile(self, level: int) -> None:
         """Per-kernel-class HIP-event timing inside forward (0 off, 1 attention only, 2 all classes)."""

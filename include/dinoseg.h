@@ -79,6 +79,16 @@ int dinoseg_prepare_resolution(dinoseg_handle* h, int32_t r, void* stream);
 int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
                     int32_t* argmax_out, int32_t tap_block, float* tap_out, void* stream);
 
+/* Replaces VisionTransformer.get_last_selfattention (vision_transformer.py:273-280; caller visualize_attention.py:46):
+ * the materialised softmax(q k^T / 8) of the LAST block, attn_out fp32 [B, heads, N, N] with N = (r/8)^2 + 1.
+ * Visualisation path, not the inference hot path (which never writes the N x N matrix). */
+int dinoseg_last_selfattention(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* attn_out,
+                               void* stream);
+
+/* Confusion matrix for the validation metrics (validation_epoch_end, pl_torch_modules.py:310-332):
+ * cm[gt][pred] += 1 over n patches; cm int64 [n_classes, n_classes] on device (zero it first). */
+int dinoseg_op_confusion(const int32_t* pred, const int64_t* gt, int64_t n, int32_t n_classes, int64_t* cm, void* stream);
+
 /* ---- fine-tune step (replaces DINOSeg.training_step + autograd + optimizer.step, pl_torch_modules.py:258-268) ---- */
 
 /* Bind (or, with NULL, unbind) the fp32 gradient buffer of a parameter, same shape as the bound weight.  A parameter

@@ -21,6 +21,7 @@ Reference lines restated (all under /root/reference/dt_segmentation/src/):
   mlp                   vision_transformer.py:49-65         (exact erf GELU)
   block                 vision_transformer.py:110-140
   vit_forward           vision_transformer.py:237-248
+  last_selfattention    vision_transformer.py:273-280
   head_forward          pl_torch_modules.py:108-138
   dinoseg_forward       pl_torch_modules.py:239-256
   predict               pl_torch_modules.py:270-300
@@ -179,6 +180,18 @@ def vit_forward(x: Tensor, W: Dict[str, Tensor], num_heads: int, patch: int = 8,
         if taps is not None:
             taps[f"block{i}"] = t
     return layer_norm(t, W["dino.norm.weight"], W["dino.norm.bias"], eps)
+
+
+def last_selfattention(x: Tensor, W: Dict[str, Tensor], num_heads: int, patch: int = 8, eps: float = 1e-6) -> Tensor:
+    """[B,3,r,r] -> softmax attention [B,H,N,N] of the last block (VisionTransformer.get_last_selfattention,
+    vision_transformer.py:273-280)."""
+    t = prepare_tokens(x, W, patch)
+    L = count_blocks(W)
+    for i in range(L - 1):
+        t = block(t, W, i, num_heads, eps)
+    pre = f"dino.blocks.{L - 1}."
+    _, pr = attention(layer_norm(t, W[pre + "norm1.weight"], W[pre + "norm1.bias"], eps), W, pre, num_heads, return_probs=True)
+    return pr
 
 
 def head_forward(feat: Tensor, W: Dict[str, Tensor], q: Callable = _ident) -> Tensor:

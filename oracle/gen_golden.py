@@ -360,7 +360,26 @@ def g9():
     save("g9_reference_dinoseg", **out)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
+# ----------------------------------------------------------------------------- G10 get_last_selfattention
+def g10():
+    out = {}
+    cfg = TINY
+    vit = ref_vit(cfg, procedural_state_dict(cfg))
+    frames = synthetic_frames(1, 64, seed=101)
+    with torch.no_grad():
+        a = vit.get_last_selfattention(preprocess_np(frames))            # [1, H, N, N]
+    out["tiny_r64_full"] = a.numpy()
+    cfg = ViTConfig(n_blocks=3)
+    vit = ref_vit(cfg, procedural_state_dict(cfg))
+    frames = synthetic_frames(1, 96, seed=102)
+    with torch.no_grad():
+        a = vit.get_last_selfattention(preprocess_np(frames))
+    out["vits8_L3_r96_cls_rows"] = a[0, :, 0, :].numpy().copy()           # what visualize_attention.py:50 uses
+    out["vits8_L3_r96_row77"] = a[0, :, 77, :].numpy().copy()
+    save("g10_last_selfattention", **out)
+
+
+ALL = {"G10": g10, "G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

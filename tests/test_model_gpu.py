@@ -178,3 +178,38 @@ def test_weights_update_is_picked_up(cuda):
     with torch.no_grad():
         ref = O.dinoseg_forward(O.preprocess(frames.cpu().numpy()), O.to_torch(sd2), cfg.num_heads)
     assert float((lp1.cpu() - ref).abs().max()) <= TOL
+
+
+def test_g10_last_selfattention(cuda, golden_dir):
+    """model.dino.get_last_selfattention(x) as visualize_attention.py:46 calls it, against the reference's own output."""
+    g = load(golden_dir, "g10_last_selfattention")
+    m, _, _ = build(TINY, "bf16x3")
+    x = O.preprocess(synthetic_frames(1, 64, seed=101)).cuda()
+    a = m.dino.get_last_selfattention(x).cpu()
+    assert tuple(a.shape) == (1, 2, 65, 65)
+    assert float((a - torch.from_numpy(g["tiny_r64_full"])).abs().max()) <= 2e-4
+    assert float((a.sum(-1) - 1).abs().max()) <= 1e-5
+    m, _, _ = build(3, "bf16x3")
+    x = O.preprocess(synthetic_frames(1, 96, seed=102)).cuda()
+    a = m.get_last_selfattention(x).cpu()
+    assert float((a[0, :, 0] - torch.from_numpy(g["vits8_L3_r96_cls_rows"])).abs().max()) <= 2e-4
+    assert float((a[0, :, 77] - torch.from_numpy(g["vits8_L3_r96_row77"])).abs().max()) <= 2e-4
+
+
+def test_validation_metrics_on_device(cuda):
+    from sklearn.metrics import balanced_accuracy_score, f1_score, jaccard_score
+    m, sd, cfg = build(1, "bf16x3")
+    outs, preds, gts = [], [], []
+    for i in range(3):
+        frames = torch.from_numpy(synthetic_frames(2, 64, seed=30 + i)).cuda()
+        labels = torch.from_numpy(np.random.default_rng(40 + i).integers(0, 5, (2, 64))).cuda()     # classes 5, 6 absent in gt
+        o = m.validation_step((frames, labels), i)
+        outs.append(o)
+        preds.append(o["pred"].cpu().numpy())
+        gts.append(labels.cpu().numpy().reshape(-1))
+    res = m.validation_epoch_end(outs)
+    p, g_ = np.concatenate(preds), np.concatenate(gts)
+    assert abs(res["val_acc"] - balanced_accuracy_score(g_, p)) <= 1e-12
+    assert abs(res["val_F1"] - f1_score(g_, p, average="macro")) <= 1e-12
+    assert abs(res["val_iou"] - jaccard_score(g_, p, average="macro")) <= 1e-12
+    assert int(torch.stack([o["confusion"] for o in outs]).sum()) == p.size

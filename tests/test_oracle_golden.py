@@ -114,3 +114,33 @@ def test_g6_finetune_gradients(golden_dir):
             assert abs(float(gv.norm()) - gn) <= 1e-4 * gn + 1e-7, k
             idx = torch.from_numpy(g[f"{tag}|gidx|{k}"])
             assert float((gv[idx] - torch.from_numpy(g[f"{tag}|gval|{k}"])).abs().max()) <= 2e-4 * gn + 1e-7, k
+
+
+def test_g10_last_selfattention(golden_dir):
+    g = load(golden_dir, "g10_last_selfattention")
+    W = O.to_torch(procedural_state_dict(TINY))
+    with torch.no_grad():
+        a = O.last_selfattention(O.preprocess(synthetic_frames(1, 64, seed=101)), W, TINY.num_heads)
+    assert tuple(a.shape) == tuple(g["tiny_r64_full"].shape) == (1, 2, 65, 65)
+    assert float((a - torch.from_numpy(g["tiny_r64_full"])).abs().max()) <= 1e-6
+    cfg = ViTConfig(n_blocks=3)
+    W = O.to_torch(procedural_state_dict(cfg))
+    with torch.no_grad():
+        a = O.last_selfattention(O.preprocess(synthetic_frames(1, 96, seed=102)), W, cfg.num_heads)
+    assert float((a[0, :, 0] - torch.from_numpy(g["vits8_L3_r96_cls_rows"])).abs().max()) <= 5e-6
+    assert float((a[0, :, 77] - torch.from_numpy(g["vits8_L3_r96_row77"])).abs().max()) <= 5e-6
+
+
+def test_metrics_from_confusion_match_sklearn():
+    from sklearn.metrics import balanced_accuracy_score, f1_score, jaccard_score
+    from dino_amd.dinoseg import metrics_from_confusion
+    rng = np.random.default_rng(5)
+    for C, skew in ((7, False), (7, True), (3, False)):
+        gt = rng.integers(0, C if not skew else C - 2, 5000)          # skew: two classes never occur in gt
+        pred = np.where(rng.random(5000) < 0.7, gt, rng.integers(0, C if not skew else C - 1, 5000))
+        cm = np.zeros((C, C))
+        np.add.at(cm, (gt, pred), 1)
+        m = metrics_from_confusion(cm, "val")
+        assert abs(m["val_acc"] - balanced_accuracy_score(gt, pred)) <= 1e-12
+        assert abs(m["val_F1"] - f1_score(gt, pred, average="macro")) <= 1e-12
+        assert abs(m["val_iou"] - jaccard_score(gt, pred, average="macro")) <= 1e-12
