@@ -495,6 +495,14 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().attn_waves = value;
         return 0;
     }
+    if (strcmp(key, "attn_lsum_valu") == 0) {
+        dseg::options().attn_lsum_valu = value;
+        return 0;
+    }
+    if (strcmp(key, "attn_rows64") == 0) {
+        dseg::options().attn_rows64 = value;
+        return 0;
+    }
     if (strcmp(key, "attn_stages") == 0) {
         dseg::options().attn_stages = value;
         return 0;

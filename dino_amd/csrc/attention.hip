@@ -244,7 +244,15 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
             }
 
         // ---- row sums on the matrix core: ones[32 x 16] . P^T gives sum_k P[k][q] in every row (both lane halves) ----
-        {
+        if (p.lsum_valu) {
+            // row sums on the VALU: in-lane partial sums (this lane's 32 of the tile's 64 keys), halves joined at the end
+            float ps = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ps += sacc[kb][r];
+            l_run += ps;
+        } else {
             f32x16 lsum;
 #pragma unroll
             for (int r = 0; r < 16; ++r) lsum[r] = 0.f;
@@ -285,7 +293,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
     }
 
     // ---- normalise and write ctx[b*ntok + q][head*64 + d] ----
-    const float l_tot = l_run;      // the MFMA row sum already covers both lane halves
+    const float l_tot = p.lsum_valu ? l_run + __shfl_xor(l_run, 32) : l_run;     // the MFMA row sum already covers both halves
     const float inv = 1.0f / l_tot;
     if (qrow < ntok) {
         const int b = pair / p.heads, head = pair - b * p.heads;
@@ -346,6 +354,7 @@ static int launch_attn(const AttnParams& p, hipStream_t s) {
 int launch_attention(const AttnParams& p0, hipStream_t s) {
     AttnParams p = p0;
     p.dbg = options().attn_dbg;
+    p.lsum_valu = options().attn_lsum_valu;
     if (p.npad % KB != 0 || p.npad < p.ntok) {
         dinoseg_set_error("attention: npad=%d must be a multiple of 64 and >= ntok=%d", p.npad, p.ntok);
         return -1;
@@ -354,6 +363,7 @@ int launch_attention(const AttnParams& p0, hipStream_t s) {
     const bool rs = options().attn_regstage != 0;
     const int nst = options().attn_stages;
     if (p.dbg != 0 && p.planes == 1) return launch_attn<1, 4, true, false, 2>(p, s);      // ablation build (tools/bench_ops.py)
+    if (p.planes == 1 && options().attn_rows64 && nw == 4 && !rs && nst == 2) return launch_attention64(p, s);
     if (p.planes == 1) {
         if (nw == 8) return launch_attn<1, 8, false, false, 2>(p, s);
         if (rs) return launch_attn<1, 4, false, true, 2>(p, s);

@@ -55,6 +55,9 @@ struct Options {
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
     int attn_dbg = 0;        // same for AttnParams::dbg
     int attn_waves = 4;      // waves (x 32 query rows) per attention-forward workgroup: 4 or 8
+    int attn_rows64 = 0;     // bf16 mode: use the 64-rows-per-wave kernel (attention64.hip); measured 2 % slower
+    int attn_lsum_valu = 1;  // softmax row sums on the VALU (1, measured 5-7 % faster: the chip is power-limited, MFMAs are
+                             // the expensive instructions) or as a ones-vector MFMA (0)
     int attn_regstage = 0;   // 1: K/V tiles staged through registers, 0: LDS-DMA
     int attn_stages = 2;     // LDS ring slots of the LDS-DMA variant: 2 or 3
 };
@@ -67,8 +70,10 @@ struct AttnParams {
     float* lse;                        // optional [B,H,ntok] log2-domain log-sum-exp (for backward), may be null
     int B, heads, ntok, npad, planes;
     int dbg;                           // timing-only ablations: bit0 skip max/exp, bit1 skip steady-state loads, bit2 skip PV
+    int lsum_valu;                     // row sums by VALU adds instead of a ones-vector MFMA
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
+int launch_attention64(const AttnParams& p, hipStream_t s);   // bf16 only: 64 query rows per wave (attention64.hip)
 
 // fp32 [rows, cols] -> bf16 planes [planes][rows_pad][cols_pad], zero padded
 int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,

@@ -73,10 +73,11 @@ def bench_attn():
     lib = capi.lib()
     B, H, ntok = 32, 6, 3601
     npad = (ntok + 63) // 64 * 64
-    variants = [("ldsdma-2slot", dict(attn_waves=4, attn_regstage=0, attn_stages=2)),
-                ("ldsdma-3slot", dict(attn_waves=4, attn_regstage=0, attn_stages=3)),
-                ("8-wave WG", dict(attn_waves=8, attn_regstage=0, attn_stages=2)),
-                ("reg-staged", dict(attn_waves=4, attn_regstage=1, attn_stages=2))]
+    base = dict(attn_rows64=0, attn_waves=4, attn_regstage=0, attn_stages=2, attn_lsum_valu=1)
+    variants = [("32 rows/wave", dict(base)),
+                ("  MFMA row sums", dict(base, attn_lsum_valu=0)),
+                ("64 rows/wave", dict(base, attn_rows64=1)),
+                ("3-slot ring", dict(base, attn_stages=3))]
     for planes in (1, 2):
         q = rand_bf16((planes, B, H, npad, 64))
         k = rand_bf16((planes, B, H, npad, 64))
@@ -96,9 +97,9 @@ def bench_attn():
         fl = 4.0 * B * H * ntok * ntok * 64
         for name, _ in variants:
             t = sorted(times[name][1:])
-            print(f"attention planes={planes} {name:14s}: min {t[0] * 1e3:7.1f} us  median {t[len(t) // 2] * 1e3:7.1f} us  "
+            print(f"attention planes={planes} {name:18s}: min {t[0] * 1e3:7.1f} us  median {t[len(t) // 2] * 1e3:7.1f} us  "
                   f"{fl / (t[len(t) // 2] * 1e-3) / 1e12:6.1f} TFLOP/s", flush=True)
-    for kk, vv in dict(attn_waves=4, attn_regstage=0, attn_stages=2).items():
+    for kk, vv in base.items():
         lib.dinoseg_set_option(kk.encode(), vv)
 
 
