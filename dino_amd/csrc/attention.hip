@@ -20,34 +20,19 @@
 // 16 v_cvt_pk.
 //
 // PLANES = 2 (parity mode): Q, K, V and P are bf16 hi+lo pairs; each product is 3 MFMAs.
-#include "common.h"
+#include "attn_common.h"
 #include "kernels.h"
 
 namespace dseg {
 
 constexpr int QW = 32;          // query rows per wave
 constexpr int KB = 64;          // keys per tile
-constexpr int KV_TILE = 64 * 128;   // [64][64] bf16 slab = 8 KiB
+constexpr int KV_TILE = attn::KV_TILE_BYTES;   // [64][64] bf16 slab = 8 KiB
 
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-
-// K/V tile swizzle: chunk ^ (bit1(row) << 2 | (row >> 2) & 3).  Like common.h's swizzle it gives every 16-row
-// ds_read_b128 lane group 16 distinct 16-byte slots (it is a bit permutation of (row>>1)&7), and in addition the
-// 4 key rows of a transposing ds_read_b64_tr_b16 block fall on 4 distinct 64-byte quarters of the bank row
-// (rows r and r+2 differ in chunk bit 2), so the V^T reads are conflict-free too.
-__device__ __forceinline__ int swz2(int row, int chunk) { return chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)); }
-__device__ __forceinline__ int tile_off2(int row, int chunk) { return row * 128 + (swz2(row, chunk) << 4); }
-
-__device__ __forceinline__ int sigma23(int i) {   // swap bits 2 and 3
-    return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
-}
-
-// A-operand fragment (8 keys of one d column) from a row-major [key][d] LDS image: two transposing reads
-__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
-    const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)p0);
-    const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)p1);
-    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-}
+using attn::sigma23;
+using attn::tr_frag;
+__device__ __forceinline__ int swz2(int row, int chunk) { return attn::swz(row, chunk); }
+__device__ __forceinline__ int tile_off2(int row, int chunk) { return attn::tile_off(row, chunk); }
 
 template <int PLANES, int NW, bool DBG, bool REGSTAGE, int NST>     // NW waves per workgroup, each 32 query rows; all share the K/V tiles
 __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {

@@ -5,22 +5,17 @@
 // rows per wave did not help because the LDS->register traffic and the barrier group grow with it.)
 // The two query blocks go through the score / softmax phase one after the other (32 live score registers), their
 // probabilities are kept as bf16 fragments, and the PV phase uses each V^T fragment for both blocks.
-#include "common.h"
+#include "attn_common.h"
 #include "kernels.h"
 
 namespace dseg {
 
 namespace a64 {
-constexpr int KB = 64, KV_TILE = 64 * 128, STAGE_BYTES = 2 * KV_TILE;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-__device__ __forceinline__ int swz2(int row, int chunk) { return chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)); }
-__device__ __forceinline__ int tile_off2(int row, int chunk) { return row * 128 + (swz2(row, chunk) << 4); }
-__device__ __forceinline__ int sigma23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
-__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
-    const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)p0);
-    const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)p1);
-    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-}
+constexpr int KB = 64, KV_TILE = attn::KV_TILE_BYTES, STAGE_BYTES = 2 * KV_TILE;
+using attn::sigma23;
+using attn::tr_frag;
+__device__ __forceinline__ int swz2(int row, int chunk) { return attn::swz(row, chunk); }
+__device__ __forceinline__ int tile_off2(int row, int chunk) { return attn::tile_off(row, chunk); }
 }  // namespace a64
 
 __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(AttnParams p) {

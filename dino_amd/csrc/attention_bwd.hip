@@ -14,23 +14,16 @@
 // Row-major LDS tiles are read row-wise (ds_read_b128) for the score-type products and column-wise
 // (ds_read_b64_tr_b16) for the products that contract over the tile's rows.
 // Outputs go to dQKV planes [planes][B*ntok][3*heads*64] = gradient of the qkv GEMM output (Q | K | V columns).
-#include "common.h"
+#include "attn_common.h"
 #include "kernels.h"
 
 namespace dseg {
 
-constexpr int BKV_TILE = 64 * 128;   // [64][64] bf16 slab
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_b;
-
-__device__ __forceinline__ int bswz(int row, int chunk) { return chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)); }
-__device__ __forceinline__ int boff(int row, int chunk) { return row * 128 + (bswz(row, chunk) << 4); }
-__device__ __forceinline__ int bsigma23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
-
-__device__ __forceinline__ bf16x8 btr_frag(const char* p0, const char* p1) {
-    const bf16x4_b a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_b*)p0);
-    const bf16x4_b b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_b*)p1);
-    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-}
+constexpr int BKV_TILE = attn::KV_TILE_BYTES;   // [64][64] bf16 slab
+__device__ __forceinline__ int bswz(int row, int chunk) { return attn::swz(row, chunk); }
+__device__ __forceinline__ int boff(int row, int chunk) { return attn::tile_off(row, chunk); }
+__device__ __forceinline__ int bsigma23(int i) { return attn::sigma23(i); }
+__device__ __forceinline__ bf16x8 btr_frag(const char* p0, const char* p1) { return attn::tr_frag(p0, p1); }
 
 // registers 8*s2..8*s2+7 of a 32x32 accumulator -> bf16 hi(/lo) B-operand fragment
 template <int PLANES>

@@ -82,14 +82,14 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
         bn = q % nbn;
     };
 
-    auto issue = [&](int step) {
+    auto issue_range = [&](int step, int i0, int i1) {
         const int ti = step / nk, kt = step - ti * nk;
         int bm, bn;
         tile_of(ti, bm, bn);
         char* sbase = smem + (step % STAGES) * STAGE_BYTES;
         const int prow = lane >> 2;                         // row inside a 16-row piece
 #pragma unroll
-        for (int i = 0; i < PIECES_PER_WAVE; ++i) {
+        for (int i = i0; i < i1; ++i) {
             const int piece = wave * PIECES_PER_WAVE + i;   // first A_PIECES pieces: A rows, then W rows
             const bf16_t* src;
             if (piece < C::A_PIECES) {
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
             glds16(src, sbase + piece * 1024);
         }
     };
+    auto issue = [&](int step) { issue_range(step, 0, PIECES_PER_WAVE); };
 
     if (p.stagger > 0 && (local & 1)) {
         // all persistent workgroups run the same program on equal work and stay in phase: the whole chip stores its
@@ -141,7 +142,13 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();   // everyone's pieces of this slab landed; everyone finished reading slot (step-1)%S
-        if (step + STAGES - 1 < total_steps && !(p.dbg & 2)) issue(step + STAGES - 1);
+        const bool do_issue = step + STAGES - 1 < total_steps && !(p.dbg & 2);
+        const bool spread = (p.dbg & 4) != 0;      // experiment: LDS-DMA pieces spread through the slab's MFMAs instead of a burst
+        constexpr int H1 = (PIECES_PER_WAVE + 1) / 2;
+        if (do_issue) {
+            if (spread) issue_range(step + STAGES - 1, 0, H1);
+            else issue(step + STAGES - 1);
+        }
 
         const char* sa = smem + (step % STAGES) * STAGE_BYTES;
         const char* sw = sa + A_BYTES;
@@ -158,6 +165,11 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);   // lane: column n, registers: rows m
+            if (kk == 0 && spread) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (do_issue) issue_range(step + STAGES - 1, H1, PIECES_PER_WAVE);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 

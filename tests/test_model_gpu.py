@@ -213,3 +213,39 @@ def test_validation_metrics_on_device(cuda):
     assert abs(res["val_F1"] - f1_score(g_, p, average="macro")) <= 1e-12
     assert abs(res["val_iou"] - jaccard_score(g_, p, average="macro")) <= 1e-12
     assert int(torch.stack([o["confusion"] for o in outs]).sum()) == p.size
+
+
+@pytest.mark.parametrize("r,B", [(8, 1), (16, 3), (104, 2)])
+def test_tiny_and_ragged_resolutions(cuda, r, B):
+    """Edge shapes: a single patch (N = 2 tokens), 2x2 patches, and a 13x13 grid (N = 170: ragged in every tile size)."""
+    cfg = ViTConfig(n_blocks=2)
+    for precision, tol in (("bf16x3", TOL), ("bf16", 0.35)):
+        m, sd, _ = build(cfg, precision)
+        m.set_resolution(r)
+        frames = synthetic_frames(B, r, seed=70 + r)
+        with torch.no_grad():
+            ref = O.dinoseg_forward(O.preprocess(frames), O.to_torch(sd), cfg.num_heads)
+        lp, am = m.forward_frames(torch.from_numpy(frames).cuda())
+        assert lp.shape == ref.shape and torch.isfinite(lp).all()
+        assert float((lp.cpu() - ref).abs().max()) <= tol
+        if precision == "bf16x3":
+            top2 = ref.topk(2, dim=1).values
+            safe = (top2[:, 0] - top2[:, 1]) > 2 * TOL
+            assert torch.equal(am.cpu().long()[safe], ref.argmax(1)[safe])
+
+
+def test_training_step_ragged_batch(cuda):
+    """Fine-tune step at a 13x13 grid with B=3 (row counts that divide nothing) against the oracle's autograd."""
+    cfg = ViTConfig(embed_dim=128, num_heads=2, n_blocks=1)
+    m, sd, _ = build(cfg, "bf16x3")
+    m.unfreeze_bb()
+    frames = synthetic_frames(3, 104, seed=5)
+    labels = np.random.default_rng(6).integers(0, 7, (3, 169)).astype(np.int64)
+    out = m.training_step((torch.from_numpy(frames).cuda(), torch.from_numpy(labels).cuda()), 0)
+    W = O.to_torch(sd, requires_grad=True)
+    loss = O.nll_loss(O.dinoseg_forward(O.preprocess(frames), W, cfg.num_heads), torch.from_numpy(labels))
+    loss.backward()
+    assert abs(float(out["loss"]) - float(loss.detach())) <= 2e-4
+    for k, p in m.named_parameters():
+        gn = float(W[k].grad.norm())
+        assert float((p.grad.cpu() - W[k].grad).abs().max()) <= 3e-3 * gn + 1e-7, k
