@@ -503,12 +503,8 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().attn_rows64 = value;
         return 0;
     }
-    if (strcmp(key, "attn_stages") == 0) {
-        dseg::options().attn_stages = value;
-        return 0;
-    }
-    if (strcmp(key, "attn_regstage") == 0) {
-        dseg::options().attn_regstage = value;
+    if (strcmp(key, "attn_variant") == 0) {
+        dseg::options().attn_variant = value;
         return 0;
     }
     if (strcmp(key, "attn_dbg") == 0) {

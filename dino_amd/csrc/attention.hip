@@ -34,13 +34,18 @@ using attn::tr_frag;
 __device__ __forceinline__ int swz2(int row, int chunk) { return attn::swz(row, chunk); }
 __device__ __forceinline__ int tile_off2(int row, int chunk) { return attn::tile_off(row, chunk); }
 
-template <int PLANES, int NW, bool DBG, bool REGSTAGE, int NST>     // NW waves per workgroup, each 32 query rows; all share the K/V tiles
+// VAR bit 0: no per-tile row maximum.  The tile's probabilities are exponentiated against the current reference straight
+//            away and the in-lane partial row sum (needed anyway) is the overflow detector: if any lane's sum exceeds
+//            2^RESCALE_THR the tile is redone the careful way (scores recomputed from the K tile still in LDS, row
+//            maximum, rescale).  Saves 16 v_max3 + a cross-half exchange per tile on the vector issue port.
+//     bit 1: waves whose 32 query rows are all past ntok (last q-tile of a (batch, head)) only stage and synchronise
+template <int PLANES, int NW, bool DBG, int VAR>     // NW waves per workgroup, each 32 query rows; all share the K/V tiles
 __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
     constexpr int QB = NW * QW;
     const int dbg = DBG ? p.dbg : 0;        // timing ablations are compiled out of the production instantiation
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = PLANES * 2 * KV_TILE;   // per plane: K slab + V slab
-    constexpr int NSTAGE = REGSTAGE ? 2 : NST;
+    // (a 3-slot ring with counted vmcnt measured 4 % slower: LDS 48 KiB per workgroup and a dynamic slot index)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,7 +82,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
 #pragma unroll
             for (int i = 0; i < (16 + NW - 1) / NW; ++i) {
                 const int piece = wave + i * NW;              // 0..7: K rows, 8..15: V rows
-                if (piece < 16) {
+                if (16 % NW == 0 || piece < 16) {               // (compile-time true for 4 and 8 waves: straight-line issue)
                     const int row = (piece & 7) * 8 + (lane >> 3);
                     const int c = swz2(row, lane & 7);
                     const bf16_t* src = (piece < 8 ? Kg : Vg) + pl * p.qkv_plane + (long)(key0 + row) * 64 + c * 8;
@@ -86,21 +91,6 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
             }
         }
     };
-
-    // Register staging (REGSTAGE): global_load_dwordx4 -> VGPR issued before the tile's MFMA work, ds_write_b128 after
-    // it.  An LDS-DMA piece costs 60-185 issue cycles beside MFMAs (MI355X_MICROARCH.md cycle table) against ~20 for a
-    // load + LDS-write pair; with 4 pieces per wave and tile that was a quarter of the loop (ablation: -24 % w/o loads).
-    uint4 sr[PLANES][4];
-#define DSEG_STAGE_LOAD(KEY0)                                                                                          \
-    _Pragma("unroll") for (int pl = 0; pl < PLANES; ++pl) _Pragma("unroll") for (int i = 0; i < 4; ++i) {              \
-        const int piece = wave + i * NW;                                                                               \
-        const int row = (piece & 7) * 8 + (lane >> 3);                                                                 \
-        sr[pl][i] = *reinterpret_cast<const uint4*>((piece < 8 ? Kg : Vg) + pl * p.qkv_plane + (long)((KEY0) + row) * 64 + \
-                                                    swz2(row, lane & 7) * 8);                                          \
-    }
-#define DSEG_STAGE_WRITE(ST)                                                                                           \
-    _Pragma("unroll") for (int pl = 0; pl < PLANES; ++pl) _Pragma("unroll") for (int i = 0; i < 4; ++i)                \
-        *reinterpret_cast<uint4*>(smem + (ST) * STAGE_BYTES + pl * 2 * KV_TILE + (wave + i * NW) * 1024 + lane * 16) = sr[pl][i];
 
     f32x16 o[2];
 #pragma unroll
@@ -119,19 +109,11 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
     const uint4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
-    // K/V tiles run through an NSTAGE-slot LDS ring (NSTAGE - 1 tiles in flight while one is multiplied, counted
-    // vmcnt).  Measured: 3 slots are 5 % SLOWER than 2 at this shape (742 -> 775 us; LDS 48 KiB per workgroup and a
-    // dynamic slot index), so the loop is not bound by the LDS-DMA round trip; 2 slots are the default.
+    // K/V tiles are double-buffered in LDS: tile t+1 is in flight (LDS-DMA) while tile t is multiplied.
     const int ntiles = (ntok + KB - 1) / KB;
-    if (REGSTAGE) {
-        DSEG_STAGE_LOAD(0)
-        DSEG_STAGE_WRITE(0)
-        __syncthreads();
-    } else {
-        stage(0, 0);
-        if (NSTAGE > 2 && ntiles > 1) stage(1, KB);
-    }
+    stage(0, 0);
 
+    const bool wave_active = qt * QB + wave * QW < ntok;     // wave-uniform
     const int krow_perm = sigma23(lr);
     // transposed V read (ds_read_b64_tr_b16): within each 16-lane group, lane 4q+p addresses key row q, d columns
     // 4p..4p+3 of a 4-key x 16-d block and receives column (lane&15) of the 4 keys.  Group g = lane>>4 covers
@@ -139,60 +121,61 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_gl = (lane >> 4) & 1;
 
     for (int t = 0; t < ntiles; ++t) {
-        if (REGSTAGE) {
-            if (t + 1 < ntiles) { DSEG_STAGE_LOAD((t + 1) * KB) }      // in flight during this tile's MFMA work
-        } else {
-        // tile t landed (this wave's pieces); the one issued after it may still be in flight
-        if (NSTAGE > 2 && t + 1 < ntiles) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((16 + NW - 1) / NW) * PLANES) : "memory");   // exact only when NW divides 16
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();      // everyone's pieces of tile t landed; everyone is done reading slot (t-1)%NSTAGE
-        if (t + NSTAGE - 1 < ntiles && !(dbg & 2)) stage((t + NSTAGE - 1) % NSTAGE, (t + NSTAGE - 1) * KB);
-        }
-        const char* sb = smem + (REGSTAGE ? (t & 1) : (t % NSTAGE)) * STAGE_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();      // everyone's pieces of tile t landed; everyone is done reading slot (t-1)&1
+        if (t + 1 < ntiles && !(dbg & 2)) stage((t + 1) & 1, (t + 1) * KB);
+        if ((VAR & 2) && !wave_active) continue;
+        const char* sb = smem + (t & 1) * STAGE_BYTES;
 
-        // ---- S^T[key][q] = K . Q^T ----
+        // ---- S'^T[key][q] = K . Q^T - m_run: the tile's 8 K fragments are read up front (one LDS latency per tile) ----
         f32x16 sacc[2];
+        auto scores = [&]() {
+            bf16x8 kf[PLANES][2][4];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            sacc[kb] = negm;            // C input of the chain: S' = K.Q^T - m_run
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int off = tile_off2(kb * 32 + krow_perm, s * 2 + lh);
-                const bf16x8 khi = lds_frag(sb + off);
-                if (PLANES == 2) {
-                    const bf16x8 klo = lds_frag(sb + 2 * KV_TILE + off);
-                    sacc[kb] = mfma32(klo, qf[0][s], sacc[kb]);
-                    sacc[kb] = mfma32(khi, qf[PLANES - 1][s], sacc[kb]);
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int off = tile_off2(kb * 32 + krow_perm, s * 2 + lh);
+                    kf[0][kb][s] = lds_frag(sb + off);
+                    if (PLANES == 2) kf[PLANES - 1][kb][s] = lds_frag(sb + 2 * KV_TILE + off);
                 }
-                sacc[kb] = mfma32(khi, qf[0][s], sacc[kb]);
+            sacc[0] = negm;             // C input of the chains
+            sacc[1] = negm;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (PLANES == 2) {
+                        sacc[kb] = mfma32(kf[PLANES - 1][kb][s], qf[0][s], sacc[kb]);
+                        sacc[kb] = mfma32(kf[0][kb][s], qf[PLANES - 1][s], sacc[kb]);
+                    }
+                    sacc[kb] = mfma32(kf[0][kb][s], qf[0][s], sacc[kb]);
+                }
+            // lane (query lr, half lh): sacc[kb][8*s2 + j] is key  t*64 + kb*32 + s2*16 + lh*8 + j
+            if ((t + 1) * KB > ntok) {   // ragged last tile: mask keys >= ntok (wave-uniform branch)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * KB + kb * 32 + (r >> 3) * 16 + lh * 8 + (r & 7);
+                        if (key >= ntok) sacc[kb][r] = -INFINITY;
+                    }
             }
-        }
-        // lane (query lr, half lh): sacc[kb][8*s2 + j] is key  t*64 + kb*32 + s2*16 + lh*8 + j
-
-        if ((t + 1) * KB > ntok) {   // ragged last tile: mask keys >= ntok (wave-uniform branch)
+        };
+        // P = 2^S' in place; returns this lane's partial row sum (its 32 of the tile's 64 keys)
+        auto exponentiate = [&]() {
+            float ps = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = t * KB + kb * 32 + (r >> 3) * 16 + lh * 8 + (r & 7);
-                    if (key >= ntok) sacc[kb][r] = -INFINITY;
+                    sacc[kb][r] = (dbg & 1) ? sacc[kb][r] * 0.01f : __builtin_amdgcn_exp2f(sacc[kb][r]);
+                    ps += sacc[kb][r];
                 }
-        }
-
-        // ---- online softmax (log2 domain), deferred rescale ----
-        float mx = sacc[0][0];
-        if (!(dbg & 1)) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-        }
-        if (t == 0 || __any(mx > RESCALE_THR)) {
-            // everything still measured against the old reference is rescaled exactly once: S', O, l and negm
+            return ps;
+        };
+        // move the reference: everything still measured against the old one is rescaled exactly once (S', O, l, negm)
+        auto rescale = [&](float mx) {
             const float delta = (t == 0) ? mx : fmaxf(mx, 0.f);
             const float alpha = __builtin_amdgcn_exp2f(-delta);
             m_run += delta;
@@ -207,11 +190,36 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
             for (int d = 0; d < 2; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        };
+        auto row_max = [&]() {
+            float mx = sacc[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+            return fmaxf(mx, __shfl_xor(mx, 32));
+        };
+
+        // ---- online softmax (log2 domain), deferred rescale ----
+        scores();
+        float ps;
+        if (VAR & 1) {
+            bool careful = (t == 0);
+            if (!careful) {
+                ps = exponentiate();
+                // 2^RESCALE_THR bounds every P of the tile on the fast path; !(<=) also catches inf / NaN sums
+                careful = __any(!(ps <= 65536.f));
+                if (careful) scores();
+            }
+            if (careful) {
+                rescale(row_max());
+                ps = exponentiate();
+            }
+        } else {
+            const float mx = (dbg & 1) ? sacc[0][0] : row_max();
+            if (t == 0 || __any(mx > RESCALE_THR)) rescale(mx);
+            ps = exponentiate();
         }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = (dbg & 1) ? sacc[kb][r] * 0.01f : __builtin_amdgcn_exp2f(sacc[kb][r]);
 
         // ---- P fragments (B operand: k = key, col = query): registers 8*s2..8*s2+7 of sacc[kb] ----
         bf16x8 pf[PLANES][4];
@@ -228,14 +236,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
                 if (PLANES == 2) pf[PLANES - 1][kb * 2 + s2] = __builtin_bit_cast(bf16x8, lo);
             }
 
-        // ---- row sums on the matrix core: ones[32 x 16] . P^T gives sum_k P[k][q] in every row (both lane halves) ----
+        // ---- row sums: on the VALU (in-lane partial sums, halves joined at the end), or ones[32 x 16] . P^T on the matrix core
         if (p.lsum_valu) {
-            // row sums on the VALU: in-lane partial sums (this lane's 32 of the tile's 64 keys), halves joined at the end
-            float ps = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ps += sacc[kb][r];
             l_run += ps;
         } else {
             f32x16 lsum;
@@ -269,71 +271,73 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
             }
         }
 
-        if (REGSTAGE) {
-            if (t + 1 < ntiles) { DSEG_STAGE_WRITE((t + 1) & 1) }      // slot last read in iteration t-1 (barrier below t-1)
-            __syncthreads();
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of tile t are complete
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of tile t are complete
     }
 
     // ---- normalise and write ctx[b*ntok + q][head*64 + d] ----
     const float l_tot = p.lsum_valu ? l_run + __shfl_xor(l_run, 32) : l_run;     // the MFMA row sum already covers both halves
     const float inv = 1.0f / l_tot;
-    if (qrow < ntok) {
-        const int b = pair / p.heads, head = pair - b * p.heads;
-        const int dm = p.heads * 64;
-        bf16_t* dst = p.ctx + ((long)b * ntok + qrow) * dm + head * 64;
+    const int b = pair / p.heads, head = pair - b * p.heads;
+    const int dm = p.heads * 64;
+    {
+        // Whole-row stores: the slot the last tile did NOT use is free for every wave (all passed the last barrier, nothing
+        // was staged after it); each wave owns a [32 rows][128 B] patch of it, 16-byte chunks XORed with row & 7.
+        // Row-per-lane 8-byte stores touch 32 lines per instruction and are store-issue bound; 8 lanes x 16 B per row are not.
+        char* patch = smem + (ntiles & 1) * STAGE_BYTES + wave * 4096;
+        const int q0 = qt * QB + wave * QW;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int pl = 0; pl < PLANES; ++pl) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = db * 32 + 8 * g + 4 * lh;   // registers 4g..4g+3 are d .. d+3
-                uint2 hi, lo;
-                split_bf16x2(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv, hi.x, lo.x);
-                split_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv, hi.y, lo.y);
-                *reinterpret_cast<uint2*>(dst + d) = hi;
-                if (PLANES == 2) *reinterpret_cast<uint2*>(dst + p.ctx_plane + d) = lo;
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 hi, lo;
+                    split_bf16x2(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv, hi.x, lo.x);
+                    split_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv, hi.y, lo.y);
+                    *reinterpret_cast<uint2*>(patch + lr * 128 + (((db * 4 + g) ^ (lr & 7)) << 4) + lh * 8) = pl == 0 ? hi : lo;
+                }
+            // one wave's LDS requests execute in order; the compiler must keep them in order too (the 8-byte writes and the
+            // 16-byte reads have unrelated types, so alias analysis alone would let them cross)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 8 + (lane >> 3);
+                const uint4 v = *reinterpret_cast<const uint4*>(patch + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                if (q0 + row < ntok)
+                    *reinterpret_cast<uint4*>(p.ctx + pl * p.ctx_plane + ((long)b * ntok + q0 + row) * dm + head * 64 + (lane & 7) * 8) = v;
             }
-        if (p.lse != nullptr && lh == 0) p.lse[(long)pair * ntok + qrow] = m_run + __builtin_amdgcn_logf(l_tot);
+            asm volatile("" ::: "memory");
+        }
+        if (qrow < ntok && p.lse != nullptr && lh == 0) p.lse[(long)pair * ntok + qrow] = m_run + __builtin_amdgcn_logf(l_tot);
     }
 }
 
-template <int PLANES, int NW, bool DBG, bool REGSTAGE, int NST>
+template <int PLANES, int NW, bool DBG, int VAR>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
-    attn_fwd_body<PLANES, NW, DBG, REGSTAGE, NST>(p);
-}
-// register-staged variant: 16 / 32 more live registers -> pin 2 waves per SIMD instead of spilling for 3
-template <int PLANES, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_regstage_kernel(AttnParams p) {
-    attn_fwd_body<PLANES, NW, false, true, 2>(p);
+    attn_fwd_body<PLANES, NW, DBG, VAR>(p);
 }
 
-template <int PLANES, int NW, bool DBG, bool REGSTAGE, int NST>
+template <int PLANES, int NW, bool DBG, int VAR>
 static int launch_attn(const AttnParams& p, hipStream_t s) {
     const int nq = (p.ntok + NW * QW - 1) / (NW * QW);
     const int npairs = p.B * p.heads;
     const int grid = ((npairs + 7) / 8) * 8 * nq;
-    const size_t lds = (size_t)(REGSTAGE ? 2 : NST) * PLANES * 2 * KV_TILE;
-    static bool attr_done = false;
-    if (!attr_done) {
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<PLANES, NW, DBG, REGSTAGE, NST>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    if (REGSTAGE) {
-        static bool rs_attr = false;
-        if (!rs_attr) {
-            DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_regstage_kernel<PLANES, NW>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            rs_attr = true;
-        }
-        hipLaunchKernelGGL((attn_fwd_regstage_kernel<PLANES, NW>), dim3(grid), dim3(NW * 64), lds, s, p);
-    } else {
-        hipLaunchKernelGGL((attn_fwd_kernel<PLANES, NW, DBG, REGSTAGE, NST>), dim3(grid), dim3(NW * 64), lds, s, p);
-    }
+    const size_t lds = (size_t)2 * PLANES * 2 * KV_TILE;
+    hipLaunchKernelGGL((attn_fwd_kernel<PLANES, NW, DBG, VAR>), dim3(grid), dim3(NW * 64), lds, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+template <int PLANES>
+static int launch_attn_planes(const AttnParams& p, hipStream_t s) {
+    const int nw = options().attn_waves;        // query rows per workgroup = 32 * waves (K/V bytes per FLOP ~ 1 / waves)
+    if (nw == 8) return launch_attn<PLANES, 8, false, 0>(p, s);
+    switch (options().attn_variant & 3) {
+        case 1: return launch_attn<PLANES, 4, false, 1>(p, s);
+        case 2: return launch_attn<PLANES, 4, false, 2>(p, s);
+        case 3: return launch_attn<PLANES, 4, false, 3>(p, s);
+        default: return launch_attn<PLANES, 4, false, 0>(p, s);
+    }
 }
 
 int launch_attention(const AttnParams& p0, hipStream_t s) {
@@ -344,21 +348,10 @@ int launch_attention(const AttnParams& p0, hipStream_t s) {
         dinoseg_set_error("attention: npad=%d must be a multiple of 64 and >= ntok=%d", p.npad, p.ntok);
         return -1;
     }
-    const int nw = options().attn_waves;        // query rows per workgroup = 32 * waves (K/V bytes per FLOP ~ 1 / waves)
-    const bool rs = options().attn_regstage != 0;
-    const int nst = options().attn_stages;
-    if (p.dbg != 0 && p.planes == 1) return launch_attn<1, 4, true, false, 2>(p, s);      // ablation build (tools/bench_ops.py)
-    if (p.planes == 1 && options().attn_rows64 && nw == 4 && !rs && nst == 2) return launch_attention64(p, s);
-    if (p.planes == 1) {
-        if (nw == 8) return launch_attn<1, 8, false, false, 2>(p, s);
-        if (rs) return launch_attn<1, 4, false, true, 2>(p, s);
-        return nst == 3 ? launch_attn<1, 4, false, false, 3>(p, s) : launch_attn<1, 4, false, false, 2>(p, s);
-    }
-    if (p.planes == 2) {
-        if (nw == 8) return launch_attn<2, 8, false, false, 2>(p, s);
-        if (rs) return launch_attn<2, 4, false, true, 2>(p, s);
-        return nst == 3 ? launch_attn<2, 4, false, false, 3>(p, s) : launch_attn<2, 4, false, false, 2>(p, s);
-    }
+    if (p.dbg != 0 && p.planes == 1) return launch_attn<1, 4, true, 0>(p, s);      // ablation build (tools/bench_ops.py)
+    if (p.planes == 1 && options().attn_rows64 && options().attn_waves == 4) return launch_attention64(p, s);
+    if (p.planes == 1) return launch_attn_planes<1>(p, s);
+    if (p.planes == 2) return launch_attn_planes<2>(p, s);
     dinoseg_set_error("attention: planes must be 1 or 2");
     return -1;
 }

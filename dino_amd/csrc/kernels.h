@@ -58,8 +58,7 @@ struct Options {
     int attn_rows64 = 0;     // bf16 mode: use the 64-rows-per-wave kernel (attention64.hip); measured 2 % slower
     int attn_lsum_valu = 1;  // softmax row sums on the VALU (1, measured 5-7 % faster: the chip is power-limited, MFMAs are
                              // the expensive instructions) or as a ones-vector MFMA (0)
-    int attn_regstage = 0;   // 1: K/V tiles staged through registers, 0: LDS-DMA
-    int attn_stages = 2;     // LDS ring slots of the LDS-DMA variant: 2 or 3
+    int attn_variant = 3;    // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the tile work
 };
 Options& options();
 

@@ -110,6 +110,9 @@ def test_qkv_gemm_layout(cuda, planes, H, ntok):
     assert torch.all(gq[:, :, ntok:] == 0) and torch.all(gk[:, :, ntok:] == 0) and torch.all(gv[:, :, ntok:] == 0)
 
 
+ATTN_VARIANT_DEFAULT = 3
+
+
 def _attention_case(B, H, ntok, planes, seed, spike=False):
     npad = (ntok + 63) // 64 * 64
     g = np.random.default_rng(seed)
@@ -162,6 +165,28 @@ def test_attention(cuda, planes, B, H, ntok):
 def test_attention_rescale_branch(cuda, planes):
     got, ref, _, _ = _attention_case(1, 1, 300, planes, seed=77, spike=True)
     assert float((got - ref).abs().max()) <= (1.2e-2 if planes == 1 else 1e-4)
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_attention_kernel_variants(cuda, planes, variant):
+    """dinoseg_set_option('attn_variant'): bit 0 = overflow check on the row sums instead of a per-tile row maximum,
+    bit 1 = idle waves of the last q-tile skip the tile work.  Without a rescale after the first tile all variants do the
+    same arithmetic in the same order."""
+    lib = capi.lib()
+    try:
+        capi.check(lib.dinoseg_set_option(b"attn_variant", 0))
+        base, ref, lse0, _ = _attention_case(2, 2, 197, planes, seed=5)
+        capi.check(lib.dinoseg_set_option(b"attn_variant", variant))
+        got, _, lse, _ = _attention_case(2, 2, 197, planes, seed=5)
+        got2, ref2, lse2, ref_lse2 = _attention_case(1, 1, 300, planes, seed=77, spike=True)     # rescale path
+        got3, ref3, _, _ = _attention_case(1, 2, 3601, planes, seed=9)      # 17 valid rows in the last q-tile
+    finally:
+        capi.check(lib.dinoseg_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT))
+    assert torch.equal(got, base) and torch.equal(lse, lse0)
+    tol = 1.2e-2 if planes == 1 else 1e-4
+    assert float((got2 - ref2).abs().max()) <= tol and float((got3 - ref3).abs().max()) <= tol
+    assert float((lse2 - ref_lse2).abs().max()) <= (6e-3 if planes == 1 else 1e-4)
 
 
 @pytest.mark.parametrize("D", [128, 384, 768])
