@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (EPI == EPI_GELU) v[e] = gelu_erf(v[e]);
+                if (EPI == EPI_GELU) v[e] = PLANES == 1 ? gelu_fast(v[e]) : gelu_erf(v[e]);
                 if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
                 if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
             }

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
                                           v1[0] + bb[4], v1[1] + bb[5], v1[2] + bb[6], v1[3] + bb[7]};
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                if (EPI == EPI_GELU) v[e] = gelu_erf(v[e]);
+                                if (EPI == EPI_GELU) v[e] = gelu_fast(v[e]);     // bf16 fast mode only (planes == 1)
                                 if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
                                 if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
                             }

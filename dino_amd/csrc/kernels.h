@@ -58,7 +58,8 @@ struct Options {
     int attn_rows64 = 0;     // bf16 mode: use the 64-rows-per-wave kernel (attention64.hip); measured 2 % slower
     int attn_lsum_valu = 1;  // softmax row sums on the VALU (1, measured 5-7 % faster: the chip is power-limited, MFMAs are
                              // the expensive instructions) or as a ones-vector MFMA (0)
-    int attn_variant = 3;    // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the tile work
+    int attn_variant = 3;    // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
+                             // tile work; bit 2 (bf16 mode): software-pipelined kernel attention_pipe.hip (measured 10 % slower)
 };
 Options& options();
 
@@ -72,6 +73,7 @@ struct AttnParams {
     int lsum_valu;                     // row sums by VALU adds instead of a ones-vector MFMA
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
+int launch_attention_pipe(const AttnParams& p, hipStream_t s); // bf16 only: software-pipelined across tiles (attention_pipe.hip)
 int launch_attention64(const AttnParams& p, hipStream_t s);   // bf16 only: 64 query rows per wave (attention64.hip)
 
 // fp32 [rows, cols] -> bf16 planes [planes][rows_pad][cols_pad], zero padded

@@ -73,11 +73,9 @@ def bench_attn():
     lib = capi.lib()
     B, H, ntok = 32, 6, 3601
     npad = (ntok + 63) // 64 * 64
-    base = dict(attn_rows64=0, attn_waves=4, attn_variant=0, attn_lsum_valu=1)
-    variants = [("base", dict(base)),
-                ("no row max (1)", dict(base, attn_variant=1)),
-                ("idle waves skip (2)", dict(base, attn_variant=2)),
-                ("both (3)", dict(base, attn_variant=3))]
+    base = dict(attn_rows64=0, attn_waves=4, attn_variant=3)
+    variants = [("per-tile (3)", dict(base, attn_variant=3)),
+                ("pipelined (7)", dict(base, attn_variant=7))]
     for planes in (1, 2):
         q = rand_bf16((planes, B, H, npad, 64))
         k = rand_bf16((planes, B, H, npad, 64))
