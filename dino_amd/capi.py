@@ -86,11 +86,12 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("DINOSEG_LIB", LIB_PATH)      # A/B runs of two builds (tools/ab_bench.sh); default: the in-tree build
+    if not os.path.exists(path):
         raise DinosegError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C dino_amd/csrc`). dino_amd has no CPU/PyTorch fallback.")
-    l = C.CDLL(LIB_PATH)
+    l = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(l, name)   # AttributeError if the symbol is not exported
         fn.restype = res

@@ -204,6 +204,29 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
     const int gn = n0 + c4 * 4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + gn);
+    if (EPI == EPI_RESID) {
+        // out = resid + acc + bias (usually in place).  The residual rows are fetched 8 at a time before any store:
+        // a load issued after a store to the same buffer waits for the store's acknowledgement (one vmcnt for both).
+#pragma unroll
+        for (int it0 = 0; it0 < 16; it0 += 8) {
+            f32x4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int gm = m0 + (it0 + u) * 8 + rb;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const float* src = (p.resid ? p.resid : p.out_f32) + (long)gm * p.ldo_f32 + gn;
+                x[u] = gm < M ? *reinterpret_cast<const f32x4*>(src) : z;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = (it0 + u) * 8 + rb;
+                const int gm = m0 + row;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(C + row * 128 + c4 * 4) + bias4 + x[u];
+                if (gm < M) *reinterpret_cast<f32x4*>(p.out_f32 + (long)gm * p.ldo_f32 + gn) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
         const int row = it * 8 + rb;
@@ -213,11 +236,6 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
         v += bias4;
         if (EPI == EPI_PLAIN) {
             *reinterpret_cast<f32x4*>(p.out_f32 + (long)gm * p.ldo_f32 + gn) = v;
-        } else if (EPI == EPI_RESID) {
-            float* dst = p.out_f32 + (long)gm * p.ldo_f32 + gn;
-            const float* src = p.resid ? p.resid + (long)gm * p.ldo_f32 + gn : dst;
-            f32x4 x = *reinterpret_cast<const f32x4*>(src);
-            *reinterpret_cast<f32x4*>(dst) = x + v;
         } else if (EPI == EPI_ATOMIC) {
             float* dst = p.out_f32 + (long)gm * p.ldo_f32 + gn;
 #pragma unroll

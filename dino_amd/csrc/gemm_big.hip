@@ -39,8 +39,7 @@ struct Cfg {
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES + NWAVES * 4096;   // ring + one 32x32 fp32 patch per wave
 };
 using Cfg256x384 = Cfg<2, 4, 4, 3, 3, 1>;   // 120 KiB ring + 32 KiB epilogue patches, 1 workgroup / CU, 154 FLOP per staged byte
-using Cfg128x128 = Cfg<2, 2, 2, 2, 2, 3>;   // 32 KiB ring + 16 KiB patches, 3 workgroups / CU (phases of different tiles overlap)
-using Cfg128x192 = Cfg<2, 2, 2, 3, 2, 3>;   // 40 KiB ring + 16 KiB patches, 3 workgroups / CU (BN = 192: fewer bytes per FLOP than 128x128)
+// (Cfg<2,2,2,2,2,3> = 128x128 and Cfg<2,2,2,3,2,3> = 128x192 with 3 workgroups per CU were measured: 15-25 % slower)
 
 // 64-byte rows (4 chunks of 16 B): XOR the chunk with (row>>2)&3 -> the 16 rows of a ds_read_b128 lane group
 // fall on 16 distinct 16-byte slots of the 256-byte bank row.
@@ -115,15 +114,28 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
         for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
     f32x16 acc[MI][NI];
-    auto zero_acc = [&]() {
+    // The bias is the accumulators' initial value (lane = column: one float per 32-column block), so the epilogue has no
+    // bias registers and no bias adds.  The next tile's values are fetched at the top of the epilogue, before its stores.
+    float bias_col[NI];
+    auto bias_ptr = [&](int ti_c) {
+        int bm2, bn2;
+        tile_of(ti_c, bm2, bn2);
+        return p.bias + p.n_off + bn2 * BN + wc * NI * 32 + lr;
+    };
+    auto init_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = bias_col[j];
     };
-    zero_acc();
+    {
+        const float* bp = bias_ptr(0);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bias_col[j] = bp[j * 32];
+    }
+    init_acc();
 
     // ---- prologue: fill STAGES-1 ring slots
 #pragma unroll
@@ -175,24 +187,103 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
 
         if (++kt == nk) {
             // ================= epilogue from registers =================
-            kt = 0;
-            ++ti;
-            const int m0 = bm * BM + wr * MI * 32, n0 = p.n_off + bn * BN + wc * NI * 32;
-            const bool skip_epi = (p.dbg & 1) && acc[0][0][0] != 12345.678f;   // ablation (keeps accumulators live)
-            if (!skip_epi) {
             // Each 32x32 accumulator goes through a wave-private 4 KiB LDS patch (no workgroup barrier: LDS requests of
             // one wave complete in order) and leaves as 16-byte-per-lane row segments: 8 rows x 128 B per fp32 store
             // instruction, 16 rows x 64 B per bf16 one.  (Narrower stores were store-issue bound: 4-byte stores straight
             // from the accumulators cost as much as the main loop.)
+            // The body is straight-line code on purpose.  gfx9 counts loads AND stores in one in-order vmcnt; with a global
+            // load (bias) or a branch (row guard) inside, the compiler's wait insertion falls back to vmcnt(0) before every
+            // use / in every block, and each store then waits for the previous one to be acknowledged (24-48 serial round
+            // trips per wave and tile: that was most of the "epilogue costs as much as the main loop" of the first version).
+            // So: no global loads besides the next tile's bias at the top, rows clamped instead of guarded (rows >= M of the
+            // last panel are copies of row M-1 -- the loader clamps the same way -- so their stores rewrite identical bytes).
+            kt = 0;
+            ++ti;
+            const int m0 = bm * BM + wr * MI * 32, n0 = p.n_off + bn * BN + wc * NI * 32;
+            const bool skip_epi = (p.dbg & 1) && acc[0][0][0] != 12345.678f;   // ablation (keeps accumulators live)
             float* st = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES + wave * 4096);
-            constexpr bool F32_OUT = (EPI == EPI_PLAIN || EPI == EPI_RESID || EPI == EPI_PATCH);
+            constexpr bool F32_OUT = (EPI == EPI_PLAIN || EPI == EPI_RESID);
+            const float* bnext = bias_ptr(ti < my_tiles ? ti : my_tiles - 1);
+            float bias_next[NI];
+            if (EPI == EPI_RESID) {
+                // loads the compiler does not count (see below); complete before the last counted wait of the segment ring
+#pragma unroll
+                for (int j = 0; j < NI; ++j) asm volatile("global_load_dword %0, %1, off" : "=v"(bias_next[j]) : "v"(bnext + j * 32) : "memory");
+            } else {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bias_next[j] = bnext[j * 32];
+            }
+            if (!skip_epi) {
+            if (EPI == EPI_RESID) {
+                // x += acc, in place.  The 48 row segments of the wave's tile run through a 4-deep register ring: the load
+                // of segment s+4 is issued before the store of segment s, by instructions the compiler does not count, with
+                // hand-counted vmcnt (cdna_hip_programming.md 5.7 form ii).  Addresses are a wave-uniform SGPR base per
+                // segment + one per-lane VGPR offset.  (A deeper ring spills: 243 VGPRs as is.)
+                const int cg = lane & 7;
+                const bool full = m0 + MI * 32 <= M;      // wave-uniform; the ragged last row panel takes the plain path
+                if (full) {
+                    constexpr int NSEG = MI * NI * 4, LA = 4;
+                    const uint32_t voff = (uint32_t)(((lane >> 3) * p.ldo_f32 + cg * 4) * 4);
+                    float* tile_base = p.out_f32 + (long)m0 * p.ldo_f32 + n0;
+                    auto seg_base = [&](int sg) {
+                        const int b = sg >> 2, ps = sg & 3, j = b / MI, i = b % MI;
+                        return tile_base + (long)(i * 32 + 8 * ps) * p.ldo_f32 + j * 32;
+                    };
+                    f32x4 ring[LA];
+#pragma unroll
+                    for (int sg = 0; sg < LA; ++sg)
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ring[sg]) : "v"(voff), "s"(seg_base(sg)) : "memory");
+#pragma unroll
+                    for (int sg = 0; sg < NSEG; ++sg) {
+                        const int b = sg >> 2, ps = sg & 3, j = b / MI, i = b % MI;
+                        if (ps == 0) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) st[acc_row(r, lh) * 32 + lr] = acc[i][j][r];
+                        }
+                        // operations younger than this segment's load: the later loads issued so far + the stores since
+                        const int younger = ((sg + LA - 1 < NSEG - 1 ? sg + LA - 1 : NSEG - 1) - sg) + (sg < LA ? sg : LA);
+                        f32x4& cur = ring[sg % LA];
+#define DSEG_WAIT_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(cur)::"memory"); break;
+                        switch (younger) {      // compile-time after unrolling
+                            DSEG_WAIT_VM(0) DSEG_WAIT_VM(1) DSEG_WAIT_VM(2) DSEG_WAIT_VM(3) DSEG_WAIT_VM(4) DSEG_WAIT_VM(5)
+                            DSEG_WAIT_VM(6) DSEG_WAIT_VM(7) DSEG_WAIT_VM(8) DSEG_WAIT_VM(9) DSEG_WAIT_VM(10) DSEG_WAIT_VM(11)
+                            DSEG_WAIT_VM(12) DSEG_WAIT_VM(13) DSEG_WAIT_VM(14) DSEG_WAIT_VM(15)
+                        }
+#undef DSEG_WAIT_VM
+                        static_assert(2 * LA - 1 <= 15, "extend the vmcnt ladder");
+                        const int row = (lane >> 3) + 8 * ps;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 4) + cur;
+                        if (sg + LA < NSEG)
+                            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ring[sg % LA]) : "v"(voff), "s"(seg_base(sg + LA)) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(seg_base(sg)) : "memory");
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < MI * NI; ++b) {
+                        const int j = b / MI, i = b % MI;
+                        const int gn = n0 + j * 32 + cg * 4;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st[acc_row(r, lh) * 32 + lr] = acc[i][j][r];
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const int row = (lane >> 3) + 8 * ps;
+                            const int gm = m0 + i * 32 + row;
+                            if (gm < M) {
+                                float* dst = p.out_f32 + (long)gm * p.ldo_f32 + gn;
+                                *reinterpret_cast<f32x4*>(dst) =
+                                    *reinterpret_cast<const f32x4*>(dst) + *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 4);
+                            }
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the uncounted bias loads above
+                }
+                asm volatile("" : "+v"(bias_next[0]), "+v"(bias_next[1]), "+v"(bias_next[2]));
+                static_assert(NI == 3, "bias anchor names three registers");
+            } else {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int cg = F32_OUT ? (lane & 7) : (lane & 3);
                 const int gn = n0 + j * 32 + cg * (F32_OUT ? 4 : 8);
-                float bb[8];
-#pragma unroll
-                for (int e = 0; e < (F32_OUT ? 4 : 8); ++e) bb[e] = p.bias[gn + e];
                 int which = 0, hcol = 0;
                 bf16_t* qkv_base = nullptr;
                 if (EPI == EPI_QKV) {
@@ -208,31 +299,20 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
 #pragma unroll
                         for (int ps = 0; ps < 4; ++ps) {
                             const int row = (lane >> 3) + 8 * ps;
-                            const int gm = m0 + i * 32 + row;
-                            f32x4 v = *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 4);
-                            v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3];
-                            if (gm < M) {
-                                if (EPI == EPI_PLAIN) {
-                                    *reinterpret_cast<f32x4*>(p.out_f32 + (long)gm * p.ldo_f32 + gn) = v;
-                                } else if (EPI == EPI_RESID) {
-                                    float* dst = p.out_f32 + (long)gm * p.ldo_f32 + gn;
-                                    *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + v;
-                                } else {
-                                    const int bq = gm / p.n_patches, tok = gm - bq * p.n_patches;
-                                    const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (long)(1 + tok) * p.ldo_f32 + gn);
-                                    *reinterpret_cast<f32x4*>(p.out_f32 + ((long)gm + bq + 1) * p.ldo_f32 + gn) = v + pe;
-                                }
-                            }
+                            int gm = m0 + i * 32 + row;
+                            gm = gm < M ? gm : M - 1;
+                            *reinterpret_cast<f32x4*>(p.out_f32 + (long)gm * p.ldo_f32 + gn) =
+                                *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 4);
                         }
                     } else {
 #pragma unroll
                         for (int ps = 0; ps < 2; ++ps) {
                             const int row = (lane >> 2) + 16 * ps;
-                            const int gm = m0 + i * 32 + row;
+                            int gm = m0 + i * 32 + row;
+                            gm = gm < M ? gm : M - 1;
                             const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 8);
                             const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 8 + 4);
-                            float v[8] = {v0[0] + bb[0], v0[1] + bb[1], v0[2] + bb[2], v0[3] + bb[3],
-                                          v1[0] + bb[4], v1[1] + bb[5], v1[2] + bb[6], v1[3] + bb[7]};
+                            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 if (EPI == EPI_GELU) v[e] = gelu_fast(v[e]);     // bf16 fast mode only (planes == 1)
@@ -241,21 +321,22 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
                             }
                             const uint4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
                                              pack_bf16x2(v[6], v[7])};
-                            if (gm < M) {
-                                if (EPI == EPI_QKV) {
-                                    const int bq = gm / p.ntok, tok = gm - bq * p.ntok;
-                                    *reinterpret_cast<uint4*>(qkv_base + ((long)(bq * p.heads + (hcol >> 6)) * p.npad + tok) * 64 +
-                                                              (hcol & 63)) = o;
-                                } else {
-                                    *reinterpret_cast<uint4*>(p.out_bf16 + (long)gm * p.ldo + gn) = o;
-                                }
+                            if (EPI == EPI_QKV) {
+                                const int bq = gm / p.ntok, tok = gm - bq * p.ntok;
+                                *reinterpret_cast<uint4*>(qkv_base + ((long)(bq * p.heads + (hcol >> 6)) * p.npad + tok) * 64 +
+                                                          (hcol & 63)) = o;
+                            } else {
+                                *reinterpret_cast<uint4*>(p.out_bf16 + (long)gm * p.ldo + gn) = o;
                             }
                         }
                     }
                 }
             }
             }
-            zero_acc();
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bias_col[j] = bias_next[j];
+            init_acc();
         }
     }
 }
@@ -284,9 +365,6 @@ static int launch_big_cfg(const GemmParams& p, hipStream_t s) {
 
 template <int EPI>
 static int launch_big_one(const GemmParams& p, hipStream_t s) {
-    const int variant = options().gemm_big;     // 1: 256x384, 2: 128x128 x3/CU, 3: 128x192 x4/CU
-    if (variant == 2 && p.N % big::Cfg128x128::BN == 0) return launch_big_cfg<EPI, big::Cfg128x128>(p, s);
-    if (variant == 3 && p.N % big::Cfg128x192::BN == 0) return launch_big_cfg<EPI, big::Cfg128x192>(p, s);
     return launch_big_cfg<EPI, big::Cfg256x384>(p, s);
 }
 

@@ -264,13 +264,13 @@ def test_head_final(cuda, C, K, ld):
 
 def test_gemm_big_matches_small_kernel(cuda):
     """Same operands through both GEMM kernels (dinoseg_set_option('gemm_big', 0/1)): identical up to fp32 summation order."""
-    M, N, K = 3000, 1152, 384
+    M, N, K = 3000, 1152, 384         # 11.7 row panels of 256: the last one is ragged (plain residual path)
     A, W, bias = seeded((M, K), 31), seeded((N, K), 32) * 0.1, seeded((N,), 33)
     Ap, Wp = pack(A, 1), pack(W, 1)
     lib = capi.lib()
     outs = []
     X0 = seeded((M, N), 34)
-    for big in (0, 1, 2, 3):          # 0: 128x128 kernel; 1: auto (256x384 persistent here); 2/3: persistent 128x128 / 128x192 x3/CU
+    for big in (0, 1, 2):          # 0: 128x128 kernel; 1: auto (256x384 persistent here); 2: persistent kernel wherever it applies
         capi.check(lib.dinoseg_set_option(b"gemm_big", big))
         out = torch.zeros((M, N), device="cuda")
         capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, 1, capi.EPI_PLAIN,
@@ -284,7 +284,7 @@ def test_gemm_big_matches_small_kernel(cuda):
         outs.append((out, X, unpack(g)))
     capi.check(lib.dinoseg_set_option(b"gemm_big", 1))
     scale = float(outs[0][0].abs().max())
-    for big in (1, 2, 3):
+    for big in (1, 2):
         assert float((outs[0][0] - outs[big][0]).abs().max()) <= 2e-5 * scale, big
         assert float((outs[0][1] - outs[big][1]).abs().max()) <= 2e-5 * scale, big
         assert float((outs[0][2] - outs[big][2]).abs().max()) <= 2.0 ** -7 * float(outs[0][2].abs().max()), big
