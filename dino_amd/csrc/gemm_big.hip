@@ -81,38 +81,46 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
         bn = q % nbn;
     };
 
-    auto issue_range = [&](int step, int i0, int i1) {
-        const int ti = step / nk, kt = step - ti * nk;
-        int bm, bn;
-        tile_of(ti, bm, bn);
-        char* sbase = smem + (step % STAGES) * STAGE_BYTES;
+    // ---- LDS-DMA issue stream: runs STAGES-1 slabs ahead of the multiply stream, across tile boundaries.
+    // Per-lane source offsets are set up once per tile (row clamp, row x stride); a k-step then costs one scalar base
+    // update and PIECES_PER_WAVE loads.  (The first version recomputed the tile coordinates, the clamp and a 64-bit row
+    // product for every piece of every k-step: ~150 scalar / vector instructions ahead of each step's first MFMA.)
+    uint32_t voff[PIECES_PER_WAVE];         // byte offset of this lane's 16 bytes inside A (A pieces) / the W column block
+    int is_ti = 0, is_kt = 0, is_slot = 0;
+    const char* is_wbase = nullptr;
+    auto setup_issue_tile = [&](int ti_i) {
+        int bm_i, bn_i;
+        tile_of(ti_i, bm_i, bn_i);
+        is_wbase = reinterpret_cast<const char*>(p.W + (long)(p.n_off + bn_i * BN) * K);
         const int prow = lane >> 2;                         // row inside a 16-row piece
 #pragma unroll
-        for (int i = i0; i < i1; ++i) {
+        for (int i = 0; i < PIECES_PER_WAVE; ++i) {
             const int piece = wave * PIECES_PER_WAVE + i;   // first A_PIECES pieces: A rows, then W rows
-            const bf16_t* src;
-            if (piece < C::A_PIECES) {
-                const int row = piece * 16 + prow;
-                const int c = (lane & 3) ^ ((row >> 2) & 3);
-                int gm = bm * BM + row;
-                gm = gm < M ? gm : M - 1;
-                src = p.A + (long)gm * p.lda + kt * BK + c * 8;
-            } else {
-                const int row = (piece - C::A_PIECES) * 16 + prow;
-                const int c = (lane & 3) ^ ((row >> 2) & 3);
-                src = p.W + (long)(p.n_off + bn * BN + row) * K + kt * BK + c * 8;
-            }
-            glds16(src, sbase + piece * 1024);
+            const bool is_a = piece < C::A_PIECES;          // wave-uniform
+            const int row = (is_a ? piece : piece - C::A_PIECES) * 16 + prow;
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            int gm = bm_i * BM + row;
+            gm = gm < M ? gm : M - 1;
+            voff[i] = (uint32_t)(((is_a ? gm * p.lda : row * K) + c * 8) * 2);
         }
     };
-    auto issue = [&](int step) { issue_range(step, 0, PIECES_PER_WAVE); };
+    auto issue_next = [&]() {
+        char* sbase = smem + is_slot * STAGE_BYTES;
+        const char* abase = reinterpret_cast<const char*>(p.A) + is_kt * (BK * 2);
+        const char* wbase = is_wbase + is_kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < PIECES_PER_WAVE; ++i) {
+            const int piece = wave * PIECES_PER_WAVE + i;
+            glds16((piece < C::A_PIECES ? abase : wbase) + voff[i], sbase + piece * 1024);
+        }
+        if (++is_kt == nk) {
+            is_kt = 0;
+            if (++is_ti < my_tiles) setup_issue_tile(is_ti);
+        }
+        is_slot = is_slot + 1 == STAGES ? 0 : is_slot + 1;
+    };
+    setup_issue_tile(0);
 
-    if (p.stagger > 0 && (local & 1)) {
-        // all persistent workgroups run the same program on equal work and stay in phase: the whole chip stores its
-        // epilogues at once (HBM burst) and then loads nothing while it multiplies.  Starting every other workgroup half
-        // a tile late spreads the store bursts under the other half's main loops.
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     f32x16 acc[MI][NI];
     // The bias is the accumulators' initial value (lane = column: one float per 32-column block), so the epilogue has no
     // bias registers and no bias adds.  The next tile's values are fetched at the top of the epilogue, before its stores.
@@ -140,9 +148,9 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
     // ---- prologue: fill STAGES-1 ring slots
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
-        if (s < total_steps) issue(s);
+        if (s < total_steps) issue_next();
 
-    int kt = 0, ti = 0;
+    int kt = 0, ti = 0, cs_slot = 0;
     for (int step = 0; step < total_steps; ++step) {
         // slab `step` was issued STAGES-1 steps ago; allow the younger ones to stay in flight
         const int ahead = total_steps - 1 - step;           // slabs issued after this one (capped below)
@@ -154,18 +162,11 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();   // everyone's pieces of this slab landed; everyone finished reading slot (step-1)%S
-        const bool do_issue = step + STAGES - 1 < total_steps && !(p.dbg & 2);
-        const bool spread = (p.dbg & 4) != 0;      // experiment: LDS-DMA pieces spread through the slab's MFMAs instead of a burst
-        constexpr int H1 = (PIECES_PER_WAVE + 1) / 2;
-        if (do_issue) {
-            if (spread) issue_range(step + STAGES - 1, 0, H1);
-            else issue(step + STAGES - 1);
-        }
+        if (step + STAGES - 1 < total_steps && !(p.dbg & 2)) issue_next();
 
-        const char* sa = smem + (step % STAGES) * STAGE_BYTES;
+        const char* sa = smem + cs_slot * STAGE_BYTES;
         const char* sw = sa + A_BYTES;
-        int bm, bn;
-        tile_of(ti, bm, bn);
+        cs_slot = cs_slot + 1 == STAGES ? 0 : cs_slot + 1;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 af[MI], wf[NI];
@@ -177,11 +178,6 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);   // lane: column n, registers: rows m
-            if (kk == 0 && spread) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (do_issue) issue_range(step + STAGES - 1, H1, PIECES_PER_WAVE);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -197,6 +193,8 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
             // trips per wave and tile: that was most of the "epilogue costs as much as the main loop" of the first version).
             // So: no global loads besides the next tile's bias at the top, rows clamped instead of guarded (rows >= M of the
             // last panel are copies of row M-1 -- the loader clamps the same way -- so their stores rewrite identical bytes).
+            int bm, bn;
+            tile_of(ti, bm, bn);
             kt = 0;
             ++ti;
             const int m0 = bm * BM + wr * MI * 32, n0 = p.n_off + bn * BN + wc * NI * 32;
@@ -371,6 +369,8 @@ static int launch_big_one(const GemmParams& p, hipStream_t s) {
 bool gemm_big_supported(const GemmParams& p) {
     return p.planes == 1 && p.bias != nullptr && p.epi <= EPI_QKV && p.resid == nullptr && p.aux_out == nullptr &&
            p.ksplit <= 1 && p.N % big::Cfg256x384::BN == 0 && p.K % big::BK == 0 && p.lda % 8 == 0 && p.M >= 1 &&
+           (long)p.M * p.lda * 2 < (1L << 32) && (long)big::Cfg256x384::BN * p.K * 2 < (1L << 32) &&     // 32-bit lane offsets
+
            (p.epi != EPI_QKV || (p.dmodel % big::Cfg256x384::BN == 0 && p.N == 3 * p.dmodel));
 }
 
