@@ -162,7 +162,12 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();   // everyone's pieces of this slab landed; everyone finished reading slot (step-1)%S
-        if (step + STAGES - 1 < total_steps && !(p.dbg & 2)) issue_next();
+        // the two waves of a SIMD (w and w+4) would issue their DMA pieces at the same moment and leave the matrix pipe idle
+        // meanwhile (an LDS-DMA piece holds the wave's issue for 60-185 cycles): waves 0-3 issue before the first half of
+        // the slab's MFMAs, waves 4-7 between the halves (the target slot is free from the barrier on either way)
+        const bool do_issue = step + STAGES - 1 < total_steps && !(p.dbg & 2);
+        const bool issue_late = (p.dbg & 4) ? false : wave >= C::NWAVES / 2;
+        if (do_issue && !issue_late) issue_next();
 
         const char* sa = smem + cs_slot * STAGE_BYTES;
         const char* sw = sa + A_BYTES;
@@ -178,6 +183,11 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);   // lane: column n, registers: rows m
+            if (kk == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (do_issue && issue_late) issue_next();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
