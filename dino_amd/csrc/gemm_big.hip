@@ -39,7 +39,9 @@ struct Cfg {
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES + NWAVES * 4096;   // ring + one 32x32 fp32 patch per wave
 };
 using Cfg256x384 = Cfg<2, 4, 4, 3, 3, 1>;   // 120 KiB ring + 32 KiB epilogue patches, 1 workgroup / CU, 154 FLOP per staged byte
-// (Cfg<2,2,2,2,2,3> = 128x128 and Cfg<2,2,2,3,2,3> = 128x192 with 3 workgroups per CU were measured: 15-25 % slower)
+// (Cfg<2,2,2,2,2,3> = 128x128 and Cfg<2,2,2,3,2,3> = 128x192 with 3 workgroups per CU were measured: 15-25 % slower;
+//  Cfg<1,4,4,3,2,2> = 128x384 with 2 workgroups per CU: 2-28 % slower -- the two workgroups stay in phase, main loop and
+//  epilogue times simply add up as with one)
 
 // 64-byte rows (4 chunks of 16 B): XOR the chunk with (row>>2)&3 -> the 16 rows of a ds_read_b128 lane group
 // fall on 16 distinct 16-byte slots of the 256-byte bank row.
@@ -391,7 +393,6 @@ int launch_gemm_big(const GemmParams& p, hipStream_t s) {
         case EPI_GELU: return launch_big_one<EPI_GELU>(p, s);
         case EPI_RELU: return launch_big_one<EPI_RELU>(p, s);
         case EPI_QKV: return launch_big_one<EPI_QKV>(p, s);
-        case EPI_PATCH: return launch_big_one<EPI_PATCH>(p, s);
     }
     dinoseg_set_error("gemm_big: bad epilogue %d", p.epi);
     return -1;
