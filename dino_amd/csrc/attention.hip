@@ -75,19 +75,26 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
             qf[pl][s] = __builtin_bit_cast(
                 bf16x8, *reinterpret_cast<const uint4*>(Qg + pl * p.qkv_plane + (long)qrow_c * 64 + s * 16 + lh * 8));
 
+    // K/V tile loader: per-lane byte offsets inside a 64-row slab are fixed for the whole kernel; a tile costs one scalar
+    // base update per slab and no vector address arithmetic
+    constexpr int NPIECE = (16 + NW - 1) / NW;
+    uint32_t soff[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int row = ((wave + i * NW) & 7) * 8 + (lane >> 3);
+        soff[i] = (uint32_t)((row * 64 + swz2(row, lane & 7) * 8) * 2);
+    }
     auto stage = [&](int st, int key0) {
         char* sbase = smem + st * STAGE_BYTES;
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl) {
+            const char* kb = reinterpret_cast<const char*>(Kg + pl * p.qkv_plane + (long)key0 * 64);
+            const char* vb = reinterpret_cast<const char*>(Vg + pl * p.qkv_plane + (long)key0 * 64);
 #pragma unroll
-            for (int i = 0; i < (16 + NW - 1) / NW; ++i) {
+            for (int i = 0; i < NPIECE; ++i) {
                 const int piece = wave + i * NW;              // 0..7: K rows, 8..15: V rows
-                if (16 % NW == 0 || piece < 16) {               // (compile-time true for 4 and 8 waves: straight-line issue)
-                    const int row = (piece & 7) * 8 + (lane >> 3);
-                    const int c = swz2(row, lane & 7);
-                    const bf16_t* src = (piece < 8 ? Kg : Vg) + pl * p.qkv_plane + (long)(key0 + row) * 64 + c * 8;
-                    glds16(src, sbase + pl * 2 * KV_TILE + piece * 1024);
-                }
+                if (16 % NW == 0 || piece < 16)                 // (compile-time true for 4 and 8 waves: straight-line issue)
+                    glds16((piece < 8 ? kb : vb) + soff[i], sbase + pl * 2 * KV_TILE + piece * 1024);
             }
         }
     };
