@@ -461,6 +461,14 @@ extern "C" int dinoseg_last_selfattention(dinoseg_handle* h, const void* x, int3
     return forward_impl(h, x, x_kind, B, r, nullptr, nullptr, -1, nullptr, attn_out, stream);
 }
 
+extern "C" int dinoseg_op_resize_u8(const uint8_t* src, int32_t sh, int32_t sw, uint8_t* dst, int32_t dh, int32_t dw, void* stream) {
+    if (!src || !dst) {
+        dinoseg_set_error("dinoseg_op_resize_u8: null pointer");
+        return -1;
+    }
+    return launch_resize_u8(src, sh, sw, dst, dh, dw, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int dinoseg_op_confusion(const int32_t* pred, const int64_t* gt, int64_t n, int32_t n_classes, int64_t* cm, void* stream) {
     return launch_confusion(pred, gt, n, n_classes, cm, reinterpret_cast<hipStream_t>(stream));
 }

@@ -461,4 +461,65 @@ int launch_confusion(const int32_t* pred, const int64_t* gt, long n, int C, int6
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ uint8 resize
+// Resize(r, r) of get_transforms (pl_torch_modules.py:36) = cv2.resize(..., INTER_LINEAR) on uint8 through albumentations.
+// OpenCV is a third-party dependency that is not in /root/reference (opencv_python==4.5.5.62, requirements.txt:7); this
+// restates its published fixed-point algorithm (modules/imgproc/src/resize.cpp): per axis  f = (float)((d + 0.5) * scale - 0.5),
+// s = floor(f), f -= s;  x axis: f = 0 when s is clamped to [0, w-1];  y axis: rows clamped, f kept;  coefficients
+// round(c * 2048) as int16;  horizontal pass H = S[s] * a0 + S[s+1] * a1 in int32;  vertical pass
+// ((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2.  An exact 2x downscale takes OpenCV's INTER_AREA fast
+// path instead ((s00 + s01 + s10 + s11 + 2) >> 2).  Parity unpinned (no cv2 here): pinned only against oracle/resize_oracle.py.
+__global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, uint8_t* __restrict__ dst,
+                                                        int dh, int dw, double scale_y, double scale_x, int area2) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= dh * dw) return;
+    const int dy = idx / dw, dx = idx - dy * dw;
+    uint8_t* o = dst + (long)idx * 3;
+    if (area2) {
+        const uint8_t* r0 = src + ((long)(2 * dy) * sw + 2 * dx) * 3;
+        const uint8_t* r1 = r0 + (long)sw * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = (uint8_t)((r0[c] + r0[3 + c] + r1[c] + r1[3 + c] + 2) >> 2);
+        return;
+    }
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    auto coef = [](float v) {       // saturate_cast<short>(v * INTER_RESIZE_COEF_SCALE): round half to even, then clamp
+        const int r = (int)rintf(v * 2048.f);
+        return r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+    };
+    const int a0 = coef(1.f - fx), a1 = coef(fx), b0 = coef(1.f - fy), b1 = coef(fy);
+    const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+    const int y0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+    const int y1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+    const uint8_t* r0 = src + (long)y0 * sw * 3;
+    const uint8_t* r1 = src + (long)y1 * sw * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int h0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+        const int h1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+        o[c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+int launch_resize_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, hipStream_t s) {
+    if (sh < 1 || sw < 1 || dh < 1 || dw < 1) {
+        dinoseg_set_error("resize: bad shape %dx%d -> %dx%d", sh, sw, dh, dw);
+        return -1;
+    }
+    const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);      // as cv::resize computes them
+    const int area2 = (sw == 2 * dw && sh == 2 * dh) ? 1 : 0;
+    const long n = (long)dh * dw;
+    hipLaunchKernelGGL(resize_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sh, sw, dst, dh, dw, scale_y,
+                       scale_x, area2);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace dseg

@@ -104,6 +104,7 @@ int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, con
 int launch_attn_probs(const bf16_t* q, const bf16_t* k, long plane, int planes, int B, int heads, int ntok, int npad, float* out,
                       hipStream_t s);
 // cm[gt][pred] += 1 over n patches (int64 [C,C], accumulates)
+int launch_resize_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, hipStream_t s);
 int launch_confusion(const int32_t* pred, const int64_t* gt, long n, int C, int64_t* cm, hipStream_t s);
 
 // ---- fine-tune step (train.hip, attention_bwd.hip) ----

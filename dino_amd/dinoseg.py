@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from . import capi
+from .preprocess import resize_linear_u8
 from .weights import VIT_B8, VIT_S8, ViTConfig
 
 _IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -29,8 +30,9 @@ class _Transforms:
     (pl_torch_modules.py:33-41): ``t(image=ndarray)['image']`` -> fp32 CHW tensor.
 
     Resize(res, res) is the identity for frames already at res x res (the benchmark / golden case);
-    other sizes use a half-pixel-centre bilinear resample on uint8 (cv2.INTER_LINEAR convention,
-    not bit-pinned: albumentations/OpenCV are not available here -- see DESIGN.md).
+    other sizes go through cv2.INTER_LINEAR's fixed-point arithmetic restated in dino_amd/preprocess.py
+    (parity unpinned: albumentations / OpenCV are not available here -- see DESIGN.md).  ``predict`` does the same
+    arithmetic on the GPU (``dinoseg_op_resize_u8``) and never calls this host path.
     """
 
     def __init__(self, resolution: int):
@@ -42,19 +44,7 @@ class _Transforms:
             raise ValueError(f"expected an HxWx3 image, got {img.shape}")
         if img.shape[0] == r and img.shape[1] == r:
             return np.ascontiguousarray(img, dtype=np.uint8)
-        h, w = img.shape[:2]
-        ys = (np.arange(r, dtype=np.float64) + 0.5) * (h / r) - 0.5
-        xs = (np.arange(r, dtype=np.float64) + 0.5) * (w / r) - 0.5
-        y0 = np.floor(ys).astype(np.int64)
-        x0 = np.floor(xs).astype(np.int64)
-        fy = (ys - y0)[:, None, None]
-        fx = (xs - x0)[None, :, None]
-        y0c, y1c = np.clip(y0, 0, h - 1), np.clip(y0 + 1, 0, h - 1)
-        x0c, x1c = np.clip(x0, 0, w - 1), np.clip(x0 + 1, 0, w - 1)
-        f = img.astype(np.float64)
-        top = f[y0c][:, x0c] * (1 - fx) + f[y0c][:, x1c] * fx
-        bot = f[y1c][:, x0c] * (1 - fx) + f[y1c][:, x1c] * fx
-        return np.clip(np.rint(top * (1 - fy) + bot * fy), 0, 255).astype(np.uint8)
+        return resize_linear_u8(img, r, r)
 
     def __call__(self, image: np.ndarray) -> Dict[str, torch.Tensor]:
         u8 = self.resize(np.asarray(image))
@@ -317,8 +307,17 @@ class DINOSeg(nn.Module):
         reference returns: np.kron of the (r/8)x(r/8) argmax map with a (480//(r/8))^2 block of ones
         (pl_torch_modules.py:276-300, including the non-480 sizes it yields when 480 % (r/8) != 0)."""
         with torch.no_grad():
-            u8 = self.transforms.resize(np.array(x))
-            frames = torch.from_numpy(u8).unsqueeze(0).to(self.device)
+            raw = np.ascontiguousarray(np.array(x), dtype=np.uint8)
+            if raw.ndim != 3 or raw.shape[2] != 3:
+                raise ValueError(f"expected an HxWx3 image, got {raw.shape}")
+            r = self.resolution
+            frames = torch.from_numpy(raw).unsqueeze(0).to(self.device)          # uint8 on the wire, whatever its size
+            if raw.shape[0] != r or raw.shape[1] != r:                           # Resize(r, r) of get_transforms, on the GPU
+                self._require_gpu()
+                resized = torch.empty((1, r, r, 3), dtype=torch.uint8, device=self.device)
+                capi.check(capi.lib().dinoseg_op_resize_u8(frames.data_ptr(), raw.shape[0], raw.shape[1], resized.data_ptr(), r, r,
+                                                          capi.stream_ptr()))
+                frames = resized
             _, amax = self.forward_frames(frames, want_logp=False)
             output_size = self.resolution // 8
             low_res = amax.cpu().numpy().astype(np.int64).reshape((output_size, output_size))

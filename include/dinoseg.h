@@ -85,6 +85,12 @@ int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B,
 int dinoseg_last_selfattention(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* attn_out,
                                void* stream);
 
+/* Replaces the Resize(r, r) of get_transforms (pl_torch_modules.py:36-38, applied in predict at :291) for frames that are
+ * not already r x r: uint8 HWC [sh, sw, 3] -> [dh, dw, 3] on device, restating cv2.resize(INTER_LINEAR)'s fixed-point
+ * arithmetic (albumentations 1.1.0 -> opencv 4.5.5, third-party: parity unpinned) so that predict() keeps
+ * the frame on the wire as uint8 and resizes it ahead of the patch-embedding gather. */
+int dinoseg_op_resize_u8(const uint8_t* src, int32_t sh, int32_t sw, uint8_t* dst, int32_t dh, int32_t dw, void* stream);
+
 /* Confusion matrix for the validation metrics (validation_epoch_end, pl_torch_modules.py:310-332):
  * cm[gt][pred] += 1 over n patches; cm int64 [n_classes, n_classes] on device (zero it first). */
 int dinoseg_op_confusion(const int32_t* pred, const int64_t* gt, int64_t n, int32_t n_classes, int64_t* cm, void* stream);

@@ -118,3 +118,20 @@ def test_checkpoint_with_unimportable_hyperparameters(tmp_path):
     del sys.modules["comet_like_pkg"]
     m = DINOSeg.load_from_checkpoint(path)
     assert m.n_blocks == 1 and m.comet_logger is None and m.optimizer is torch.optim.AdamW
+
+
+def test_resize_mirror_matches_scalar_restatement():
+    """dino_amd.preprocess (host mirror of cv2.INTER_LINEAR on uint8) against the pixel-at-a-time restatement in oracle/:
+    upscale, downscale, the exact-2x INTER_AREA switch, 1-pixel sources and a known 2x ramp (taps 0.25 / 0.75)."""
+    from dino_amd.preprocess import resize_linear_u8
+    from oracle.resize_oracle import resize_linear_u8 as ref
+    rng = np.random.default_rng(0)
+    for sh, sw, dh, dw in [(5, 7, 8, 8), (12, 16, 8, 8), (16, 16, 8, 8), (3, 3, 16, 16), (1, 1, 4, 4), (48, 64, 40, 40), (9, 4, 16, 24)]:
+        img = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        assert np.array_equal(resize_linear_u8(img, dh, dw), ref(img, dh, dw)), (sh, sw, dh, dw)
+    ramp = np.tile(np.array([0, 16, 32, 48], dtype=np.uint8)[None, :, None], (2, 1, 3))
+    assert resize_linear_u8(ramp, 2, 8)[0, :, 0].tolist() == [0, 4, 12, 20, 28, 36, 44, 48]
+    const = np.full((10, 13, 3), 200, np.uint8)
+    assert np.unique(resize_linear_u8(const, 16, 16)).tolist() == [200]
+    same = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    assert resize_linear_u8(same, 8, 8) is not None and np.array_equal(resize_linear_u8(same, 8, 8), same)

@@ -106,6 +106,21 @@ def test_g5_predict_maps(cuda, golden_dir):
         m.set_resolution(250)
 
 
+def test_predict_resizes_non_square_frames_on_device(cuda):
+    """predict() on a 640x480 robot frame (docs/img/frame.jpg's shape) and on a 960x960 frame (exact-2x path): the
+    device resize + forward equals the forward on the host-resized frame (dino_amd.preprocess, same arithmetic)."""
+    from dino_amd.preprocess import resize_linear_u8
+    m, _, _ = build(1, "bf16x3")
+    m.set_resolution(240)
+    for sh, sw in ((480, 640), (960, 960), (100, 77)):
+        frame = np.random.default_rng(sh + sw).integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        pred = m.predict(frame)
+        ref = m.predict(resize_linear_u8(frame, 240, 240))
+        assert pred.shape == (480, 480) and np.array_equal(pred, ref), (sh, sw)
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((10, 10), dtype=np.uint8))
+
+
 def test_g9_against_reference_dinoseg_outputs(cuda, golden_dir):
     g = load(golden_dir, "g9_reference_dinoseg")
     for L in (1, 3):

@@ -288,3 +288,21 @@ def test_gemm_big_matches_small_kernel(cuda):
         assert float((outs[0][0] - outs[big][0]).abs().max()) <= 2e-5 * scale, big
         assert float((outs[0][1] - outs[big][1]).abs().max()) <= 2e-5 * scale, big
         assert float((outs[0][2] - outs[big][2]).abs().max()) <= 2.0 ** -7 * float(outs[0][2].abs().max()), big
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sh,sw,dh,dw", [(48, 64, 40, 40), (30, 30, 64, 64), (64, 64, 32, 32), (1, 1, 8, 8), (37, 91, 24, 56),
+                                         (480, 640, 480, 480)])
+def test_resize_u8(cuda, sh, sw, dh, dw):
+    """dinoseg_op_resize_u8 (cv2.INTER_LINEAR fixed-point restatement) is bit-exact against the scalar oracle (small cases)
+    and the host mirror (the 640x480 robot-frame case, too slow for the pixel-at-a-time oracle)."""
+    from dino_amd.preprocess import resize_linear_u8
+    from oracle.resize_oracle import resize_linear_u8 as ref
+    img = np.random.default_rng(sh * 1000 + sw).integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+    src = torch.from_numpy(img).cuda()
+    dst = torch.zeros((dh, dw, 3), dtype=torch.uint8, device="cuda")
+    capi.check(capi.lib().dinoseg_op_resize_u8(src.data_ptr(), sh, sw, dst.data_ptr(), dh, dw, S()))
+    got = dst.cpu().numpy()
+    assert np.array_equal(got, resize_linear_u8(img, dh, dw))
+    if sh * sw <= 64 * 64 and dh * dw <= 64 * 64:
+        assert np.array_equal(got, ref(img, dh, dw))
