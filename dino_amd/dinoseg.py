@@ -453,6 +453,57 @@ class DINOSeg(nn.Module):
                                              capi.stream_ptr()))
         self._bound_sig = None      # weights changed: re-pack on the next forward / training_step
 
+    def fit(self, ck_file_name=None, train_dataloader=None, val_dataloader=None, test_dataloader=None, max_epochs=None):
+        """The reference's ``fit`` (pl_torch_modules.py:367-431) without Lightning: freeze / unfreeze the backbone, train
+        ``max_epochs`` epochs with ``training_step`` + the fused optimizer step, validate after every epoch
+        (``check_val_every_n_epoch=1``), keep the checkpoint with the best ``val_acc`` (``ModelCheckpoint(monitor='val_acc',
+        mode='max')``) at ``write_path/<ck_file_name>.ckpt`` in the PL-1.5 schema, then run the test split and set
+        ``self.best_ck``.  The dataset / augmentation pipeline is out of scope, so the dataloaders are
+        arguments: any iterables of ``(x, y)`` batches with x uint8 [B,r,r,3] or fp32 [B,3,r,r] and y int [B,(r/8)^2].
+        Returns {'history': [per-epoch metrics], 'test': test metrics or None}."""
+        import os
+
+        from .ckpt import save_checkpoint
+        if train_dataloader is None or val_dataloader is None:
+            raise ValueError("fit() needs train_dataloader and val_dataloader (the DuckieSegDataset pipeline is not part of dino_amd)")
+        if self.freeze_backbone:
+            self.freeze_bb()
+        else:
+            self.unfreeze_bb()
+        if ck_file_name is None:        # same naming rule as the reference
+            ck_file_name = (str(self.n_blocks) + "_" + self.head + ("_frozen" if self.freeze_backbone else "_finetuned") +
+                            ("_grayscale" if self.grayscale else ""))
+        out_dir = self.write_path if self.write_path is not None else "."
+        os.makedirs(out_dir, exist_ok=True)
+        ck_path = os.path.join(out_dir, ck_file_name + ".ckpt")
+        best, history, step = -1.0, [], 0
+        for epoch in range(self.max_epochs if max_epochs is None else max_epochs):
+            cms, losses = [], []
+            for bi, (x, y) in enumerate(train_dataloader):
+                out = self.training_step((x, y), bi)
+                self.fused_adam_step()
+                losses.append(out["loss"])
+                cm = torch.zeros((self.cfg.n_classes, self.cfg.n_classes), dtype=torch.int64, device=self.device)
+                capi.check(capi.lib().dinoseg_op_confusion(out["pred"].to(torch.int32).contiguous().data_ptr(), out["gt"].data_ptr(),
+                                                           out["gt"].numel(), self.cfg.n_classes, cm.data_ptr(), capi.stream_ptr()))
+                cms.append({"confusion": cm})
+                step += 1
+            metrics = self.validation_epoch_end(cms, prefix="train") if cms else {}
+            metrics["train_loss"] = float(torch.stack(losses).mean()) if losses else float("nan")
+            metrics.update(self.validation_epoch_end([self.validation_step(b, i) for i, b in enumerate(val_dataloader)]))
+            metrics["epoch"] = epoch
+            history.append(metrics)
+            if metrics["val_acc"] > best:
+                best = metrics["val_acc"]
+                save_checkpoint(self, ck_path, epoch=epoch, global_step=step)
+        self.best_ck = ck_path if history else None
+        test = None
+        if test_dataloader is not None:
+            test = self.test_epoch_end([self.test_step(b, i) for i, b in enumerate(test_dataloader)])
+        if self.comet_logger is not None and self.best_ck is not None:
+            self.comet_logger.experiment.log_asset(self.best_ck)
+        return {"history": history, "test": test}
+
     def freeze_bb(self):
         for p in self.dino.parameters():
             p.requires_grad = False

@@ -188,3 +188,31 @@ def test_train_step_linear_head_vs_oracle_autograd(cuda):
     for k, p in m.named_parameters():
         gn = float(W[k].grad.norm())
         assert float((p.grad.cpu() - W[k].grad).abs().max()) <= 3e-3 * gn + 1e-7, k
+
+
+def test_fit_loop_keeps_best_checkpoint(cuda, tmp_path):
+    """fit(): the reference's control flow (pl_torch_modules.py:367-431) on synthetic loaders -- the loss falls, the best
+    val_acc checkpoint is written in the PL schema under the reference's file-name rule and reloads to the same maps."""
+    cfg = ViTConfig(embed_dim=128, num_heads=2, n_blocks=1, n_classes=7, head="mlp")
+    m = DINOSeg(arch=cfg, head="mlp", n_blocks=1, n_classes=7, lr=1e-3, optimizer=torch.optim.Adam, freeze_backbone=False,
+                max_epochs=3, write_path=str(tmp_path), precision="bf16x3").to("cuda")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in procedural_state_dict(cfg).items()})
+    m.set_resolution(64)
+    frames = torch.from_numpy(synthetic_frames(6, 64, seed=3))
+    # learnable labels: the class of a patch is a function of its mean intensity
+    lab = (frames.float().reshape(6, 8, 8, 8, 8, 3).mean(dim=(2, 4, 5)) // 37).long().reshape(6, 64)
+    train = [(frames[0:2], lab[0:2]), (frames[2:4], lab[2:4])]
+    val = [(frames[4:6], lab[4:6])]
+    out = m.fit(train_dataloader=train, val_dataloader=val, test_dataloader=val)
+    hist = out["history"]
+    assert len(hist) == 3 and hist[-1]["train_loss"] < hist[0]["train_loss"]
+    assert {"val_acc", "val_iou", "val_F1", "train_acc", "epoch"} <= set(hist[0]) and set(out["test"]) == {"test_acc", "test_iou", "test_F1"}
+    assert m.best_ck == os.path.join(str(tmp_path), "1_mlp_finetuned.ckpt") and os.path.exists(m.best_ck)
+    m2 = DINOSeg.load_from_checkpoint(m.best_ck, arch=cfg, precision="bf16x3").to("cuda")
+    assert m2.n_blocks == 1 and m2.head == "mlp" and not m2.freeze_backbone
+    best_epoch = max(range(3), key=lambda e: (hist[e]["val_acc"], -e))
+    if best_epoch == 2:     # the saved weights are the final ones: same prediction maps
+        m2.set_resolution(64)
+        assert np.array_equal(m2.predict(frames[4].numpy()), m.predict(frames[4].numpy()))
+    with pytest.raises(ValueError):
+        m.fit()
