@@ -20,6 +20,8 @@
 // 16 v_cvt_pk.
 //
 // PLANES = 2 (parity mode): Q, K, V and P are bf16 hi+lo pairs; each product is 3 MFMAs.
+#include <type_traits>
+
 #include "attn_common.h"
 #include "kernels.h"
 
@@ -75,6 +77,14 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
             qf[pl][s] = __builtin_bit_cast(
                 bf16x8, *reinterpret_cast<const uint4*>(Qg + pl * p.qkv_plane + (long)qrow_c * 64 + s * 16 + lh * 8));
 
+    // the compiler must not carry "Q loads pending" into the tile loop: with the loader's uncounted LDS-DMA in flight its
+    // own vmcnt waits there would drain the prefetch every tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[pl][s]));
+
     // K/V tile loader: per-lane byte offsets inside a 64-row slab are fixed for the whole kernel; a tile costs one scalar
     // base update per slab and no vector address arithmetic
     constexpr int NPIECE = (16 + NW - 1) / NW;
@@ -93,8 +103,17 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) {
                 const int piece = wave + i * NW;              // 0..7: K rows, 8..15: V rows
-                if (16 % NW == 0 || piece < 16)                 // (compile-time true for 4 and 8 waves: straight-line issue)
-                    glds16((piece < 8 ? kb : vb) + soff[i], sbase + pl * 2 * KV_TILE + piece * 1024);
+                if (16 % NW == 0 || piece < 16) {               // (compile-time true for 4 and 8 waves: straight-line issue)
+                    // LDS-DMA with a scalar base and a 32-bit lane offset (the builtin form keeps a 64-bit address per lane
+                    // and piece and adds the tile offset to each on the vector port, which is the port this loop is bound by).
+                    // M0 = LDS destination of the wave; saved and restored around the statement (compiler-reserved).
+                    const uint32_t lds_dst = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)(sbase + pl * 2 * KV_TILE + piece * 1024);
+                    uint32_t keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(soff[i]), "s"(piece < 8 ? kb : vb), "s"(lds_dst)
+                                 : "memory");
+                }
             }
         }
     };
@@ -126,13 +145,26 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
     // 4p..4p+3 of a 4-key x 16-d block and receives column (lane&15) of the 4 keys.  Group g = lane>>4 covers
     // d = 16*(g&1) + 0..15 of the 32-d block and keys 8*(g>>1) + 0..3 (second read: +4) of the 16-key step.
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_gl = (lane >> 4) & 1;
+    // LDS addresses: 4 + 4 per-lane byte offsets; half (kb), key step (ks), plane and ring slot are immediates
+    // (the swizzle ignores row bits 4 and 5, so +32 rows = +4096 B and +16 rows = +2048 B exactly)
+    int ka[4], va[2][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ka[s] = tile_off2(krow_perm, s * 2 + lh);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            va[db][h] = KV_TILE + tile_off2(lh * 8 + tr_q + 4 * h, db * 4 + tr_gl * 2 + (tr_p >> 1)) + (tr_p & 1) * 8;
 
-    for (int t = 0; t < ntiles; ++t) {
+    // one K/V tile; SLOT = t & 1 is a compile-time constant (two tiles per loop trip) so that every LDS address of the body
+    // is a loop-invariant register plus an immediate
+    auto tile = [&](int t, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t landed (this wave's pieces)
         __builtin_amdgcn_s_barrier();      // everyone's pieces of tile t landed; everyone is done reading slot (t-1)&1
-        if (t + 1 < ntiles && !(dbg & 2)) stage((t + 1) & 1, (t + 1) * KB);
-        if ((VAR & 2) && !wave_active) continue;
-        const char* sb = smem + (t & 1) * STAGE_BYTES;
+        if (t + 1 < ntiles && !(dbg & 2)) stage(SLOT ^ 1, (t + 1) * KB);
+        if ((VAR & 2) && !wave_active) return;
+        const char* sb = smem + SLOT * STAGE_BYTES;
 
         // ---- S'^T[key][q] = K . Q^T - m_run: the tile's 8 K fragments are read up front (one LDS latency per tile) ----
         f32x16 sacc[2];
@@ -142,9 +174,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    const int off = tile_off2(kb * 32 + krow_perm, s * 2 + lh);
-                    kf[0][kb][s] = lds_frag(sb + off);
-                    if (PLANES == 2) kf[PLANES - 1][kb][s] = lds_frag(sb + 2 * KV_TILE + off);
+                    kf[0][kb][s] = lds_frag(sb + ka[s] + kb * 4096);
+                    if (PLANES == 2) kf[PLANES - 1][kb][s] = lds_frag(sb + ka[s] + kb * 4096 + 2 * KV_TILE);
                 }
             sacc[0] = negm;             // C input of the chains
             sacc[1] = negm;
@@ -264,10 +295,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
         for (int db = 0; db < 2; ++db) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int krow0 = ks * 16 + lh * 8 + tr_q;
-                const int vch = db * 4 + tr_gl * 2 + (tr_p >> 1);
-                const int off0 = KV_TILE + tile_off2(krow0, vch) + (tr_p & 1) * 8;
-                const int off1 = KV_TILE + tile_off2(krow0 + 4, vch) + (tr_p & 1) * 8;
+                const int off0 = va[db][0] + ks * 2048, off1 = va[db][1] + ks * 2048;
                 const bf16x8 vhi = tr_frag(sb + off0, sb + off1);
                 if (PLANES == 2) {
                     const bf16x8 vlo = tr_frag(sb + 2 * KV_TILE + off0, sb + 2 * KV_TILE + off1);
@@ -279,6 +307,14 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
         }
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of tile t are complete
+    };
+    {
+        int t = 0;
+        for (; t + 1 < ntiles; t += 2) {
+            tile(t, std::integral_constant<int, 0>{});
+            tile(t + 1, std::integral_constant<int, 1>{});
+        }
+        if (t < ntiles) tile(t, std::integral_constant<int, 0>{});
     }
 
     // ---- normalise and write ctx[b*ntok + q][head*64 + d] ----
