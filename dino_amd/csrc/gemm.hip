@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
         f32x4 v = *reinterpret_cast<const f32x4*>(C + row * 128 + c4 * 4);
         v += bias4;
         if (EPI == EPI_PLAIN) {
-            *reinterpret_cast<f32x4*>(p.out_f32 + (long)gm * p.ldo_f32 + gn) = v;
+            *reinterpret_cast<f32x4*>(p.out_f32 + (long)blockIdx.y * p.split_stride + (long)gm * p.ldo_f32 + gn) = v;
         } else if (EPI == EPI_ATOMIC) {
             float* dst = p.out_f32 + (long)gm * p.ldo_f32 + gn;
 #pragma unroll

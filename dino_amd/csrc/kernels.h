@@ -40,7 +40,8 @@ struct GemmParams {
     const float* resid;                         // RESID: out = resid + acc + bias (null: in place on out_f32)
     bf16_t* aux_out;                            // GELU: also save the pre-activation planes here (training), ld = ldo
     const bf16_t* aux_in; long aux_plane;       // DGELU / DRELU operand planes [planes][M][ldo]; also plane stride of aux_out
-    int ksplit;                                 // >1: split the K loop over grid.y (use with EPI_ATOMIC)
+    int ksplit;                                 // >1: split the K loop over grid.y (EPI_ATOMIC, or EPI_PLAIN partial tiles)
+    long split_stride;                          // EPI_PLAIN with ksplit > 1: slice y writes out_f32 + y * split_stride (floats)
     int stagger;                                // (gemm_big) start every other workgroup this many s_sleep(127) late
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);       // dispatches between the two kernels below
@@ -125,6 +126,7 @@ int launch_nll_loss_grad(const float* logp, const int64_t* labels, int M, int C,
                          int ldz, hipStream_t s);
 int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int M, int D, float* dx,
                          int accumulate, float* dgamma, float* dbeta, int drop_cls, int ntok, hipStream_t s);
+int launch_splitk_reduce(const float* part, int ks, long stride, int rows, int ld_part, float* out, int ldo, int cols, hipStream_t s);
 int launch_batch_sum_rows(const float* X, int B, int ntok, int D, float* out, hipStream_t s);
 int launch_pos_resample_bwd(const float* dpos, int g, int D, int o, float* dpe, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,

@@ -242,6 +242,31 @@ int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, fl
 
 // ------------------------------------------------------------------------------------------------
 // out[t][d] = sum_b X[b*ntok + t][d]   (gradient of the broadcast pos-embed add; row 0 is also d cls_token)
+// Split-K weight gradients: out[r][c] += sum over slices of part[s][r][c] (c < cols).  The slices are written as plain
+// 16-byte stores by the GEMM (EPI_PLAIN, GemmParams::split_stride); 21 slices of a 1536 x 384 gradient are 50 MB of
+// streaming traffic (~20 us) where the same sum through fp32 atomics took most of the 183 us the GEMM launch cost.
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int ks, long stride, int rows, int ld_part,
+                                     float* __restrict__ out, int ldo, int cols) {
+    const long total = (long)rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+        const float* src = part + (long)r * ld_part + c;
+        float a = 0.f;
+        for (int sl = 0; sl < ks; ++sl) a += src[sl * stride];
+        out[(long)r * ldo + c] += a;
+    }
+}
+
+int launch_splitk_reduce(const float* part, int ks, long stride, int rows, int ld_part, float* out, int ldo, int cols, hipStream_t s) {
+    const long total = (long)rows * cols;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, part, ks, stride, rows, ld_part, out, ldo, cols);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ void batch_sum_rows_kernel(const float* __restrict__ X, int B, int ntok, int D, float* __restrict__ out) {
     const long total = (long)ntok * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {

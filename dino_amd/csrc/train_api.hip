@@ -14,12 +14,14 @@
 
 namespace {
 
+constexpr int SPLITK_TILES = 768;      // partial 128x128 fp32 tiles of one weight-gradient GEMM (48 MiB)
+
 struct TrainLayout {
     int n, ntok, npad, M, Mp, Mpad, Mppad, Cmax;
     // per block (offsets are for block 0; block l adds l * blk_stride)
     size_t Xin, A1, Q, K, V, LSE, CTX, Xmid, A2, HPRE, HB, blk_stride;
     size_t Xfin, PATCH, FEAT, H1, H2, LOGP, DZ;
-    size_t dX, dA, dXp, G, dCTX, T1, T2, NLSE, NDEL, DPOS, SINK;
+    size_t dX, dA, dXp, G, dCTX, T1, T2, NLSE, NDEL, DPOS, SINK, SPLITK;
     size_t zero_begin, zero_end;      // Q/K/V of every block (pad rows must be zero)
     size_t total;
     long a_plane, qkv_plane, f_plane, feat_plane, h1_plane, h2_plane, dz_plane, patch_plane, g_plane, t_plane;
@@ -91,6 +93,7 @@ TrainLayout make_train_layout(const dinoseg_handle* h, int B, int r) {
     L.NDEL = take((size_t)B * c.num_heads * L.npad * 4);
     L.DPOS = take((size_t)L.ntok * D * 4);
     L.SINK = take((size_t)4 * 1024 * 4);
+    L.SPLITK = take((size_t)SPLITK_TILES * 128 * 128 * 4);     // split-K partial tiles of the weight gradients
     L.total = off;
     return L;
 }
@@ -392,14 +395,25 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
         if (!dW) return 0;
         GemmParams g = {};
         g.A = Tdy; g.a_plane = tplane; g.lda = m_pad; g.W = Tx; g.w_plane = tplane;
-        g.M = n_rows; g.N = k_pad128; g.K = m_pad; g.planes = planes; g.epi = EPI_ATOMIC;
-        g.out_f32 = dW; g.ldo_f32 = k_cols; g.n_valid = k_cols;
-        const int tiles = ((n_rows + 127) / 128) * (k_pad128 / 128), nk = m_pad / 64;
-        int ks = 768 / tiles;
+        g.M = n_rows; g.N = k_pad128; g.K = m_pad; g.planes = planes;
+        const int row_tiles = (n_rows + 127) / 128, tiles = row_tiles * (k_pad128 / 128), nk = m_pad / 64;
+        int ks = SPLITK_TILES / tiles;
         if (ks > nk / 2) ks = nk / 2;
         if (ks < 1) ks = 1;
-        g.ksplit = ks;
-        return launch_gemm_small(g, s);
+        if (ks == 1) {
+            g.epi = EPI_ATOMIC;
+            g.out_f32 = dW; g.ldo_f32 = k_cols; g.n_valid = k_cols;
+            g.ksplit = 1;
+            return launch_gemm_small(g, s);
+        }
+        // slices of the batch dimension write partial tiles (plain stores), one pass sums them into dW
+        const int per = (nk + ks - 1) / ks, used = (nk + per - 1) / per;       // slices that own k-steps (gemm.hip)
+        float* part = F32(L.SPLITK);
+        g.epi = EPI_PLAIN;
+        g.out_f32 = part; g.ldo_f32 = k_pad128; g.ksplit = ks;
+        g.split_stride = (long)row_tiles * 128 * k_pad128;
+        DSEG_TRY(launch_gemm_small(g, s));
+        return launch_splitk_reduce(part, used, g.split_stride, n_rows, k_pad128, dW, k_cols, k_cols, s);
     };
     auto pad128 = [](int v) { return (v + 127) / 128 * 128; };
 
