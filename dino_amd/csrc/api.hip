@@ -487,10 +487,6 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().gemm_big = value;
         return 0;
     }
-    if (strcmp(key, "gemm_stagger") == 0) {
-        dseg::options().gemm_stagger = value;
-        return 0;
-    }
     if (strcmp(key, "gemm_dbg") == 0) {
         dseg::options().gemm_dbg = value;
         return 0;

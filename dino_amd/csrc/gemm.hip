@@ -270,7 +270,6 @@ int launch_gemm(const GemmParams& p0, hipStream_t s) {
     if (p0.M <= 0) return 0;
     GemmParams p = p0;
     p.dbg = options().gemm_dbg;
-    p.stagger = options().gemm_stagger;
     if (options().gemm_big && gemm_big_supported(p)) {
         // measured on MI355X (tools/bench_ops.py): the 256x384 persistent kernel wins when there are >= 2 tiles per CU
         // or the K loop is long; attn.proj (451 tiles, K = 384) is faster on the 128x128 kernel (tile quantisation)

@@ -42,7 +42,6 @@ struct GemmParams {
     const bf16_t* aux_in; long aux_plane;       // DGELU / DRELU operand planes [planes][M][ldo]; also plane stride of aux_out
     int ksplit;                                 // >1: split the K loop over grid.y (EPI_ATOMIC, or EPI_PLAIN partial tiles)
     long split_stride;                          // EPI_PLAIN with ksplit > 1: slice y writes out_f32 + y * split_stride (floats)
-    int stagger;                                // (gemm_big) start every other workgroup this many s_sleep(127) late
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);       // dispatches between the two kernels below
 int launch_gemm_small(const GemmParams& p, hipStream_t s); // 128x128 tile, bf16 or bf16x3 (gemm.hip)
@@ -52,7 +51,6 @@ int launch_gemm_big(const GemmParams& p, hipStream_t s);   // 256x384 persistent
 // tuning knobs (dinoseg_set_option): see api.hip
 struct Options {
     int gemm_big = 1;        // use gemm_big.hip where it applies
-    int gemm_stagger = 0;    // see GemmParams::stagger
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
     int attn_dbg = 0;        // same for AttnParams::dbg
     int attn_waves = 4;      // waves (x 32 query rows) per attention-forward workgroup: 4 or 8
