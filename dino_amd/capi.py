@@ -57,6 +57,8 @@ SIGNATURES = {
     "dinoseg_bind_grad": (C.c_int, [_vp, C.c_char_p, _fp]),
     "dinoseg_train_step": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _fp, _fp, _vp]),
     "dinoseg_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _i32, _f32, _vp]),
+    "dinoseg_adam_step_multi": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32,
+                                           _i32, _i32, _f32, _vp]),
     "dinoseg_op_attention_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dinoseg_op_layernorm_bwd": (C.c_int, [_fp, _fp, _fp, _f32, _i32, _i32, _fp, _i32, _fp, _fp, _i32, _i32, _vp]),
     "dinoseg_set_option": (C.c_int, [C.c_char_p, _i32]),

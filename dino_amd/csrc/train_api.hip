@@ -10,6 +10,8 @@
 //   db = column sums of dY (by-product of the transpose kernel)
 #include <string.h>
 
+#include <vector>
+
 #include "handle.h"
 
 namespace {
@@ -164,6 +166,25 @@ extern "C" int dinoseg_adam_step(float* p, const float* g, float* m, float* v, i
                        reinterpret_cast<hipStream_t>(stream));
 }
 
+extern "C" int dinoseg_adam_step_multi(int32_t count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                       const int64_t* n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                       int32_t decoupled, int32_t step, float grad_scale, void* stream) {
+    if (count < 0 || (count > 0 && (!p || !g || !m || !v || !n)) || step < 1) {
+        dinoseg_set_error("dinoseg_adam_step_multi: bad argument");
+        return -1;
+    }
+    std::vector<long> nn(count);
+    for (int i = 0; i < count; ++i) {
+        if (!p[i] || !g[i] || !m[i] || !v[i] || n[i] < 0) {
+            dinoseg_set_error("dinoseg_adam_step_multi: null pointer or negative size at tensor %d", i);
+            return -1;
+        }
+        nn[i] = (long)n[i];
+    }
+    return launch_multi_adam(count, p, g, m, v, nn.data(), lr, beta1, beta2, eps, weight_decay, decoupled, step, grad_scale,
+                             reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int dinoseg_op_attention_bwd(const void* q, const void* k, const void* v, int64_t qkv_plane, const void* dO,
                                         const void* O, int64_t o_plane, const float* lse, float* scratch, void* dqkv,
                                         int64_t dqkv_plane, int32_t B, int32_t heads, int32_t ntok, int32_t npad,
@@ -266,11 +287,18 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
         return n;
     };
     bool backbone = false;
-    for (auto& kv : h->grads) {
-        DSEG_CHECK_HIP(hipMemsetAsync(kv.second, 0, numel(kv.first) * sizeof(float), s));
-        if (kv.first.rfind("dino.", 0) == 0) backbone = true;
+    {
+        std::vector<float*> zp;
+        std::vector<long> zn;
+        for (auto& kv : h->grads) {
+            zp.push_back(kv.second);
+            zn.push_back((long)numel(kv.first));
+            if (kv.first.rfind("dino.", 0) == 0) backbone = true;
+        }
+        zp.push_back(loss_out);
+        zn.push_back(1);
+        DSEG_TRY(launch_multi_zero((int)zp.size(), zp.data(), zn.data(), s));      // one launch instead of ~50 memset nodes
     }
-    DSEG_CHECK_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), s));
 
     // =============================================================== forward (activations kept)
     float mean255[3], inv255[3];

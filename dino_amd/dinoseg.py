@@ -441,16 +441,19 @@ class DINOSeg(nn.Module):
         lr = self.lr if lr is None else lr
         state = self.__dict__.setdefault("_adam_state", {})
         self._adam_t = getattr(self, "_adam_t", 0) + 1
-        lib = capi.lib()
+        ps, gs, ms, vs, ns = [], [], [], [], []
         for name, p in self.named_parameters():
             if not p.requires_grad or p.grad is None:
                 continue
             if name not in state or state[name][0].data_ptr() == 0 or state[name][0].device != p.device:
                 state[name] = (torch.zeros_like(p), torch.zeros_like(p))
             m, v = state[name]
-            capi.check(lib.dinoseg_adam_step(p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr,
-                                             betas[0], betas[1], eps, weight_decay, decoupled, self._adam_t, grad_scale,
-                                             capi.stream_ptr()))
+            ps.append(p.data_ptr()); gs.append(p.grad.data_ptr()); ms.append(m.data_ptr()); vs.append(v.data_ptr()); ns.append(p.numel())
+        k = len(ps)
+        if k:
+            arr = lambda xs: (C.c_void_p * k)(*xs)
+            capi.check(capi.lib().dinoseg_adam_step_multi(k, arr(ps), arr(gs), arr(ms), arr(vs), (C.c_int64 * k)(*ns), lr, betas[0], betas[1],
+                                                          eps, weight_decay, decoupled, self._adam_t, grad_scale, capi.stream_ptr()))
         self._bound_sig = None      # weights changed: re-pack on the next forward / training_step
 
     def fit(self, ck_file_name=None, train_dataloader=None, val_dataloader=None, test_dataloader=None, max_epochs=None):

@@ -114,6 +114,12 @@ int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t
 int dinoseg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int32_t decoupled, int32_t step, float grad_scale, void* stream);
 
+/* The same update for `count` parameters in one launch per 64 tensors (host arrays of device pointers and element counts):
+ * what optimizer.step() does for the whole parameter list (pl_torch_modules.py:258-259). */
+int dinoseg_adam_step_multi(int32_t count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                            const int64_t* n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                            int32_t decoupled, int32_t step, float grad_scale, void* stream);
+
 /* Per-kernel-class timing with HIP events recorded on the forward's stream (used by bench.py for the
  * roofline leg).  level 0 = off, 1 = the dominant kernel only (fused attention), 2 = every class.
  * dinoseg_profile_read() waits for the recorded events, writes the summed milliseconds and launch counts
