@@ -1,0 +1,182 @@
+// Weight-gradient GEMM on row-major operands ("TN"):  dW[n][k] = sum_m dY[m][n] * X[m][k]   (Linear.weight.grad).
+//
+// Replaces autograd's `grad_output.t() @ input` (SURVEY.md section 2.1 "bwd" row; reference call site
+// pl_torch_modules.py:261-268 via loss.backward()).  The contraction runs over the batch rows m, which is the ROW index
+// of both operands, so an NT kernel needs both of them transposed first (the first version did that: 8 transposes per
+// transformer block, 16 % of the fine-tune step).  Here both tiles stay row-major in LDS -- [64 m][128 columns] bf16,
+// filled by LDS-DMA -- and both MFMA fragments are read column-wise with gfx950's transposing ds_read_b64_tr_b16,
+// exactly like the V^T fragments of the attention kernels:  A fragment (rows = n, k = m) from the dY tile, B fragment
+// (k = m, columns = k) from the X tile.
+//
+// Tile 128 (n) x 128 (k) per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 2 x 2 accumulators), 64 batch rows
+// per stage, double-buffered.  grid.y slices the batch (split-K); every slice writes its partial tile with plain
+// 16-byte stores (GemmParams-style split_stride) and launch_splitk_reduce sums the slices into the gradient.
+// Swizzle of the 256-byte rows: 16-byte chunk ^ 2*(row & 3): the 4 rows x 32 bytes a 16-lane group of a transposing read
+// touches fall on 4 distinct 32-byte slots of one 128-byte window.
+// PLANES = 2 (parity mode): hi + lo planes, three MFMAs per product.
+#include "attn_common.h"
+#include "kernels.h"
+
+namespace dseg {
+
+namespace tn {
+constexpr int BN = 128, BKc = 128, BMr = 64;          // tile: BN rows (n) x BKc columns (k); BMr batch rows per stage
+constexpr int TILE = BMr * 256;                       // one [64][128] bf16 tile = 16 KiB
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row & 3) << 1); }
+}  // namespace tn
+
+template <int PLANES>
+__global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_tn_kernel(TnParams p) {
+    using namespace tn;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE_BYTES = PLANES * 2 * TILE;     // per plane: dY tile, X tile
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const int tiles_k = p.Kc / BKc;
+    const int tn_ = blockIdx.x / tiles_k, tk = blockIdx.x - tn_ * tiles_k;
+    const int n0 = tn_ * BN, k0 = tk * BKc;
+    const int M = p.M;
+    const int nchunks = (M + BMr - 1) / BMr;
+    const int per = (nchunks + p.ksplit - 1) / p.ksplit;
+    const int c_begin = blockIdx.y * per;
+    const int nc = nchunks - c_begin < per ? nchunks - c_begin : per;
+    if (nc <= 0) return;
+
+    // loader: a 1-KiB piece = 4 rows x 256 B; 16 pieces per tile, 4 per wave and tile
+    auto stage = [&](int st, int chunk) {
+        char* sbase = smem + st * STAGE_BYTES;
+        const int prow = lane >> 4, slot = lane & 15;
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int piece = wave * 4 + i;
+                const int row = piece * 4 + prow;
+                const int c = swz(row, slot);              // logical chunk stored in physical slot `slot`
+                int gm = chunk * BMr + row;
+                gm = gm < M ? gm : M - 1;                  // rows >= M are zeroed at fragment level (ragged last chunk)
+                glds16(p.Y + pl * p.y_plane + (long)gm * p.ldy + n0 + c * 8, sbase + (pl * 2 + 0) * TILE + piece * 1024);
+                glds16(p.X + pl * p.x_plane + (long)gm * p.ldx + k0 + c * 8, sbase + (pl * 2 + 1) * TILE + piece * 1024);
+            }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing reads: within a 16-lane group, lane 4q+p addresses row q, columns 4p..4p+3 of a 4-row x 16-column block and
+    // receives column (lane & 15) of the 4 rows.  Group g = lane >> 4: columns 16*(g&1) + 0..15 of a 32-column block, batch
+    // rows 8*(g>>1) + 0..3 (second read: +4) of the 16-row step  ->  lane (col = lane & 31, half = lane >> 5) holds rows 8*half+0..7.
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
+    auto frag = [&](const char* tile, int colblock, int ks) {
+        const int col = colblock * 32 + tr_g1 * 16 + tr_p * 4;          // first of this lane's 4 columns
+        const int row0 = ks * 16 + lh * 8 + tr_q;
+        const char* a0 = tile + row0 * 256 + (swz(row0, col >> 3) << 4) + (col & 7) * 2;
+        const char* a1 = tile + (row0 + 4) * 256 + (swz(row0 + 4, col >> 3) << 4) + (col & 7) * 2;
+        return attn::tr_frag(a0, a1);
+    };
+
+    stage(0, c_begin);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int ci = 0; ci < nc; ++ci) {
+        const int cur = ci & 1;
+        if (ci + 1 < nc) stage(cur ^ 1, c_begin + ci + 1);
+        const char* sb = smem + cur * STAGE_BYTES;
+        const int m_chunk = (c_begin + ci) * BMr;
+        const bool ragged = m_chunk + BMr > M;              // wave-uniform: only the last chunk of the batch
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[PLANES][2], b[PLANES][2];
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[pl][i] = frag(sb + (pl * 2 + 0) * TILE, wr * 2 + i, ks);
+                    b[pl][i] = frag(sb + (pl * 2 + 1) * TILE, wc * 2 + i, ks);
+                }
+            if (ragged) {
+                // zero the dY elements of batch rows >= M (their X partners are clamped copies of row M-1: finite)
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        uint4 w = __builtin_bit_cast(uint4, a[pl][i]);
+                        uint32_t* ww = reinterpret_cast<uint32_t*>(&w);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int m = m_chunk + ks * 16 + lh * 8 + e;
+                            if (m >= M) ww[e >> 1] &= (e & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+                        }
+                        a[pl][i] = __builtin_bit_cast(bf16x8, w);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (PLANES == 2) {
+                        acc[i][j] = mfma32(a[1][i], b[0][j], acc[i][j]);
+                        acc[i][j] = mfma32(a[0][i], b[1][j], acc[i][j]);
+                    }
+                    acc[i][j] = mfma32(a[0][i], b[0][j], acc[i][j]);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- partial tile: accumulators through LDS C[128][128] fp32, then 16-byte row segments ----
+    float* C = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                C[(wr * 64 + i * 32 + acc_row(r, lh)) * 128 + wc * 64 + j * 32 + lr] = acc[i][j][r];
+    __syncthreads();
+    const int c4 = tid & 31, rb = tid >> 5;
+    float* out = p.part + (long)blockIdx.y * p.split_stride;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 8 + rb;
+        const int gn = n0 + row;
+        if (gn < p.N)
+            *reinterpret_cast<f32x4*>(out + (long)gn * p.ld_part + k0 + c4 * 4) = *reinterpret_cast<const f32x4*>(C + row * 128 + c4 * 4);
+    }
+}
+
+int launch_gemm_tn(const TnParams& p, hipStream_t s) {
+    using namespace tn;
+    if (p.M < 1 || p.N < 1 || p.Kc % BKc != 0 || p.ksplit < 1 || (p.planes != 1 && p.planes != 2) || p.ldy % 8 != 0 || p.ldx % 8 != 0) {
+        dinoseg_set_error("gemm_tn: bad shape M=%d N=%d Kc=%d ksplit=%d planes=%d", p.M, p.N, p.Kc, p.ksplit, p.planes);
+        return -1;
+    }
+    const int tiles = ((p.N + BN - 1) / BN) * (p.Kc / BKc);
+    const size_t lds = (size_t)2 * p.planes * 2 * TILE;         // 64 KiB (1 plane) / 128 KiB (2 planes); >= the 64 KiB C tile
+    if (p.planes == 1) {
+        hipLaunchKernelGGL(gemm_tn_kernel<1>, dim3(tiles, p.ksplit), dim3(256), lds, s, p);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(tiles, p.ksplit), dim3(256), lds, s, p);
+    }
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dseg

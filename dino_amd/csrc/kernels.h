@@ -124,6 +124,14 @@ int launch_nll_loss_grad(const float* logp, const int64_t* labels, int M, int C,
                          int ldz, hipStream_t s);
 int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int M, int D, float* dx,
                          int accumulate, float* dgamma, float* dbeta, int drop_cls, int ntok, hipStream_t s);
+// Weight gradient on row-major operands (gemm_tn.hip): part[slice][n][k] = sum over the slice's batch rows of Y[m][n] X[m][k]
+struct TnParams {
+    const bf16_t* Y; long y_plane; int ldy;     // dY planes [planes][M][ldy], columns n < N (N % 128 == 0 not required: rows guarded)
+    const bf16_t* X; long x_plane; int ldx;     // layer input planes [planes][M][ldx], columns k < Kc (Kc % 128 == 0)
+    int M, N, Kc, planes;
+    float* part; int ld_part; long split_stride; int ksplit;
+};
+int launch_gemm_tn(const TnParams& p, hipStream_t s);
 int launch_splitk_reduce(const float* part, int ks, long stride, int rows, int ld_part, float* out, int ldo, int cols, hipStream_t s);
 int launch_batch_sum_rows(const float* X, int B, int ntok, int D, float* out, hipStream_t s);
 int launch_pos_resample_bwd(const float* dpos, int g, int D, int o, float* dpe, hipStream_t s);

@@ -444,6 +444,31 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
         return launch_splitk_reduce(part, used, g.split_stride, n_rows, k_pad128, dW, k_cols, k_cols, s);
     };
     auto pad128 = [](int v) { return (v + 127) / 128 * 128; };
+    // weight gradient straight from the row-major dY and layer-input planes (gemm_tn.hip): no operand transposes
+    auto wgrad_tn = [&](const bf16_t* Y, long y_plane, int ldy, const bf16_t* X, long x_plane, int ldx, int m_rows, int n_rows,
+                        int k_cols, int planes, float* dW) -> int {
+        if (!dW) return 0;
+        if (k_cols % 128 != 0) {        // narrow layers (embed_dim not a multiple of 128): transposed operands + the NT kernel
+            bf16_t* T1f = B16(L.T1);
+            bf16_t* T2f = B16(L.T2);
+            DSEG_TRY(launch_transpose_planes(nullptr, Y, y_plane, ldy, m_rows, n_rows, T1f, L.t_plane, pad128(n_rows), L.Mpad, nullptr, 0, 0,
+                                             nullptr, planes, 0, 0, s));
+            DSEG_TRY(launch_transpose_planes(nullptr, X, x_plane, ldx, m_rows, k_cols, T2f, L.t_plane, pad128(k_cols), L.Mpad, nullptr, 0, 0,
+                                             nullptr, planes, 0, 0, s));
+            return wgrad(T1f, T2f, L.t_plane, L.Mpad, n_rows, pad128(k_cols), k_cols, planes, dW);
+        }
+        TnParams g = {};
+        g.Y = Y; g.y_plane = y_plane; g.ldy = ldy; g.X = X; g.x_plane = x_plane; g.ldx = ldx;
+        g.M = m_rows; g.N = n_rows; g.Kc = k_cols; g.planes = planes;
+        const int row_tiles = (n_rows + 127) / 128, tiles = row_tiles * (k_cols / 128), nchunks = (m_rows + 63) / 64;
+        int ks = SPLITK_TILES / tiles;
+        if (ks > nchunks / 2) ks = nchunks / 2;
+        if (ks < 1) ks = 1;
+        const int per = (nchunks + ks - 1) / ks, used = (nchunks + per - 1) / per;
+        g.part = F32(L.SPLITK); g.ld_part = k_cols; g.split_stride = (long)row_tiles * 128 * k_cols; g.ksplit = ks;
+        DSEG_TRY(launch_gemm_tn(g, s));
+        return launch_splitk_reduce(g.part, used, g.split_stride, n_rows, k_cols, dW, k_cols, k_cols, s);
+    };
 
     // ---- loss and d logits (pl_torch_modules.py:264-265)
     DSEG_TRY(launch_nll_loss_grad(LOGP, labels, L.Mp, C, loss_out, DZ, L.dz_plane, 64, s));
@@ -498,32 +523,26 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
         bf16_t *A1 = B16(L.A1 + o), *Q = B16(L.Q + o), *Kb = B16(L.K + o), *V = B16(L.V + o), *CTX = B16(L.CTX + o);
         bf16_t *A2 = B16(L.A2 + o), *HPRE = B16(L.HPRE + o), *HB = B16(L.HB + o);
         // ---- mlp.fc2 : X_out = X_mid + H W2^T + b
-        DSEG_TRY(launch_transpose_planes(dX, nullptr, 0, D, L.M, D, T1, tpl, pad128(D), L.Mpad, dXp, L.a_plane, D, grad(b + "mlp.fc2.bias"),
+        // (fp32 dX -> bf16 planes dXp for the two GEMMs + the bias gradient; no transposed copy: the weight gradient reads
+        //  dXp and HB row-major)
+        DSEG_TRY(launch_transpose_planes(dX, nullptr, 0, D, L.M, D, nullptr, 0, pad128(D), L.Mpad, dXp, L.a_plane, D, grad(b + "mlp.fc2.bias"),
                                          P, 0, 0, s));
-        if (grad(b + "mlp.fc2.weight")) {
-            DSEG_TRY(launch_transpose_planes(nullptr, HB, L.f_plane, F, L.M, F, T2, tpl, pad128(F), L.Mpad, nullptr, 0, 0, nullptr, P, 0, 0, s));
-            DSEG_TRY(wgrad(T1, T2, tpl, L.Mpad, D, pad128(F), F, P, grad(b + "mlp.fc2.weight")));
-        }
+        DSEG_TRY(wgrad_tn(dXp, L.a_plane, D, HB, L.f_plane, F, L.M, D, F, P, grad(b + "mlp.fc2.weight")));
         // dHpre = (dX . W2) * gelu'(Hpre)
         DSEG_TRY(dgrad(dXp, L.a_plane, D, L.M, D, tw.at(b + "mlp.fc2.weight"), F, P, EPI_DGELU, nullptr, G, (long)L.M * F, HPRE, L.f_plane));
         // ---- mlp.fc1 : Hpre = A2 W1^T + b
-        DSEG_TRY(launch_transpose_planes(nullptr, G, (long)L.M * F, F, L.M, F, T1, tpl, pad128(F), L.Mpad, nullptr, 0, 0,
-                                         grad(b + "mlp.fc1.bias"), P, 0, 0, s));
-        if (grad(b + "mlp.fc1.weight")) {
-            DSEG_TRY(launch_transpose_planes(nullptr, A2, L.a_plane, D, L.M, D, T2, tpl, pad128(D), L.Mpad, nullptr, 0, 0, nullptr, P, 0, 0, s));
-            DSEG_TRY(wgrad(T1, T2, tpl, L.Mpad, F, pad128(D), D, P, grad(b + "mlp.fc1.weight")));
-        }
+        if (grad(b + "mlp.fc1.bias"))
+            DSEG_TRY(launch_transpose_planes(nullptr, G, (long)L.M * F, F, L.M, F, nullptr, 0, pad128(F), L.Mpad, nullptr, 0, 0,
+                                             grad(b + "mlp.fc1.bias"), P, 0, 0, s));
+        DSEG_TRY(wgrad_tn(G, (long)L.M * F, F, A2, L.a_plane, D, L.M, F, D, P, grad(b + "mlp.fc1.weight")));
         DSEG_TRY(dgrad(G, (long)L.M * F, F, L.M, F, tw.at(b + "mlp.fc1.weight"), D, P, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
         // ---- norm2 (input X_mid); the residual branch keeps dX
         DSEG_TRY(launch_layernorm_bwd(dA, F32(L.Xmid + o), W(h, b + "norm2.weight"), c.ln_eps, L.M, D, dX, 1, gsink(b + "norm2.weight"),
                                       gsink(b + "norm2.bias"), 0, L.ntok, s));
         // ---- attn.proj : X_mid = X_in + ctx Wp^T + b
-        DSEG_TRY(launch_transpose_planes(dX, nullptr, 0, D, L.M, D, T1, tpl, pad128(D), L.Mpad, dXp, L.a_plane, D, grad(b + "attn.proj.bias"),
+        DSEG_TRY(launch_transpose_planes(dX, nullptr, 0, D, L.M, D, nullptr, 0, pad128(D), L.Mpad, dXp, L.a_plane, D, grad(b + "attn.proj.bias"),
                                          P, 0, 0, s));
-        if (grad(b + "attn.proj.weight")) {
-            DSEG_TRY(launch_transpose_planes(nullptr, CTX, L.a_plane, D, L.M, D, T2, tpl, pad128(D), L.Mpad, nullptr, 0, 0, nullptr, P, 0, 0, s));
-            DSEG_TRY(wgrad(T1, T2, tpl, L.Mpad, D, pad128(D), D, P, grad(b + "attn.proj.weight")));
-        }
+        DSEG_TRY(wgrad_tn(dXp, L.a_plane, D, CTX, L.a_plane, D, L.M, D, D, P, grad(b + "attn.proj.weight")));
         DSEG_TRY(dgrad(dXp, L.a_plane, D, L.M, D, tw.at(b + "attn.proj.weight"), D, P, EPI_BF16, nullptr, dCTX, L.a_plane, nullptr, 0));
         // ---- attention
         {
@@ -536,12 +555,10 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
             DSEG_TRY(launch_attention_bwd(a, s));
         }
         // ---- attn.qkv : qkv = A1 Wqkv^T + b
-        DSEG_TRY(launch_transpose_planes(nullptr, G, (long)L.M * 3 * D, 3 * D, L.M, 3 * D, T1, tpl, pad128(3 * D), L.Mpad, nullptr, 0, 0,
-                                         grad(b + "attn.qkv.bias"), P, 0, 0, s));
-        if (grad(b + "attn.qkv.weight")) {
-            DSEG_TRY(launch_transpose_planes(nullptr, A1, L.a_plane, D, L.M, D, T2, tpl, pad128(D), L.Mpad, nullptr, 0, 0, nullptr, P, 0, 0, s));
-            DSEG_TRY(wgrad(T1, T2, tpl, L.Mpad, 3 * D, pad128(D), D, P, grad(b + "attn.qkv.weight")));
-        }
+        if (grad(b + "attn.qkv.bias"))
+            DSEG_TRY(launch_transpose_planes(nullptr, G, (long)L.M * 3 * D, 3 * D, L.M, 3 * D, nullptr, 0, pad128(3 * D), L.Mpad, nullptr, 0, 0,
+                                             grad(b + "attn.qkv.bias"), P, 0, 0, s));
+        DSEG_TRY(wgrad_tn(G, (long)L.M * 3 * D, 3 * D, A1, L.a_plane, D, L.M, 3 * D, D, P, grad(b + "attn.qkv.weight")));
         DSEG_TRY(dgrad(G, (long)L.M * 3 * D, 3 * D, L.M, 3 * D, tw.at(b + "attn.qkv.weight"), D, P, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
         // ---- norm1 (input X_in)
         DSEG_TRY(launch_layernorm_bwd(dA, F32(L.Xin + o), W(h, b + "norm1.weight"), c.ln_eps, L.M, D, dX, 1, gsink(b + "norm1.weight"),
