@@ -53,6 +53,7 @@ SIGNATURES = {
     "dinoseg_workspace_bytes": (_i64, [_vp, _i32, _i32]),
     "dinoseg_last_selfattention": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _vp]),
     "dinoseg_op_confusion": (C.c_int, [_fp, _fp, _i64, _i32, _fp, _vp]),
+    "dinoseg_forward_mask": (C.c_int, [_vp, _vp, _i32, _i32, _fp, _i32, _fp, _fp, _vp]),
     "dinoseg_op_resize_u8": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i32, _vp]),
     "dinoseg_bind_grad": (C.c_int, [_vp, C.c_char_p, _fp]),
     "dinoseg_train_step": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _fp, _fp, _vp]),

@@ -293,8 +293,16 @@ static int ensure_workspace(dinoseg_handle* h, const WsLayout& L, int B, int r, 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+struct MaskRequest {            // forward_mask / get_last_selfattention(x, cls_mask): see dinoseg_forward_mask
+    const float* cls_mask;
+    int n_masks;
+    float* emb_out;
+    float* attn_out;
+};
+
 static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
-                        int32_t* argmax_out, int32_t tap_block, float* tap_out, float* attn_out, void* stream) {
+                        int32_t* argmax_out, int32_t tap_block, float* tap_out, float* attn_out, void* stream,
+                        const MaskRequest* mreq = nullptr) {
     if (!h || !x || B <= 0) {
         dinoseg_set_error("dinoseg_forward: bad argument");
         return -1;
@@ -370,6 +378,36 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
         }
         if (attn_out && i == c.n_blocks - 1)      // get_last_selfattention: probabilities of the last block, then stop
             return launch_attn_probs(Q, Kb, L.qkv_plane, P, B, H, L.ntok, L.npad, attn_out, s);
+        if (mreq && i == c.n_blocks - 1) {
+            // last block with cls_mask (Block.forward, vision_transformer.py:127-140): the CLS token attends through each mask;
+            // its residual is repeated once per mask; MLP and the final norm run on those n_masks rows only.  The patch-token
+            // rows of X / A / CTX / HB are dead from here on and host the n_masks rows (checked: n_masks < ntok).
+            const int Nm = mreq->n_masks;
+            DSEG_TRY(launch_cls_mask_attn(Q, Kb, V, L.qkv_plane, P, H, L.ntok, L.npad, mreq->cls_mask, Nm, CTX, L.ctx_plane,
+                                          mreq->attn_out, s));
+            if (!mreq->emb_out) return 0;
+            float* Xm = X + D;                        // rows 1 .. Nm
+            DSEG_TRY(launch_broadcast_row0(X, D, Nm, s));
+            auto lin = [&](const std::string& name, const bf16_t* Ain, long a_plane, int lda, int N, int K, int epi, bf16_t* ob,
+                           long o_plane) -> int {
+                const PackedLinear& pk = h->packed.at(name + ".weight");
+                GemmParams g = {};
+                g.A = Ain; g.a_plane = a_plane; g.lda = lda;
+                g.W = pk.w; g.w_plane = pk.plane;
+                g.M = Nm; g.N = N; g.K = K; g.planes = P; g.epi = epi;
+                g.bias = W(h, name + ".bias");
+                g.out_f32 = Xm; g.ldo_f32 = D;
+                g.out_bf16 = ob; g.out_plane = o_plane; g.ldo = N;
+                return launch_gemm_small(g, s);
+            };
+            DSEG_TRY(lin(b + "attn.proj", CTX, L.ctx_plane, D, D, D, EPI_RESID, nullptr, 0));
+            DSEG_TRY(launch_layernorm(Xm, W(h, b + "norm2.weight"), W(h, b + "norm2.bias"), c.ln_eps, Nm, D, A, L.a_plane, P, nullptr, 0,
+                                      L.ntok, s));
+            DSEG_TRY(lin(b + "mlp.fc1", A, L.a_plane, D, F, D, EPI_GELU, HB, L.hb_plane));
+            DSEG_TRY(lin(b + "mlp.fc2", HB, L.hb_plane, F, D, F, EPI_RESID, nullptr, 0));
+            return launch_layernorm(Xm, W(h, "dino.norm.weight"), W(h, "dino.norm.bias"), c.ln_eps, Nm, D, A, L.a_plane, P,
+                                    mreq->emb_out, 0, L.ntok, s);
+        }
         {
             AttnParams a = {};
             a.q = Q; a.k = Kb; a.v = V; a.qkv_plane = L.qkv_plane;
@@ -459,6 +497,20 @@ extern "C" int dinoseg_last_selfattention(dinoseg_handle* h, const void* x, int3
         return -1;
     }
     return forward_impl(h, x, x_kind, B, r, nullptr, nullptr, -1, nullptr, attn_out, stream);
+}
+
+extern "C" int dinoseg_forward_mask(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t r, const float* cls_mask,
+                                    int32_t n_masks, float* emb_out, float* attn_out, void* stream) {
+    if (!h || h->cfg.n_blocks < 1 || !cls_mask || n_masks < 1 || (!emb_out && !attn_out)) {
+        dinoseg_set_error("dinoseg_forward_mask: needs at least one block, n_masks >= 1 masks and one output buffer");
+        return -1;
+    }
+    if (r > 0 && r % 8 == 0 && n_masks >= (r / 8) * (r / 8) + 1) {
+        dinoseg_set_error("dinoseg_forward_mask: n_masks=%d must be smaller than the token count %d", n_masks, (r / 8) * (r / 8) + 1);
+        return -1;
+    }
+    const MaskRequest mr = {cls_mask, n_masks, emb_out, attn_out};
+    return forward_impl(h, x, x_kind, 1, r, nullptr, nullptr, -1, nullptr, nullptr, stream, &mr);
 }
 
 extern "C" int dinoseg_op_resize_u8(const uint8_t* src, int32_t sh, int32_t sw, uint8_t* dst, int32_t dh, int32_t dw, void* stream) {

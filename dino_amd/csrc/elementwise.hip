@@ -432,6 +432,98 @@ int launch_attn_probs(const bf16_t* q, const bf16_t* k, long plane, int planes, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Masked CLS attention of the last block: Attention.forward(x, cls_mask) (vision_transformer.py:80-107), the engine of
+// VisionTransformer.forward_mask / get_last_selfattention(x, cls_mask) (:250-280).  Only the CLS query row is used; its
+// logits are MULTIPLIED by each mask (the CLS key gets factor 0, so masked keys keep logit 0 -- the reference's arithmetic,
+// not a -inf mask), softmax over all N keys, context = probs @ V.  One workgroup per (mask, head); one frame.
+// Q~ is pre-scaled by head_dim^-0.5 * log2e, so everything runs in the log2 domain (a factor on the logit commutes).
+// Outputs: ctx planes [planes][n_masks][heads*64] (rows = masks) and, optionally, probs [heads][n_masks][ntok] fp32.
+__global__ __launch_bounds__(256) void cls_mask_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                            const bf16_t* __restrict__ v, long plane, int planes, int heads, int ntok,
+                                                            int npad, const float* __restrict__ mask, int n_masks,
+                                                            bf16_t* __restrict__ ctx, long ctx_plane, float* __restrict__ probs) {
+    extern __shared__ float sc[];           // [ntok] scores -> probabilities, then [4][64] partial contexts
+    __shared__ float qs[64];
+    __shared__ float red[8];
+    const int m = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long po = (long)hd * npad * 64;
+    auto ld = [&](const bf16_t* base, long idx) {
+        float x = bf16_to_f32(base[idx]);
+        if (planes == 2) x += bf16_to_f32(base[plane + idx]);
+        return x;
+    };
+    if (tid < 64) qs[tid] = ld(q, po + tid);                      // CLS row = token 0
+    __syncthreads();
+    const float* mrow = mask + (long)m * (ntok - 1);
+    float mx = -INFINITY;
+    for (int n = tid; n < ntok; n += 256) {
+        float s = 0.f;
+        for (int d = 0; d < 64; ++d) s = fmaf(qs[d], ld(k, po + (long)n * 64 + d), s);
+        s *= (n == 0) ? 0.f : mrow[n - 1];
+        sc[n] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int n = tid; n < ntok; n += 256) {
+        const float e = __builtin_amdgcn_exp2f(sc[n] - mx);
+        sc[n] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wv] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    if (probs) {
+        float* pr = probs + ((long)hd * n_masks + m) * ntok;
+        for (int n = tid; n < ntok; n += 256) pr[n] = sc[n] * inv;
+    }
+    // context: wave wv sums keys n = wv, wv+4, ...; lane = d
+    float acc = 0.f;
+    for (int n = wv; n < ntok; n += 4) acc = fmaf(sc[n], ld(v, po + (long)n * 64 + lane), acc);
+    __syncthreads();                         // everyone is done reading sc[] as probabilities
+    sc[wv * 64 + lane] = acc;
+    __syncthreads();
+    if (tid < 64) {
+        const float o = (sc[tid] + sc[64 + tid] + sc[128 + tid] + sc[192 + tid]) * inv;
+        const uint32_t hi = pack_bf16x2(o, 0.f);
+        const long idx = (long)m * heads * 64 + hd * 64 + tid;
+        ctx[idx] = (bf16_t)(hi & 0xFFFF);
+        if (planes == 2) ctx[ctx_plane + idx] = (bf16_t)(pack_bf16x2(o - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
+    }
+}
+
+int launch_cls_mask_attn(const bf16_t* q, const bf16_t* k, const bf16_t* v, long plane, int planes, int heads, int ntok, int npad,
+                         const float* mask, int n_masks, bf16_t* ctx, long ctx_plane, float* probs, hipStream_t s) {
+    const size_t lds = (size_t)(ntok > 256 ? ntok : 256) * sizeof(float);
+    if (lds > 60 * 1024) {
+        dinoseg_set_error("cls_mask_attn: %d tokens exceed the LDS score buffer", ntok);
+        return -1;
+    }
+    hipLaunchKernelGGL(cls_mask_attn_kernel, dim3(n_masks, heads), dim3(256), lds, s, q, k, v, plane, planes, heads, ntok, npad, mask,
+                       n_masks, ctx, ctx_plane, probs);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// rows 1 .. n of X [*, D] = row 0 (the CLS residual repeated once per mask, Block.forward vision_transformer.py:131-135)
+__global__ void broadcast_row0_kernel(float* __restrict__ X, int D, int n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)n * D) X[D + i] = X[i % D];
+}
+
+int launch_broadcast_row0(float* X, int D, int n, hipStream_t s) {
+    const long total = (long)n * D;
+    hipLaunchKernelGGL(broadcast_row0_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, D, n);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Confusion matrix for the validation metrics (validation_epoch_end, pl_torch_modules.py:310-332):
 // cm[gt][pred] += 1 (int64), block-private histogram in LDS first.
 __global__ __launch_bounds__(256) void confusion_kernel(const int32_t* __restrict__ pred, const int64_t* __restrict__ gt, long n,

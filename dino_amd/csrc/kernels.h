@@ -103,6 +103,9 @@ int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, con
 int launch_attn_probs(const bf16_t* q, const bf16_t* k, long plane, int planes, int B, int heads, int ntok, int npad, float* out,
                       hipStream_t s);
 // cm[gt][pred] += 1 over n patches (int64 [C,C], accumulates)
+int launch_cls_mask_attn(const bf16_t* q, const bf16_t* k, const bf16_t* v, long plane, int planes, int heads, int ntok, int npad,
+                         const float* mask, int n_masks, bf16_t* ctx, long ctx_plane, float* probs, hipStream_t s);
+int launch_broadcast_row0(float* X, int D, int n, hipStream_t s);
 int launch_resize_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, hipStream_t s);
 int launch_confusion(const int32_t* pred, const int64_t* gt, long n, int C, int64_t* cm, hipStream_t s);
 

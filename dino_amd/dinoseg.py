@@ -195,7 +195,8 @@ class DINOSeg(nn.Module):
         import weakref
         owner = weakref.ref(self)
         # reference call site: mlp_dino.dino.get_last_selfattention(x)  (visualize_attention.py:46)
-        self.dino.get_last_selfattention = lambda x: owner().get_last_selfattention(x)
+        self.dino.get_last_selfattention = lambda x, cls_mask=None: owner().get_last_selfattention(x, cls_mask)
+        self.dino.forward_mask = lambda x, cls_mask: owner().forward_mask(x, cls_mask)      # vision_transformer.py:250
 
         self._handle: Optional[C.c_void_p] = None
         self._bound_sig = None
@@ -330,9 +331,34 @@ class DINOSeg(nn.Module):
         _, _, tap = self._run(x, capi.INPUT_F32_CHW, x.shape[0], x.shape[2], tap_block=block)
         return tap.reshape(x.shape[0], -1, self.cfg.embed_dim)
 
-    def get_last_selfattention(self, x: torch.Tensor) -> torch.Tensor:
+    def _mask_request(self, x: torch.Tensor, cls_mask: torch.Tensor, want_emb: bool, want_attn: bool):
+        self._require_gpu()
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        if x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != 3 or x.shape[2] != x.shape[3] or x.shape[2] % 8 != 0:
+            raise ValueError(f"expected a single frame [1,3,r,r] with r % 8 == 0, got {tuple(x.shape)}")
+        r = x.shape[2]
+        n = (r // 8) ** 2
+        m = cls_mask.to(device=self.device, dtype=torch.float32).reshape(cls_mask.shape[0], -1).contiguous()
+        if m.shape[1] != n:
+            raise ValueError(f"cls_mask must be [n_masks, {r // 8}, {r // 8}], got {tuple(cls_mask.shape)}")
+        self._sync_weights()
+        emb = torch.empty((m.shape[0], self.cfg.embed_dim), dtype=torch.float32, device=x.device) if want_emb else None
+        att = torch.empty((1, self.cfg.num_heads, m.shape[0], n + 1), dtype=torch.float32, device=x.device) if want_attn else None
+        capi.check(capi.lib().dinoseg_forward_mask(self._handle, x.data_ptr(), capi.INPUT_F32_CHW, r, m.data_ptr(), m.shape[0],
+                                                   capi.ptr(emb), capi.ptr(att), capi.stream_ptr()))
+        return emb, att
+
+    def forward_mask(self, x: torch.Tensor, cls_mask: torch.Tensor) -> torch.Tensor:
+        """One embedding per mask, [n_masks, embed_dim]: ``model.dino.forward_mask(x, cls_mask)`` of the reference
+        (vision_transformer.py:250-271).  x: one frame fp32 [1,3,r,r]; cls_mask [n_masks, r/8, r/8]."""
+        return self._mask_request(x, cls_mask, True, False)[0]
+
+    def get_last_selfattention(self, x: torch.Tensor, cls_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Attention probabilities [B, heads, N, N] of the last block (reference: ``model.dino.get_last_selfattention(x)``,
-        vision_transformer.py:273-280; used by visualize_attention.py:46).  x: fp32 [B,3,r,r]."""
+        vision_transformer.py:273-280; used by visualize_attention.py:46).  x: fp32 [B,3,r,r].  With cls_mask
+        [n_masks, r/8, r/8]: the masked CLS attention [1, heads, n_masks, N] of one frame."""
+        if cls_mask is not None:
+            return self._mask_request(x, cls_mask, False, True)[1]
         self._require_gpu()
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3] or x.shape[2] % 8 != 0:

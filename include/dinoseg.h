@@ -85,6 +85,16 @@ int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B,
 int dinoseg_last_selfattention(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* attn_out,
                                void* stream);
 
+/* Replaces VisionTransformer.forward_mask (vision_transformer.py:250-271) and get_last_selfattention(x, cls_mask)
+ * (:273-280) for ONE frame x (kinds as dinoseg_forward): every block but the last runs as usual; in the last block the CLS
+ * query attends through each of the n_masks masks (its logits MULTIPLIED by the mask, CLS key by 0; Attention.forward
+ * :80-107), the CLS residual is repeated once per mask (Block.forward :127-140), then MLP and the final norm.
+ * cls_mask: fp32 [n_masks, (r/8)^2] on device, n_masks <= (r/8)^2.  emb_out: fp32 [n_masks, embed_dim] (nullable);
+ * attn_out: fp32 [heads, n_masks, (r/8)^2 + 1] masked attention of the last block (nullable; with emb_out NULL the call
+ * stops after the attention, like get_last_selfattention). */
+int dinoseg_forward_mask(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t r, const float* cls_mask, int32_t n_masks,
+                         float* emb_out, float* attn_out, void* stream);
+
 /* Replaces the Resize(r, r) of get_transforms (pl_torch_modules.py:36-38, applied in predict at :291) for frames that are
  * not already r x r: uint8 HWC [sh, sw, 3] -> [dh, dw, 3] on device, restating cv2.resize(INTER_LINEAR)'s fixed-point
  * arithmetic (albumentations 1.1.0 -> opencv 4.5.5, third-party: parity unpinned) so that predict() keeps

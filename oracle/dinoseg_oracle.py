@@ -194,6 +194,46 @@ def last_selfattention(x: Tensor, W: Dict[str, Tensor], num_heads: int, patch: i
     return pr
 
 
+def _masked_cls_attention(t: Tensor, W: Dict[str, Tensor], pre: str, H: int, cls_mask: Tensor):
+    """Attention.forward with cls_mask (vision_transformer.py:80-107): only the CLS query row is kept, its logits are
+    MULTIPLIED by each of the Nm masks (a zero column is prepended for the CLS key, so masked keys keep logit 0 rather
+    than -inf), softmax, then attn @ v gives one context row per mask.  t: [1, N, D] (already norm1'd); cls_mask
+    [Nm, ph, pw].  Returns (proj output [1, Nm, D], probabilities [1, H, Nm, N])."""
+    B, N, D = t.shape
+    dh = D // H
+    qkv = linear(t, W[pre + "attn.qkv.weight"], W[pre + "attn.qkv.bias"])
+    qkv = qkv.reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    Q, K, V = qkv[0], qkv[1], qkv[2]
+    s = (Q @ K.transpose(-2, -1)) * (dh ** -0.5)
+    Nm = cls_mask.shape[0]
+    m = torch.cat([torch.zeros((Nm, 1), dtype=s.dtype), cls_mask.reshape(Nm, -1).to(s.dtype)], dim=1)    # [Nm, N]
+    s = s[0:1, :, 0:1, :] * m                                                                              # [1, H, Nm, N]
+    s = s - s.amax(dim=-1, keepdim=True)
+    e = torch.exp(s)
+    pr = e / e.sum(dim=-1, keepdim=True)
+    ctx = (pr @ V).transpose(1, 2).reshape(B, Nm, D)
+    return linear(ctx, W[pre + "attn.proj.weight"], W[pre + "attn.proj.bias"]), pr
+
+
+def forward_mask(x: Tensor, W: Dict[str, Tensor], num_heads: int, cls_mask: Tensor, patch: int = 8, eps: float = 1e-6,
+                 return_attention: bool = False) -> Tensor:
+    """VisionTransformer.forward_mask (vision_transformer.py:250-271) / get_last_selfattention(x, cls_mask) (:273-280) for
+    one frame x [1,3,r,r]: all blocks but the last run normally; in the last one the CLS token attends through each of the
+    Nm masks and the CLS residual is repeated Nm times (Block.forward :127-140).  Returns the Nm mask embeddings [Nm, D]
+    after the final norm, or the masked attention [1, H, Nm, N]."""
+    t = prepare_tokens(x, W, patch)
+    L = count_blocks(W)
+    for i in range(L - 1):
+        t = block(t, W, i, num_heads, eps)
+    pre = f"dino.blocks.{L - 1}."
+    y, pr = _masked_cls_attention(layer_norm(t, W[pre + "norm1.weight"], W[pre + "norm1.bias"], eps), W, pre, num_heads, cls_mask)
+    if return_attention:
+        return pr
+    xm = t[:, 0:1, :].repeat(1, cls_mask.shape[0], 1) + y
+    xm = xm + mlp(layer_norm(xm, W[pre + "norm2.weight"], W[pre + "norm2.bias"], eps), W, pre)
+    return layer_norm(xm, W["dino.norm.weight"], W["dino.norm.bias"], eps)[0]
+
+
 def head_forward(feat: Tensor, W: Dict[str, Tensor], q: Callable = _ident) -> Tensor:
     """[M,D] -> [M,C] log-probabilities; MLP head if clf.layer_2 exists, else the Linear head."""
     if "clf.layer_2.weight" in W:

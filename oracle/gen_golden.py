@@ -379,7 +379,27 @@ def g10():
     save("g10_last_selfattention", **out)
 
 
-ALL = {"G10": g10, "G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
+def g11():
+    """forward_mask / get_last_selfattention(x, cls_mask): the masked-CLS path of the last block."""
+    out = {}
+    for tag, cfg, r, nm in (("tiny_r64", TINY, 64, 3), ("vits8_L3_r96", ViTConfig(n_blocks=3), 96, 5)):
+        vit = ref_vit(cfg, procedural_state_dict(cfg))
+        frames = synthetic_frames(1, r, seed=111 + r)
+        o = r // 8
+        rng = np.random.default_rng(7 + r)
+        masks = (rng.random((nm, o, o)) < 0.4).astype(np.float32)
+        masks[0] = 1.0                                   # all keys
+        masks[-1] = 0.0                                  # no key: uniform attention over zero logits
+        with torch.no_grad():
+            emb = vit.forward_mask(preprocess_np(frames), torch.from_numpy(masks))
+            att = vit.get_last_selfattention(preprocess_np(frames), cls_mask=torch.from_numpy(masks))
+        out[tag + "_masks"] = masks
+        out[tag + "_emb"] = emb.numpy()
+        out[tag + "_attn"] = att.numpy()
+    save("g11_forward_mask", **out)
+
+
+ALL = {"G11": g11, "G10": g10, "G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

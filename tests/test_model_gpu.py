@@ -264,3 +264,25 @@ def test_training_step_ragged_batch(cuda):
     for k, p in m.named_parameters():
         gn = float(W[k].grad.norm())
         assert float((p.grad.cpu() - W[k].grad).abs().max()) <= 3e-3 * gn + 1e-7, k
+
+
+def test_g11_forward_mask(cuda, golden_dir):
+    """model.dino.forward_mask(x, cls_mask) / get_last_selfattention(x, cls_mask) against the reference ViT's outputs
+    (vision_transformer.py:250-280): masks multiply the CLS logits (all-ones, random and all-zero masks in the fixture)."""
+    g = load(golden_dir, "g11_forward_mask")
+    for tag, cfg, r in (("tiny_r64", ViTConfig(embed_dim=128, num_heads=2, n_blocks=2), 64), ("vits8_L3_r96", ViTConfig(n_blocks=3), 96)):
+        m = DINOSeg(head="mlp", n_blocks=cfg.n_blocks, precision="bf16x3", arch=cfg)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in procedural_state_dict(cfg).items()}, strict=True)
+        m.to("cuda:0")
+        x = O.preprocess(synthetic_frames(1, r, seed=111 + r)).cuda()
+        masks = torch.from_numpy(g[tag + "_masks"])
+        emb = m.dino.forward_mask(x, masks).cpu()
+        att = m.dino.get_last_selfattention(x, cls_mask=masks).cpu()
+        ref_e, ref_a = torch.from_numpy(g[tag + "_emb"]), torch.from_numpy(g[tag + "_attn"])
+        assert emb.shape == ref_e.shape and att.shape == ref_a.shape
+        print(tag, float((emb - ref_e).abs().max()), float((att - ref_a).abs().max()))
+        assert float((emb - ref_e).abs().max()) <= TOL and float((att - ref_a).abs().max()) <= 1e-4
+        full = m.dino.get_last_selfattention(x).cpu()           # the all-ones mask leaves the CLS row's logits... except its own key
+        assert full.shape == (1, cfg.num_heads, (r // 8) ** 2 + 1, (r // 8) ** 2 + 1)
+    with pytest.raises(ValueError):
+        m.forward_mask(x, torch.zeros((2, 3, 3)))

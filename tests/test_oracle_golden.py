@@ -144,3 +144,17 @@ def test_metrics_from_confusion_match_sklearn():
         assert abs(m["val_acc"] - balanced_accuracy_score(gt, pred)) <= 1e-12
         assert abs(m["val_F1"] - f1_score(gt, pred, average="macro")) <= 1e-12
         assert abs(m["val_iou"] - jaccard_score(gt, pred, average="macro")) <= 1e-12
+
+
+def test_g11_forward_mask(golden_dir):
+    """forward_mask / get_last_selfattention(x, cls_mask) of the reference ViT (vision_transformer.py:250-280) vs the oracle."""
+    from dino_amd.weights import ViTConfig
+    g = np.load(os.path.join(golden_dir, "g11_forward_mask.npz"))
+    for tag, cfg, r in (("tiny_r64", ViTConfig(embed_dim=128, num_heads=2, n_blocks=2), 64), ("vits8_L3_r96", ViTConfig(n_blocks=3), 96)):
+        W = O.to_torch(procedural_state_dict(cfg))
+        x = O.preprocess(synthetic_frames(1, r, seed=111 + r))
+        m = torch.from_numpy(g[tag + "_masks"])
+        emb = O.forward_mask(x, W, cfg.num_heads, m)
+        att = O.forward_mask(x, W, cfg.num_heads, m, return_attention=True)
+        assert float((emb - torch.from_numpy(g[tag + "_emb"])).abs().max()) <= 2e-5
+        assert float((att - torch.from_numpy(g[tag + "_attn"])).abs().max()) <= 1e-5
