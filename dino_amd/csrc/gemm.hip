@@ -273,8 +273,10 @@ int launch_gemm(const GemmParams& p0, hipStream_t s) {
     if (options().gemm_big && gemm_big_supported(p)) {
         // measured on MI355X (tools/bench_ops.py): the 256x384 persistent kernel wins when there are >= 2 tiles per CU
         // or the K loop is long; attn.proj (451 tiles, K = 384) is faster on the 128x128 kernel (tile quantisation)
+        // A small batch (single-frame predict: M = 3601 -> 15 row panels) leaves most CUs without a 256x384 tile:
+        // below 128 tiles the 128x128 kernel has 3-6x more workgroups to spread (fc2 at B = 1: 60 -> 40 us).
         const long tiles = (long)((p.M + 255) / 256) * (p.N / 384);
-        if (options().gemm_big > 1 || tiles >= 512 || p.K >= 1024 || p.K % BK != 0) return launch_gemm_big(p, s);
+        if (options().gemm_big > 1 || p.K % BK != 0 || (tiles >= 128 && (tiles >= 512 || p.K >= 1024))) return launch_gemm_big(p, s);
     }
     return launch_gemm_small(p, s);
 }

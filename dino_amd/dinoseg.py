@@ -323,7 +323,9 @@ class DINOSeg(nn.Module):
             output_size = self.resolution // 8
             low_res = amax.cpu().numpy().astype(np.int64).reshape((output_size, output_size))
             high_res_patch_size = 480 // output_size
-            return np.kron(low_res, np.ones((high_res_patch_size, high_res_patch_size), dtype=int))
+            # == np.kron(low_res, np.ones((k, k), dtype=int)) of the reference (:297-298), 4x cheaper on the host
+            k = high_res_patch_size
+            return np.repeat(np.repeat(low_res, k, axis=0), k, axis=1)
 
     def debug_tokens(self, x: torch.Tensor, block: int) -> torch.Tensor:
         """Token matrix [B, N, D] after prepare_tokens (block=0) or after transformer block `block`."""
