@@ -54,6 +54,12 @@ SIGNATURES = {
     "dinoseg_last_selfattention": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _vp]),
     "dinoseg_op_confusion": (C.c_int, [_fp, _fp, _i64, _i32, _fp, _vp]),
     "dinoseg_forward_mask": (C.c_int, [_vp, _vp, _i32, _i32, _fp, _i32, _fp, _fp, _vp]),
+    "dinoseg_features": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _fp, _vp]),
+    "dinoseg_train_forward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _vp]),
+    "dinoseg_backward": (C.c_int, [_vp, _fp, _vp]),
+    "dinoseg_grad_stages": (C.c_int, [_vp]),
+    "dinoseg_stream_wait_grad_stage": (C.c_int, [_vp, _i32, _vp]),
+    "dinoseg_train_status": (C.c_int, [_vp, C.POINTER(_i32), _vp]),
     "dinoseg_op_resize_u8": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i32, _vp]),
     "dinoseg_bind_grad": (C.c_int, [_vp, C.c_char_p, _fp]),
     "dinoseg_train_step": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _fp, _fp, _vp]),
@@ -117,8 +123,9 @@ def check(rc: int) -> None:
         raise DinosegError(f"dinoseg error {rc}: {msg}")
 
 
-def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def stream_ptr(device=None) -> int:
+    """hipStream_t of torch's current stream on `device` (default: the current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -23,7 +23,24 @@ extern "C" void dinoseg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* dinoseg_last_error(void) { return g_err; }
-extern "C" int dinoseg_version(void) { return 100; }
+extern "C" int dinoseg_version(void) { return 200; }
+
+int device_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        dinoseg_set_error("hipGetDevice failed");
+        return -1;
+    }
+    if (dev >= 0 && dev < 64 && cache[dev].load() > 0) return cache[dev].load();
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+        dinoseg_set_error("hipDeviceGetAttribute(MultiprocessorCount) failed on device %d", dev);
+        return -1;
+    }
+    if (dev >= 0 && dev < 64) cache[dev].store(n);
+    return n;
+}
 
 
 
@@ -88,6 +105,7 @@ extern "C" int dinoseg_create(const dinoseg_config* cfg, dinoseg_handle** out) {
 
 extern "C" int dinoseg_destroy(dinoseg_handle* h) {
     if (!h) return 0;
+    DeviceGuard guard(h);
     if (h->wbuf) (void)hipFree(h->wbuf);
     if (h->pos_cache) (void)hipFree(h->pos_cache);
     if (h->ws) (void)hipFree(h->ws);
@@ -97,6 +115,7 @@ extern "C" int dinoseg_destroy(dinoseg_handle* h) {
         (void)hipEventDestroy(r.b);
     }
     for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
+    for (auto& e : h->stage_ev) (void)hipEventDestroy(e);
     delete h;
     return 0;
 }
@@ -118,6 +137,35 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
     if (!ok) {
         dinoseg_set_error("dinoseg_bind_weight: shape mismatch for '%s'", name);
         return -1;
+    }
+    {
+        // the device that owns the parameters owns the handle: workspace, packed weights and every launch follow it
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, dev_ptr) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+            (void)hipGetLastError();
+            dinoseg_set_error("dinoseg_bind_weight: '%s' is not a device pointer", name);
+            return -1;
+        }
+        if (h->device >= 0 && h->device != attr.device && !h->bound.empty() && h->bound.count(name) == 0) {
+            dinoseg_set_error("dinoseg_bind_weight: '%s' lives on device %d, earlier tensors on device %d", name, attr.device, h->device);
+            return -1;
+        }
+        if (h->device != attr.device) {
+            if (h->device >= 0) {        // model.to(another device): everything the library allocated is on the old one
+                DeviceGuard old(h);
+                if (h->wbuf) (void)hipFree(h->wbuf);
+                if (h->pos_cache) (void)hipFree(h->pos_cache);
+                if (h->ws) (void)hipFree(h->ws);
+                (void)dinoseg_train_release(h);
+                h->wbuf = nullptr; h->pos_cache = nullptr; h->ws = nullptr;
+                h->wbuf_bytes = h->pos_cap = h->ws_bytes = 0;
+                h->ws_B = h->ws_r = h->tws_B = h->tws_r = h->tr_B = -1;
+                h->packed.clear();
+                h->bound.clear();
+                h->grads.clear();
+            }
+            h->device = attr.device;
+        }
     }
     BoundTensor t;
     t.ptr = reinterpret_cast<const float*>(dev_ptr);
@@ -158,6 +206,8 @@ static std::vector<LinSpec> linear_specs(const dinoseg_handle* h) {
 extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     if (!h) return -1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DeviceGuard guard(h);
+    DSEG_TRY(check_stream_device(h, s));
     for (auto& kv : h->expected)
         if (!h->bound.count(kv.first)) {
             dinoseg_set_error("dinoseg_refresh_weights: missing key '%s' (strict load)", kv.first.c_str());
@@ -210,6 +260,7 @@ extern "C" int dinoseg_prepare_resolution(dinoseg_handle* h, int32_t r, void* st
     }
     if (h->pos_r == r) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DeviceGuard guard(h);
     const int o = r / 8, D = h->cfg.embed_dim;
     const size_t need = ((size_t)o * o + 1) * D * sizeof(float);
     if (need > h->pos_cap) {
@@ -298,6 +349,8 @@ struct MaskRequest {            // forward_mask / get_last_selfattention(x, cls_
     int n_masks;
     float* emb_out;
     float* attn_out;
+    float* feat_out;            // dinoseg_features: final-norm tokens [B, N, D] after feat_blocks blocks (0 = all), then stop
+    int feat_blocks;
 };
 
 static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
@@ -320,6 +373,8 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
         return -3;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DeviceGuard guard(h);
+    DSEG_TRY(check_stream_device(h, s));
     DSEG_TRY(dinoseg_prepare_resolution(h, r, stream));
 
     const dinoseg_config& c = h->cfg;
@@ -378,7 +433,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
         }
         if (attn_out && i == c.n_blocks - 1)      // get_last_selfattention: probabilities of the last block, then stop
             return launch_attn_probs(Q, Kb, L.qkv_plane, P, B, H, L.ntok, L.npad, attn_out, s);
-        if (mreq && i == c.n_blocks - 1) {
+        if (mreq && mreq->cls_mask && i == c.n_blocks - 1) {
             // last block with cls_mask (Block.forward, vision_transformer.py:127-140): the CLS token attends through each mask;
             // its residual is repeated once per mask; MLP and the final norm run on those n_masks rows only.  The patch-token
             // rows of X / A / CTX / HB are dead from here on and host the n_masks rows (checked: n_masks < ntok).
@@ -448,7 +503,13 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             DSEG_PROF(DINOSEG_PROF_FC2, DSEG_TRY(launch_gemm(g, s)));
         }
         if (tap_block == i + 1 && tap_out) DSEG_CHECK_HIP(hipMemcpyAsync(tap_out, X, xbytes, hipMemcpyDeviceToDevice, s));
+        if (mreq && mreq->feat_out && mreq->feat_blocks == i + 1 && i + 1 < c.n_blocks)      // forward(x, intermediate=k)
+            return launch_layernorm(X, W(h, "dino.norm.weight"), W(h, "dino.norm.bias"), c.ln_eps, L.M, D, nullptr, 0, 1, mreq->feat_out, 0,
+                                    L.ntok, s);
     }
+    if (mreq && mreq->feat_out)     // VisionTransformer.forward(x, all=True): every token through the final norm, fp32
+        return launch_layernorm(X, W(h, "dino.norm.weight"), W(h, "dino.norm.bias"), c.ln_eps, L.M, D, nullptr, 0, 1, mreq->feat_out, 0,
+                                L.ntok, s);
 
     // ---- final norm, drop CLS (vision_transformer.py:243; pl_torch_modules.py:243,253) ----
     DSEG_PROF(DINOSEG_PROF_LN, DSEG_TRY(launch_layernorm(X, W(h, "dino.norm.weight"), W(h, "dino.norm.bias"), c.ln_eps, L.M, D, FEAT, L.feat_plane,
@@ -509,8 +570,18 @@ extern "C" int dinoseg_forward_mask(dinoseg_handle* h, const void* x, int32_t x_
         dinoseg_set_error("dinoseg_forward_mask: n_masks=%d must be smaller than the token count %d", n_masks, (r / 8) * (r / 8) + 1);
         return -1;
     }
-    const MaskRequest mr = {cls_mask, n_masks, emb_out, attn_out};
+    const MaskRequest mr = {cls_mask, n_masks, emb_out, attn_out, nullptr, 0};
     return forward_impl(h, x, x_kind, 1, r, nullptr, nullptr, -1, nullptr, nullptr, stream, &mr);
+}
+
+extern "C" int dinoseg_features(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, int32_t n_blocks,
+                                float* tokens_out, void* stream) {
+    if (!h || !tokens_out || n_blocks < 0 || n_blocks > h->cfg.n_blocks) {
+        dinoseg_set_error("dinoseg_features: needs an output buffer and 0 <= n_blocks <= %d", h ? h->cfg.n_blocks : 0);
+        return -1;
+    }
+    const MaskRequest mr = {nullptr, 0, nullptr, nullptr, tokens_out, n_blocks};
+    return forward_impl(h, x, x_kind, B, r, nullptr, nullptr, -1, nullptr, nullptr, stream, &mr);
 }
 
 extern "C" int dinoseg_op_resize_u8(const uint8_t* src, int32_t sh, int32_t sw, uint8_t* dst, int32_t dh, int32_t dw, void* stream) {
@@ -541,22 +612,6 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
     }
     if (strcmp(key, "gemm_dbg") == 0) {
         dseg::options().gemm_dbg = value;
-        return 0;
-    }
-    if (strcmp(key, "attn_waves") == 0) {
-        if (value != 4 && value != 8) {
-            dinoseg_set_error("dinoseg_set_option: attn_waves must be 4 or 8");
-            return -1;
-        }
-        dseg::options().attn_waves = value;
-        return 0;
-    }
-    if (strcmp(key, "attn_lsum_valu") == 0) {
-        dseg::options().attn_lsum_valu = value;
-        return 0;
-    }
-    if (strcmp(key, "attn_rows64") == 0) {
-        dseg::options().attn_rows64 = value;
         return 0;
     }
     if (strcmp(key, "attn_variant") == 0) {

@@ -16,8 +16,8 @@
 //
 // VALU diet (the first version was bound by VALU issue, 193 instructions per 64-key tile and wave, MFMA pipe
 // 43 % busy): the running maximum rides in the score accumulator's initial value, the rescale is deferred behind a
-// threshold, and the row sums are an extra ones-vector MFMA -- what is left per tile is 32 v_exp, 16 v_max3 and
-// 16 v_cvt_pk.
+// threshold (VAR bit 0: behind an overflow check on the row sums, no per-tile maximum at all) -- what is left per tile
+// is 32 v_exp, 32 v_add and 16 v_cvt_pk.
 //
 // PLANES = 2 (parity mode): Q, K, V and P are bf16 hi+lo pairs; each product is 3 MFMAs.
 #include <type_traits>
@@ -47,6 +47,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
     const int dbg = DBG ? p.dbg : 0;        // timing ablations are compiled out of the production instantiation
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = PLANES * 2 * KV_TILE;   // per plane: K slab + V slab
+    static_assert(NW * 4096 <= STAGE_BYTES, "the O-store epilogue gives every wave a 4 KiB patch of one ring slot");
     // (a 3-slot ring with counted vmcnt measured 4 % slower: LDS 48 KiB per workgroup and a dynamic slot index)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -126,14 +127,12 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
     // Softmax state.  m_run is the (log2-domain) reference each row's scores are measured against; it enters the
     // score MFMA chain as the accumulator's initial value (negm = -m_run in all 16 registers), so S' = S - m_run
     // costs no VALU.  m_run moves only when a row maximum exceeds it by more than RESCALE_THR (rare after the first
-    // tiles), so the O / l rescale is off the steady-state path.  l is summed by the matrix core (ones . P^T).
+    // tiles), so the O / l rescale is off the steady-state path.
     constexpr float RESCALE_THR = 16.f;     // P <= 2^16: far from fp32 / bf16 overflow
     f32x16 negm;
 #pragma unroll
     for (int r = 0; r < 16; ++r) negm[r] = 0.f;
     float m_run = 0.f, l_run = 0.f;
-    const uint4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
     // K/V tiles are double-buffered in LDS: tile t+1 is in flight (LDS-DMA) while tile t is multiplied.
     const int ntiles = (ntok + KB - 1) / KB;
@@ -274,20 +273,9 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
                 if (PLANES == 2) pf[PLANES - 1][kb * 2 + s2] = __builtin_bit_cast(bf16x8, lo);
             }
 
-        // ---- row sums: on the VALU (in-lane partial sums, halves joined at the end), or ones[32 x 16] . P^T on the matrix core
-        if (p.lsum_valu) {
-            l_run += ps;
-        } else {
-            f32x16 lsum;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) lsum[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                lsum = mfma32(ones, pf[0][ks], lsum);
-                if (PLANES == 2) lsum = mfma32(ones, pf[PLANES - 1][ks], lsum);
-            }
-            l_run += lsum[0];
-        }
+        // ---- row sums on the VALU: in-lane partial sums of the fp32 probabilities, the two lane halves are joined at the end
+        // (a ones-vector MFMA for the sums measured 5-7 % slower: the matrix pipe is the scarce unit)
+        l_run += ps;
 
         // ---- O^T[d][q] += V^T . P^T  (V^T fragments by transposing LDS reads) ----
         if (!(dbg & 4))
@@ -318,7 +306,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
     }
 
     // ---- normalise and write ctx[b*ntok + q][head*64 + d] ----
-    const float l_tot = p.lsum_valu ? l_run + __shfl_xor(l_run, 32) : l_run;     // the MFMA row sum already covers both halves
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int b = pair / p.heads, head = pair - b * p.heads;
     const int dm = p.heads * 64;
@@ -373,8 +361,6 @@ static int launch_attn(const AttnParams& p, hipStream_t s) {
 
 template <int PLANES>
 static int launch_attn_planes(const AttnParams& p, hipStream_t s) {
-    const int nw = options().attn_waves;        // query rows per workgroup = 32 * waves (K/V bytes per FLOP ~ 1 / waves)
-    if (nw == 8) return launch_attn<PLANES, 8, false, 0>(p, s);
     switch (options().attn_variant & 3) {
         case 1: return launch_attn<PLANES, 4, false, 1>(p, s);
         case 2: return launch_attn<PLANES, 4, false, 2>(p, s);
@@ -386,14 +372,11 @@ static int launch_attn_planes(const AttnParams& p, hipStream_t s) {
 int launch_attention(const AttnParams& p0, hipStream_t s) {
     AttnParams p = p0;
     p.dbg = options().attn_dbg;
-    p.lsum_valu = options().attn_lsum_valu;
     if (p.npad % KB != 0 || p.npad < p.ntok) {
         dinoseg_set_error("attention: npad=%d must be a multiple of 64 and >= ntok=%d", p.npad, p.ntok);
         return -1;
     }
     if (p.dbg != 0 && p.planes == 1) return launch_attn<1, 4, true, 0>(p, s);      // ablation build (tools/bench_ops.py)
-    if (p.planes == 1 && options().attn_rows64 && options().attn_waves == 4) return launch_attention64(p, s);
-    if (p.planes == 1 && (options().attn_variant & 4) && options().attn_waves == 4) return launch_attention_pipe(p, s);
     if (p.planes == 1) return launch_attn_planes<1>(p, s);
     if (p.planes == 2) return launch_attn_planes<2>(p, s);
     dinoseg_set_error("attention: planes must be 1 or 2");

@@ -417,13 +417,12 @@ static int launch_bwd(const AttnBwdParams& p, hipStream_t s) {
     const int grid = ((npairs + 7) / 8) * 8 * nq;
     const size_t lds_dq = (size_t)2 * PLANES * 2 * BKV_TILE;
     const size_t lds_dkv = (size_t)2 * (PLANES * 2 * BKV_TILE + 512);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce once;
+    if (once.first()) {
         DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<PLANES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
         DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<PLANES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
-        attr_done = true;
     }
     const long rows = (long)p.B * p.heads * p.npad;
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p.dO, p.O, p.dO_plane, PLANES,

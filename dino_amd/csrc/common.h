@@ -119,7 +119,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }  // namespace dseg
 
 // ---- host-side error plumbing shared by all translation units ----
+#include <atomic>
+// hipFuncSetAttribute (the > 64 KiB dynamic-LDS opt-in) and the CU count are per device: once-flags keyed by ordinal
+struct PerDeviceOnce {
+    std::atomic<bool> done[64];
+    PerDeviceOnce() { for (auto& d : done) d.store(false); }
+    // true exactly once per device (callers then do the per-device setup); devices beyond the table always set up again
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        return !done[d].exchange(true);
+    }
+};
 extern "C" void dinoseg_set_error(const char* fmt, ...);
+// compute units of the current device (cached per ordinal); <= 0 on failure with the error message set
+int device_cu_count();
 #define DSEG_CHECK_HIP(expr)                                                                  \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \

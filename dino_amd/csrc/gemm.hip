@@ -255,12 +255,10 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     const int nbn = p.N / BN, nbm = (p.M + BM - 1) / BM;
     const int grid = ((nbm + 7) / 8) * 8 * nbn;
     const size_t lds = (size_t)PLANES * 2 * 2 * TILE_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce once;
+    if (once.first())
         DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<PLANES, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
     hipLaunchKernelGGL((gemm_nt_kernel<PLANES, EPI>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3(256), lds, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;

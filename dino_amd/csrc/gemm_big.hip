@@ -353,14 +353,12 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
 
 template <int EPI, class C>
 static int launch_big_cfg(const GemmParams& p, hipStream_t s) {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        DSEG_CHECK_HIP(hipGetDevice(&dev));
-        DSEG_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    static PerDeviceOnce once;
+    if (once.first())
         DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<EPI, C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    }
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return -2;
     const int nbn = p.N / C::BN, nbm = (p.M + C::BM - 1) / C::BM;
     // persistent workgroups: WGS per CU, a multiple of the 8 XCDs; no more per XCD than it has (panel, bn) pairs
     int per_xcd = ncu / 8 * C::WGS;

@@ -167,12 +167,10 @@ int launch_gemm_tn(const TnParams& p, hipStream_t s) {
     if (p.planes == 1) {
         hipLaunchKernelGGL(gemm_tn_kernel<1>, dim3(tiles, p.ksplit), dim3(256), lds, s, p);
     } else {
-        static bool attr = false;
-        if (!attr) {
+        static PerDeviceOnce once;
+        if (once.first())
             DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<2>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr = true;
-        }
         hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(tiles, p.ksplit), dim3(256), lds, s, p);
     }
     DSEG_CHECK_HIP(hipGetLastError());

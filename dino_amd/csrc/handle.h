@@ -32,6 +32,7 @@ struct PackedLinear {       // W[N,K] operand planes of one nn.Linear, padded to
 struct dinoseg_handle {
     dinoseg_config cfg;
     int planes;
+    int device = -1;            // ordinal of the GPU that owns the bound tensors (set by the first dinoseg_bind_weight)
     std::map<std::string, BoundTensor> bound;
     std::map<std::string, std::vector<int64_t>> expected;
     // packed weights (library-owned)
@@ -53,6 +54,11 @@ struct dinoseg_handle {
     char* tws = nullptr;                   // training workspace: saved activations + backward scratch
     size_t tws_bytes = 0;
     int tws_B = -1, tws_r = -1;
+    int tr_B = -1, tr_r = -1;              // batch / resolution of the saved forward dinoseg_backward will differentiate
+    // gradient-stage events of the last backward (dinoseg_stream_wait_grad_stage): stage 0 = head, 1 + k = final norm and block
+    // n_blocks-1-k, n_blocks + 1 = embeddings; stage_done = number of stages the last backward recorded
+    std::vector<hipEvent_t> stage_ev;
+    int stage_done = 0;
     char* twbuf = nullptr;                 // transposed packed weights for the input-gradient GEMMs
     size_t twbuf_bytes = 0;
     int prof_level = 0;                    // 0 off, 1 attention only, 2 every class
@@ -60,6 +66,33 @@ struct dinoseg_handle {
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
 };
+
+// Every entry point that takes a handle runs on the handle's device, whatever the caller's current device is (the reference's
+// model.to('cuda:1') pattern leaves the current device at 0): allocations, hipFuncSetAttribute and launches all follow it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const dinoseg_handle* h) {
+        if (!h || h->device < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+// a non-default stream must live on the handle's device: a launch on another device's stream with this device's pointers faults
+static inline int check_stream_device(const dinoseg_handle* h, hipStream_t s) {
+    if (!h || h->device < 0 || s == nullptr) return 0;
+    hipDevice_t d = -1;
+    if (hipStreamGetDevice(s, &d) != hipSuccess) return 0;      // legacy / per-thread default stream handles
+    if ((int)d != h->device) {
+        dinoseg_set_error("stream belongs to device %d but the model's tensors live on device %d", (int)d, h->device);
+        return -1;
+    }
+    return 0;
+}
 
 static inline int prof_begin(dinoseg_handle* h, int cat, hipStream_t s) {
     if (h->prof_level == 0 || (h->prof_level == 1 && cat != DINOSEG_PROF_ATTN)) return -1;

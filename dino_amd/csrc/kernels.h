@@ -53,12 +53,8 @@ struct Options {
     int gemm_big = 1;        // use gemm_big.hip where it applies
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
     int attn_dbg = 0;        // same for AttnParams::dbg
-    int attn_waves = 4;      // waves (x 32 query rows) per attention-forward workgroup: 4 or 8
-    int attn_rows64 = 0;     // bf16 mode: use the 64-rows-per-wave kernel (attention64.hip); measured 2 % slower
-    int attn_lsum_valu = 1;  // softmax row sums on the VALU (1, measured 5-7 % faster: the chip is power-limited, MFMAs are
-                             // the expensive instructions) or as a ones-vector MFMA (0)
     int attn_variant = 3;    // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
-                             // tile work; bit 2 (bf16 mode): software-pipelined kernel attention_pipe.hip (measured 10 % slower)
+                             // tile work
 };
 Options& options();
 
@@ -69,11 +65,8 @@ struct AttnParams {
     float* lse;                        // optional [B,H,ntok] log2-domain log-sum-exp (for backward), may be null
     int B, heads, ntok, npad, planes;
     int dbg;                           // timing-only ablations: bit0 skip max/exp, bit1 skip steady-state loads, bit2 skip PV
-    int lsum_valu;                     // row sums by VALU adds instead of a ones-vector MFMA
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
-int launch_attention_pipe(const AttnParams& p, hipStream_t s); // bf16 only: software-pipelined across tiles (attention_pipe.hip)
-int launch_attention64(const AttnParams& p, hipStream_t s);   // bf16 only: 64 query rows per wave (attention64.hip)
 
 // fp32 [rows, cols] -> bf16 planes [planes][rows_pad][cols_pad], zero padded
 int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,
@@ -123,8 +116,9 @@ int launch_attention_bwd(const AttnBwdParams& p, hipStream_t s);
 int launch_transpose_planes(const float* src_f32, const bf16_t* src_pl, long src_plane, int ld_src, int M, int C,
                             bf16_t* T, long t_plane, int c_pad, int m_pad, bf16_t* Nout, long n_plane, int ldn,
                             float* colsum, int planes, int drop_cls, int ntok, hipStream_t s);
-int launch_nll_loss_grad(const float* logp, const int64_t* labels, int M, int C, float* loss, bf16_t* dz, long dz_plane,
-                         int ldz, hipStream_t s);
+// labels != null: F.nll_loss (mean over rows whose label is not -100) + d logits; labels == null: d logits from the caller's dlogp
+int launch_nll_loss_grad(const float* logp, const int64_t* labels, const float* dlogp, int M, int C, float* acc, int* flags,
+                         float* loss, bf16_t* dz, long dz_plane, int ldz, hipStream_t s);
 int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int M, int D, float* dx,
                          int accumulate, float* dgamma, float* dbeta, int drop_cls, int ntok, hipStream_t s);
 // Weight gradient on row-major operands (gemm_tn.hip): part[slice][n][k] = sum over the slice's batch rows of Y[m][n] X[m][k]

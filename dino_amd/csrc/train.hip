@@ -88,35 +88,77 @@ int launch_transpose_planes(const float* src_f32, const bf16_t* src_pl, long src
 }
 
 // ------------------------------------------------------------------------------------------------
-// loss = mean_m -logp[m][y_m]  (F.nll_loss, pl_torch_modules.py:265) and its gradient through log_softmax:
-// dz[m][c] = (exp(logp[m][c]) - [c == y_m]) / M, written as hi/lo planes [2][M][ldz] (zero padded columns).
-__global__ __launch_bounds__(256) void nll_loss_grad_kernel(const float* __restrict__ logp, const int64_t* __restrict__ labels,
-                                                            int M, int C, float* __restrict__ loss,
-                                                            bf16_t* __restrict__ dz, long dz_plane, int ldz) {
+// F.nll_loss (pl_torch_modules.py:265; default reduction 'mean', ignore_index = -100) and the backward of log_softmax.
+//   nll_reduce_kernel   : acc[0] += sum over valid rows of -logp[m][y_m];  acc[1] += number of valid rows;
+//                         flags[0] |= 1 when a label is neither in [0, C) nor ignore_index (F.nll_loss raises there;
+//                         the row is then treated as ignored and the caller reads the flag: dinoseg_train_status)
+//   logsoftmax_bwd_kernel: dz[m][c] = dl[m][c] - exp(logp[m][c]) * sum_c dl[m][c], hi/lo planes [2][M][ldz] (zero padded
+//                         columns), where dl is either the caller's d loss / d logp (autograd path, dinoseg_backward) or
+//                         nll_loss's own -[c == y_m] / n_valid (fused path; also finalises loss = acc[0] / acc[1]).
+//                         Both paths go through the same arithmetic, so F.nll_loss(model(x), y).backward() and
+//                         training_step() produce the same d logits bit for bit.
+constexpr int IGNORE_INDEX = -100;
+
+__global__ __launch_bounds__(256) void nll_reduce_kernel(const float* __restrict__ logp, const int64_t* __restrict__ labels, int M,
+                                                         int C, float* __restrict__ acc, int* __restrict__ flags) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    float l = 0.f;
+    float l = 0.f, n = 0.f;
     if (m < M) {
-        const int y = (int)labels[m];
-        const float invM = 1.0f / (float)M;
-        for (int c = 0; c < ldz; ++c) {
-            float g = 0.f;
-            if (c < C) {
-                const float lp = logp[(long)m * C + c];
-                g = (expf(lp) - (c == y ? 1.f : 0.f)) * invM;
-                if (c == y) l = -lp * invM;
-            }
-            const uint32_t hi = pack_bf16x2(g, 0.f);
-            dz[(long)m * ldz + c] = (bf16_t)(hi & 0xFFFF);
-            dz[dz_plane + (long)m * ldz + c] = (bf16_t)(pack_bf16x2(g - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
+        const long y = labels[m];
+        if (y >= 0 && y < C) {
+            l = -logp[(long)m * C + y];
+            n = 1.f;
+        } else if (y != IGNORE_INDEX) {
+            atomicOr(flags, 1);
         }
     }
     l = wave_sum(l);
-    if ((threadIdx.x & 63) == 0 && l != 0.f) atomicAdd(loss, l);
+    n = wave_sum(n);
+    if ((threadIdx.x & 63) == 0 && n != 0.f) {
+        atomicAdd(acc, l);
+        atomicAdd(acc + 1, n);
+    }
 }
 
-int launch_nll_loss_grad(const float* logp, const int64_t* labels, int M, int C, float* loss, bf16_t* dz, long dz_plane,
-                         int ldz, hipStream_t s) {
-    hipLaunchKernelGGL(nll_loss_grad_kernel, dim3((M + 255) / 256), dim3(256), 0, s, logp, labels, M, C, loss, dz, dz_plane, ldz);
+__global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __restrict__ logp, const float* __restrict__ dlogp,
+                                                             const int64_t* __restrict__ labels, const float* __restrict__ acc,
+                                                             int M, int C, float* __restrict__ loss, bf16_t* __restrict__ dz,
+                                                             long dz_plane, int ldz) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (labels && m == 0) *loss = acc[1] > 0.f ? acc[0] / acc[1] : __builtin_nanf("");   // torch: mean over zero rows is nan
+    if (m >= M) return;
+    float rowsum = 0.f, own = 0.f;
+    int y = -1;
+    if (labels) {
+        const long yy = labels[m];
+        if (yy >= 0 && yy < C) {
+            y = (int)yy;
+            own = -1.0f / acc[1];
+            rowsum = own;
+        }
+    } else {
+        for (int c = 0; c < C; ++c) rowsum += dlogp[(long)m * C + c];
+    }
+    for (int c = 0; c < ldz; ++c) {
+        float g = 0.f;
+        if (c < C) {
+            const float dl = labels ? (c == y ? own : 0.f) : dlogp[(long)m * C + c];
+            g = dl - expf(logp[(long)m * C + c]) * rowsum;
+        }
+        const uint32_t hi = pack_bf16x2(g, 0.f);
+        dz[(long)m * ldz + c] = (bf16_t)(hi & 0xFFFF);
+        dz[dz_plane + (long)m * ldz + c] = (bf16_t)(pack_bf16x2(g - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
+    }
+}
+
+int launch_nll_loss_grad(const float* logp, const int64_t* labels, const float* dlogp, int M, int C, float* acc, int* flags,
+                         float* loss, bf16_t* dz, long dz_plane, int ldz, hipStream_t s) {
+    if (labels) {
+        DSEG_CHECK_HIP(hipMemsetAsync(acc, 0, 2 * sizeof(float), s));
+        hipLaunchKernelGGL(nll_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, logp, labels, M, C, acc, flags);
+    }
+    hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3((M + 255) / 256), dim3(256), 0, s, logp, dlogp, labels, acc, M, C, loss, dz, dz_plane,
+                       ldz);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -23,7 +23,7 @@ struct TrainLayout {
     // per block (offsets are for block 0; block l adds l * blk_stride)
     size_t Xin, A1, Q, K, V, LSE, CTX, Xmid, A2, HPRE, HB, blk_stride;
     size_t Xfin, PATCH, FEAT, H1, H2, LOGP, DZ;
-    size_t dX, dA, dXp, G, dCTX, T1, T2, NLSE, NDEL, DPOS, SINK, SPLITK;
+    size_t dX, dA, dXp, G, dCTX, T1, T2, NLSE, NDEL, DPOS, SINK, ACC, SPLITK;
     size_t zero_begin, zero_end;      // Q/K/V of every block (pad rows must be zero)
     size_t total;
     long a_plane, qkv_plane, f_plane, feat_plane, h1_plane, h2_plane, dz_plane, patch_plane, g_plane, t_plane;
@@ -95,6 +95,7 @@ TrainLayout make_train_layout(const dinoseg_handle* h, int B, int r) {
     L.NDEL = take((size_t)B * c.num_heads * L.npad * 4);
     L.DPOS = take((size_t)L.ntok * D * 4);
     L.SINK = take((size_t)4 * 1024 * 4);
+    L.ACC = take(256);        // nll_loss accumulators {sum of -logp[y], valid rows} + sticky bad-label flag (int at +128)
     L.SPLITK = take((size_t)SPLITK_TILES * 128 * 128 * 4);     // split-K partial tiles of the weight gradients
     L.total = off;
     return L;
@@ -206,22 +207,28 @@ extern "C" int dinoseg_op_layernorm_bwd(const float* dy, const float* x, const f
 }
 
 // ------------------------------------------------------------------------------------------------ the step
-extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r,
-                                  const int64_t* labels, float* loss_out, float* logp_out, void* stream) {
-    if (!h || !x || !labels || !loss_out || B <= 0) {
-        dinoseg_set_error("dinoseg_train_step: bad argument");
+// Forward with saved activations (DINOSeg.forward under autograd, pl_torch_modules.py:239-256).  The saved state stays valid
+// until the next call; train_backward_impl consumes it.
+static int train_forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out, hipStream_t s) {
+    if (!h || !x || B <= 0) {
+        dinoseg_set_error("dinoseg_train_forward: bad argument");
         return -1;
     }
     if (r <= 0 || r % 8 != 0) {
         dinoseg_set_error("Resolution should be a multiple of 8.");
         return -1;
     }
+    if (x_kind != DINOSEG_INPUT_U8_HWC && x_kind != DINOSEG_INPUT_F32_CHW) {
+        dinoseg_set_error("dinoseg_train_forward: bad x_kind %d", x_kind);
+        return -1;
+    }
     if (!h->weights_ready) {
-        dinoseg_set_error("dinoseg_train_step: weights not packed (call dinoseg_refresh_weights after binding)");
+        dinoseg_set_error("dinoseg_train_forward: weights not packed (call dinoseg_refresh_weights after binding)");
         return -3;
     }
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    DSEG_TRY(dinoseg_prepare_resolution(h, r, stream));
+    h->tr_B = -1;       // no valid saved forward until this one has been enqueued completely
+    DSEG_TRY(check_stream_device(h, s));
+    DSEG_TRY(dinoseg_prepare_resolution(h, r, reinterpret_cast<void*>(s)));
     const dinoseg_config& c = h->cfg;
     const int D = c.embed_dim, F = D * c.mlp_ratio, P = h->planes, HP = head_planes(), H = c.num_heads, C = c.n_classes;
     const int NB = c.n_blocks;
@@ -244,61 +251,12 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
     if (h->tws_B != B || h->tws_r != r) {
         for (int l = 0; l < NB; ++l)   // Q/K/V pad rows must be zero (never written afterwards)
             DSEG_CHECK_HIP(hipMemsetAsync(ws + L.Q + l * L.blk_stride, 0, L.LSE - L.Q, s));
+        DSEG_CHECK_HIP(hipMemsetAsync(ws + L.ACC, 0, 256, s));
         h->tws_B = B;
         h->tws_r = r;
     }
     auto F32 = [&](size_t o) { return reinterpret_cast<float*>(ws + o); };
     auto B16 = [&](size_t o) { return reinterpret_cast<bf16_t*>(ws + o); };
-
-    // ---- transposed packed weights for dX = dY . W  (weights change every optimiser step: repack)
-    const std::vector<TLin> tspecs = transposed_specs(h);
-    std::map<std::string, TW> tw;
-    {
-        size_t total = 0;
-        for (const TLin& t : tspecs) total += align_up((size_t)t.planes * t.k_pad * t.n_pad * 2, 256);
-        if (total > h->twbuf_bytes) {
-            if (h->twbuf) {
-                DSEG_CHECK_HIP(hipStreamSynchronize(s));
-                DSEG_CHECK_HIP(hipFree(h->twbuf));
-            }
-            h->twbuf = nullptr;
-            DSEG_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&h->twbuf), total));
-            h->twbuf_bytes = total;
-        }
-        size_t off = 0;
-        for (const TLin& t : tspecs) {
-            TW e;
-            e.w = reinterpret_cast<bf16_t*>(h->twbuf + off);
-            e.plane = (long)t.k_pad * t.n_pad;
-            off += align_up((size_t)t.planes * t.k_pad * t.n_pad * 2, 256);
-            // W [N][K] fp32 -> W^T planes [k_pad][n_pad]: "rows" of the source are N, transposed destination rows are K
-            DSEG_TRY(launch_pack_planes_t(W(h, t.wname), t.N, t.K, e.w, e.plane, t.n_pad, t.k_pad, t.planes, s));
-            tw[t.wname] = e;
-        }
-    }
-
-    auto grad = [&](const std::string& name) -> float* {
-        auto it = h->grads.find(name);
-        return it == h->grads.end() ? nullptr : it->second;
-    };
-    auto numel = [&](const std::string& name) {
-        size_t n = 1;
-        for (int64_t d : h->expected.at(name)) n *= (size_t)d;
-        return n;
-    };
-    bool backbone = false;
-    {
-        std::vector<float*> zp;
-        std::vector<long> zn;
-        for (auto& kv : h->grads) {
-            zp.push_back(kv.second);
-            zn.push_back((long)numel(kv.first));
-            if (kv.first.rfind("dino.", 0) == 0) backbone = true;
-        }
-        zp.push_back(loss_out);
-        zn.push_back(1);
-        DSEG_TRY(launch_multi_zero((int)zp.size(), zp.data(), zn.data(), s));      // one launch instead of ~50 memset nodes
-    }
 
     // =============================================================== forward (activations kept)
     float mean255[3], inv255[3];
@@ -374,7 +332,7 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
         }
     }
     float* Xfin = F32(L.Xfin);
-    bf16_t *FEAT = B16(L.FEAT), *H1 = B16(L.H1), *H2 = B16(L.H2), *DZ = B16(L.DZ);
+    bf16_t *FEAT = B16(L.FEAT), *H1 = B16(L.H1), *H2 = B16(L.H2);
     float* LOGP = F32(L.LOGP);
     DSEG_TRY(launch_layernorm(Xfin, W(h, "dino.norm.weight"), W(h, "dino.norm.bias"), c.ln_eps, L.M, D, FEAT, L.feat_plane, HP,
                               nullptr, 1, L.ntok, s));
@@ -402,8 +360,103 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
                                    nullptr, s));
     }
     if (logp_out) DSEG_CHECK_HIP(hipMemcpyAsync(logp_out, LOGP, (size_t)L.Mp * C * 4, hipMemcpyDeviceToDevice, s));
+    h->tr_B = B;
+    h->tr_r = r;
+    return 0;
+}
+
+// Backward of the last train_forward_impl.  Exactly one of (labels, dlogp) is given:
+//   labels : loss = F.nll_loss(logp, labels) (mean over the rows whose label is not -100) -> *loss_out, then backward of it
+//   dlogp  : fp32 [B*n, C] upstream gradient d L / d logp (torch.autograd path)
+// Gradients are written (not accumulated) into the buffers bound with dinoseg_bind_grad.
+static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const float* dlogp, float* loss_out, hipStream_t s) {
+    if (!h || (labels == nullptr) == (dlogp == nullptr) || (labels && !loss_out)) {
+        dinoseg_set_error("dinoseg_backward: needs exactly one of labels (+ loss_out) and dlogp");
+        return -1;
+    }
+    if (h->tr_B <= 0 || !h->tws) {
+        dinoseg_set_error("dinoseg_backward: no saved forward (call dinoseg_train_forward first)");
+        return -3;
+    }
+    if (!h->weights_ready) {
+        dinoseg_set_error("dinoseg_backward: weights were re-bound after the forward; run the forward again");
+        return -3;
+    }
+    const int B = h->tr_B, r = h->tr_r;
+    const dinoseg_config& c = h->cfg;
+    const int D = c.embed_dim, F = D * c.mlp_ratio, P = h->planes, HP = head_planes(), H = c.num_heads, C = c.n_classes;
+    const int NB = c.n_blocks;
+    const bool mlp_head = c.head_kind == DINOSEG_HEAD_MLP;
+    const TrainLayout L = make_train_layout(h, B, r);
+    char* ws = h->tws;
+    auto F32 = [&](size_t o) { return reinterpret_cast<float*>(ws + o); };
+    auto B16 = [&](size_t o) { return reinterpret_cast<bf16_t*>(ws + o); };
+
+    // ---- transposed packed weights for dX = dY . W  (weights change every optimiser step: repack)
+    const std::vector<TLin> tspecs = transposed_specs(h);
+    std::map<std::string, TW> tw;
+    {
+        size_t total = 0;
+        for (const TLin& t : tspecs) total += align_up((size_t)t.planes * t.k_pad * t.n_pad * 2, 256);
+        if (total > h->twbuf_bytes) {
+            if (h->twbuf) {
+                DSEG_CHECK_HIP(hipStreamSynchronize(s));
+                DSEG_CHECK_HIP(hipFree(h->twbuf));
+            }
+            h->twbuf = nullptr;
+            DSEG_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&h->twbuf), total));
+            h->twbuf_bytes = total;
+        }
+        size_t off = 0;
+        for (const TLin& t : tspecs) {
+            TW e;
+            e.w = reinterpret_cast<bf16_t*>(h->twbuf + off);
+            e.plane = (long)t.k_pad * t.n_pad;
+            off += align_up((size_t)t.planes * t.k_pad * t.n_pad * 2, 256);
+            // W [N][K] fp32 -> W^T planes [k_pad][n_pad]: "rows" of the source are N, transposed destination rows are K
+            DSEG_TRY(launch_pack_planes_t(W(h, t.wname), t.N, t.K, e.w, e.plane, t.n_pad, t.k_pad, t.planes, s));
+            tw[t.wname] = e;
+        }
+    }
+
+    auto grad = [&](const std::string& name) -> float* {
+        auto it = h->grads.find(name);
+        return it == h->grads.end() ? nullptr : it->second;
+    };
+    auto numel = [&](const std::string& name) {
+        size_t n = 1;
+        for (int64_t d : h->expected.at(name)) n *= (size_t)d;
+        return n;
+    };
+    bool backbone = false;
+    {
+        std::vector<float*> zp;
+        std::vector<long> zn;
+        for (auto& kv : h->grads) {
+            zp.push_back(kv.second);
+            zn.push_back((long)numel(kv.first));
+            if (kv.first.rfind("dino.", 0) == 0) backbone = true;
+        }
+        if (!zp.empty()) DSEG_TRY(launch_multi_zero((int)zp.size(), zp.data(), zn.data(), s));      // one launch instead of ~50 memset nodes
+    }
+    float* Xfin = F32(L.Xfin);
+    bf16_t *FEAT = B16(L.FEAT), *H1 = B16(L.H1), *H2 = B16(L.H2), *DZ = B16(L.DZ);
+    float* LOGP = F32(L.LOGP);
+    bf16_t* PATCH = B16(L.PATCH);
 
     // =============================================================== backward
+    // stage events: a side stream can start reducing a gradient bucket while the rest of backward still runs
+    h->stage_done = 0;
+    auto stage_mark = [&](int stage) -> int {
+        while ((int)h->stage_ev.size() <= stage) {
+            hipEvent_t ev;
+            DSEG_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            h->stage_ev.push_back(ev);
+        }
+        DSEG_CHECK_HIP(hipEventRecord(h->stage_ev[stage], s));
+        h->stage_done = stage + 1;
+        return 0;
+    };
     float* sink = F32(L.SINK);
     bf16_t *T1 = B16(L.T1), *T2 = B16(L.T2);
 
@@ -471,7 +524,8 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
     };
 
     // ---- loss and d logits (pl_torch_modules.py:264-265)
-    DSEG_TRY(launch_nll_loss_grad(LOGP, labels, L.Mp, C, loss_out, DZ, L.dz_plane, 64, s));
+    DSEG_TRY(launch_nll_loss_grad(LOGP, labels, dlogp, L.Mp, C, F32(L.ACC), reinterpret_cast<int*>(ws + L.ACC + 128), loss_out, DZ,
+                                  L.dz_plane, 64, s));
     const long tpl = L.t_plane;
     float* dX = F32(L.dX);
     float* dA = F32(L.dA);
@@ -508,6 +562,7 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
         if (backbone)
             DSEG_TRY(dgrad(DZ, L.dz_plane, 64, L.Mp, 64, tw.at("clf.layer_1.weight"), D, HP, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
     }
+    DSEG_TRY(stage_mark(0));
     if (!backbone) return 0;      // frozen backbone (freeze_bb, pl_torch_modules.py:434-436): only the head trains
 
     // ---- final norm (CLS rows get no gradient from the head)
@@ -563,6 +618,7 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
         // ---- norm1 (input X_in)
         DSEG_TRY(launch_layernorm_bwd(dA, F32(L.Xin + o), W(h, b + "norm1.weight"), c.ln_eps, L.M, D, dX, 1, gsink(b + "norm1.weight"),
                                       gsink(b + "norm1.bias"), 0, L.ntok, s));
+        DSEG_TRY(stage_mark(1 + (NB - 1 - l)));
     }
 
     // ---- embeddings: tokens = [cls ; conv(patches)] + pos   (vision_transformer.py:224-235)
@@ -577,5 +633,63 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
         DSEG_TRY(launch_transpose_planes(nullptr, PATCH, L.patch_plane, 192, L.Mp, 192, T2, tpl, 256, L.Mppad, nullptr, 0, 0, nullptr, P, 0, 0, s));
         DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, D, 256, 192, P, grad("dino.patch_embed.proj.weight")));
     }
+    return stage_mark(NB + 1);
+}
+
+extern "C" int dinoseg_train_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
+                                     void* stream) {
+    DeviceGuard guard(h);
+    return train_forward_impl(h, x, x_kind, B, r, logp_out, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_backward(dinoseg_handle* h, const float* dlogp, void* stream) {
+    DeviceGuard guard(h);
+    return train_backward_impl(h, nullptr, dlogp, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r,
+                                  const int64_t* labels, float* loss_out, float* logp_out, void* stream) {
+    if (!labels || !loss_out) {
+        dinoseg_set_error("dinoseg_train_step: bad argument");
+        return -1;
+    }
+    DeviceGuard guard(h);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DSEG_TRY(train_forward_impl(h, x, x_kind, B, r, logp_out, s));
+    return train_backward_impl(h, labels, nullptr, loss_out, s);
+}
+
+extern "C" int dinoseg_grad_stages(const dinoseg_handle* h) { return h ? h->cfg.n_blocks + 2 : -1; }
+
+extern "C" int dinoseg_stream_wait_grad_stage(dinoseg_handle* h, int32_t stage, void* stream) {
+    if (!h || stage < 0 || stage >= h->cfg.n_blocks + 2) {
+        dinoseg_set_error("dinoseg_stream_wait_grad_stage: stage out of range");
+        return -1;
+    }
+    if (stage >= h->stage_done) {
+        dinoseg_set_error("dinoseg_stream_wait_grad_stage: the last backward recorded %d stage(s); stage %d was not reached "
+                          "(frozen backbone?)", h->stage_done, stage);
+        return -3;
+    }
+    DeviceGuard guard(h);
+    DSEG_CHECK_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), h->stage_ev[stage], 0));
+    return 0;
+}
+
+extern "C" int dinoseg_train_status(dinoseg_handle* h, int32_t* bad_labels, void* stream) {
+    if (!h || !bad_labels) {
+        dinoseg_set_error("dinoseg_train_status: null argument");
+        return -1;
+    }
+    *bad_labels = 0;
+    if (!h->tws || h->tws_B < 0) return 0;
+    DeviceGuard guard(h);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const TrainLayout L = make_train_layout(h, h->tws_B, h->tws_r);
+    int flag = 0;
+    DSEG_CHECK_HIP(hipMemcpyAsync(&flag, h->tws + L.ACC + 128, sizeof(int), hipMemcpyDeviceToHost, s));
+    DSEG_CHECK_HIP(hipStreamSynchronize(s));
+    if (flag) DSEG_CHECK_HIP(hipMemsetAsync(h->tws + L.ACC + 128, 0, sizeof(int), s));
+    *bad_labels = flag;
     return 0;
 }

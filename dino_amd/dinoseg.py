@@ -9,6 +9,7 @@ the model without a ROCm device raises.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, Optional
 
 import numpy as np
@@ -104,8 +105,10 @@ class _PatchEmbed(nn.Module):
 
 
 class _ViTParams(nn.Module):
-    """Parameter holder with the reference ViT's state_dict names (vision_transformer.py:161-196).
-    It has no forward: the arithmetic lives in libdinoseg_hip.so."""
+    """The backbone as the reference exposes it (``model.dino``): the parameter names of the reference ViT's state_dict
+    (vision_transformer.py:161-196) and its call surface -- ``dino(x)``, ``dino.get_last_selfattention(x)``,
+    ``dino.forward_mask(x, cls_mask)`` -- with the arithmetic in libdinoseg_hip.so.  It holds a weak reference to the
+    owning DINOSeg (which owns the native handle); a detached copy raises instead of computing on stale state."""
 
     def __init__(self, cfg: ViTConfig):
         super().__init__()
@@ -117,10 +120,47 @@ class _ViTParams(nn.Module):
         self.norm = nn.LayerNorm(D, eps=cfg.ln_eps)
         nn.init.trunc_normal_(self.pos_embed, std=0.02)
         nn.init.trunc_normal_(self.cls_token, std=0.02)
-        for m in self.modules():
-            if isinstance(m, nn.Linear):
-                nn.init.trunc_normal_(m.weight, std=0.02)
-                nn.init.zeros_(m.bias)
+        self.apply(self._init_weights)
+        object.__setattr__(self, "_owner_ref", None)
+
+    def _init_weights(self, m):
+        """vision_transformer.py:189-196 (what ``random_init=True`` re-applies, pl_torch_modules.py:181-183)."""
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def _set_owner(self, owner) -> None:
+        object.__setattr__(self, "_owner_ref", weakref.ref(owner))
+
+    def _owner(self):
+        ref = self.__dict__.get("_owner_ref")
+        owner = ref() if ref is not None else None
+        if owner is None:
+            raise capi.DinosegError("this backbone is not attached to a DINOSeg (the native handle lives there)")
+        return owner
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_owner_ref"] = None          # weak references do not pickle / deep-copy; DINOSeg re-links its copy
+        return state
+
+    def forward(self, x: torch.Tensor, all: bool = True, intermediate=False) -> torch.Tensor:
+        """VisionTransformer.forward (vision_transformer.py:237-248): fp32 [B,3,r,r] -> final-norm tokens [B, N, D]
+        (``all=False``: the CLS row [B, D]); ``intermediate=k`` stops after block k."""
+        t = self._owner().features(x, n_blocks=int(intermediate) if intermediate else 0)
+        return t if all else t[:, 0]
+
+    def get_last_selfattention(self, x, cls_mask=None):
+        """vision_transformer.py:273-280; reference call site visualize_attention.py:46."""
+        return self._owner().get_last_selfattention(x, cls_mask)
+
+    def forward_mask(self, x, cls_mask):
+        """vision_transformer.py:250-271."""
+        return self._owner().forward_mask(x, cls_mask)
 
 
 class _MLPHead(nn.Module):
@@ -135,6 +175,24 @@ class _LinearHead(nn.Module):
     def __init__(self, n_classes, input_dim):
         super().__init__()
         self.layer_1 = nn.Linear(input_dim, n_classes)
+
+
+class _DinoSegFunction(torch.autograd.Function):
+    """DINOSeg.forward under autograd: forward = dinoseg_train_forward (activations kept in the library's workspace),
+    backward = dinoseg_backward(d loss / d logp).  The parameters are inputs only so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, model, x, kind, B, r, *params):
+        logp = model._autograd_forward(x, kind, B, r)
+        ctx.model = model
+        ctx.epoch = model._fwd_epoch
+        ctx.params = params
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        grads = ctx.model._autograd_backward(dlogp, ctx.epoch, ctx.params)
+        return (None, None, None, None, None) + grads
 
 
 # --------------------------------------------------------------------------- the model
@@ -192,14 +250,14 @@ class DINOSeg(nn.Module):
         self.clf = (_MLPHead(self.cfg.n_classes, self.cfg.embed_dim) if head == "mlp"
                     else _LinearHead(self.cfg.n_classes, self.cfg.embed_dim))
 
-        import weakref
-        owner = weakref.ref(self)
-        # reference call site: mlp_dino.dino.get_last_selfattention(x)  (visualize_attention.py:46)
-        self.dino.get_last_selfattention = lambda x, cls_mask=None: owner().get_last_selfattention(x, cls_mask)
-        self.dino.forward_mask = lambda x, cls_mask: owner().forward_mask(x, cls_mask)      # vision_transformer.py:250
+        self.dino._set_owner(self)
+        if random_init:         # pl_torch_modules.py:181-183
+            self.dino.apply(self.dino._init_weights)
 
         self._handle: Optional[C.c_void_p] = None
         self._bound_sig = None
+        self._grad_sig = None
+        self._weights_epoch = 0
 
     # ---- plumbing -------------------------------------------------------------------------
     @property
@@ -211,7 +269,33 @@ class DINOSeg(nn.Module):
             raise capi.DinosegError("DINOSeg runs only on a ROCm device (call .to('cuda:0')); there is no CPU path")
 
     def _param_signature(self):
-        return tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items())
+        return (self._weights_epoch,) + tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items())
+
+    def invalidate_weights(self) -> None:
+        """Force a re-pack of the bf16 weight planes on the next call.  In-place edits through ``p.data`` (or any write that
+        does not bump the tensor version counter) are invisible to the automatic check; call this after them."""
+        self._weights_epoch += 1
+
+    def _stream(self) -> int:
+        """hipStream_t of torch's current stream ON THE MODEL'S DEVICE (not the caller's current device)."""
+        return capi.stream_ptr(self.device)
+
+    # the native handle, its bound-pointer signatures and the weak owner link are process state, not model state
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_handle"] = None
+        state["_bound_sig"] = None
+        state["_grad_sig"] = None
+        state.pop("_adam_state", None)
+        state.pop("_grad_bucket_cache", None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._handle = None
+        self._bound_sig = None
+        self._grad_sig = None
+        self.dino._set_owner(self)
 
     def _sync_weights(self) -> None:
         """Create the native handle if needed and (re)bind + repack when any parameter moved or changed."""
@@ -234,7 +318,7 @@ class DINOSeg(nn.Module):
                 raise capi.DinosegError(f"parameter {name} must be contiguous fp32")
             shape = (C.c_int64 * t.dim())(*t.shape)
             capi.check(lib.dinoseg_bind_weight(self._handle, name.encode(), t.data_ptr(), shape, t.dim()))
-        capi.check(lib.dinoseg_refresh_weights(self._handle, capi.stream_ptr()))
+        capi.check(lib.dinoseg_refresh_weights(self._handle, self._stream()))
         self._bound_sig = sig
 
     def set_precision(self, precision: str) -> None:
@@ -274,19 +358,31 @@ class DINOSeg(nn.Module):
         tap = (torch.empty((B * (n + 1), self.cfg.embed_dim), dtype=torch.float32, device=dev)
                if tap_block >= 0 else None)
         capi.check(capi.lib().dinoseg_forward(self._handle, x.data_ptr(), kind, B, r, capi.ptr(logp), capi.ptr(amax),
-                                              tap_block, capi.ptr(tap), capi.stream_ptr()))
+                                              tap_block, capi.ptr(tap), self._stream()))
         return logp, amax, tap
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """fp32 [B,3,r,r] (normalised) -> fp32 [B*(r/8)^2, n_classes] log-probabilities."""
+        """fp32 [B,3,r,r] (normalised) -> fp32 [B*(r/8)^2, n_classes] log-probabilities (pl_torch_modules.py:239-256).
+        With grad enabled and at least one trainable parameter the result carries an autograd graph: its backward calls
+        ``dinoseg_backward`` and hands d loss / d parameter to torch (x itself gets no gradient: the reference never asks)."""
         self._require_gpu()
-        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3]:
-            raise ValueError(f"expected [B,3,r,r], got {tuple(x.shape)}")
-        if x.shape[2] % 8 != 0:
-            raise ValueError("Resolution should be a multiple of 8.")
-        x = x.to(device=self.device, dtype=torch.float32).contiguous()
-        logp, _, _ = self._run(x, capi.INPUT_F32_CHW, x.shape[0], x.shape[2])
+        x, kind, B, r = self._prep_batch(x)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _DinoSegFunction.apply(self, x, kind, B, r, *self.parameters())
+        logp, _, _ = self._run(x, kind, B, r)
         return logp
+
+    def features(self, x: torch.Tensor, n_blocks: int = 0) -> torch.Tensor:
+        """``model.dino(x)``: final-norm tokens fp32 [B, N, D] after `n_blocks` blocks (0 = all), CLS token first
+        (VisionTransformer.forward, vision_transformer.py:237-248).  Inference only (no autograd graph)."""
+        self._require_gpu()
+        x, kind, B, r = self._prep_batch(x)
+        if not 0 <= n_blocks <= self.cfg.n_blocks:
+            raise ValueError(f"intermediate must be in [0, {self.cfg.n_blocks}]")
+        self._sync_weights()
+        out = torch.empty((B, (r // 8) ** 2 + 1, self.cfg.embed_dim), dtype=torch.float32, device=self.device)
+        capi.check(capi.lib().dinoseg_features(self._handle, x.data_ptr(), kind, B, r, n_blocks, out.data_ptr(), self._stream()))
+        return out
 
     @torch.no_grad()
     def forward_frames(self, frames_u8: torch.Tensor, want_logp: bool = True):
@@ -317,7 +413,7 @@ class DINOSeg(nn.Module):
                 self._require_gpu()
                 resized = torch.empty((1, r, r, 3), dtype=torch.uint8, device=self.device)
                 capi.check(capi.lib().dinoseg_op_resize_u8(frames.data_ptr(), raw.shape[0], raw.shape[1], resized.data_ptr(), r, r,
-                                                          capi.stream_ptr()))
+                                                          self._stream()))
                 frames = resized
             _, amax = self.forward_frames(frames, want_logp=False)
             output_size = self.resolution // 8
@@ -347,7 +443,7 @@ class DINOSeg(nn.Module):
         emb = torch.empty((m.shape[0], self.cfg.embed_dim), dtype=torch.float32, device=x.device) if want_emb else None
         att = torch.empty((1, self.cfg.num_heads, m.shape[0], n + 1), dtype=torch.float32, device=x.device) if want_attn else None
         capi.check(capi.lib().dinoseg_forward_mask(self._handle, x.data_ptr(), capi.INPUT_F32_CHW, r, m.data_ptr(), m.shape[0],
-                                                   capi.ptr(emb), capi.ptr(att), capi.stream_ptr()))
+                                                   capi.ptr(emb), capi.ptr(att), self._stream()))
         return emb, att
 
     def forward_mask(self, x: torch.Tensor, cls_mask: torch.Tensor) -> torch.Tensor:
@@ -370,7 +466,7 @@ class DINOSeg(nn.Module):
         N = (r // 8) ** 2 + 1
         out = torch.empty((B, self.cfg.num_heads, N, N), dtype=torch.float32, device=x.device)
         capi.check(capi.lib().dinoseg_last_selfattention(self._handle, x.data_ptr(), capi.INPUT_F32_CHW, B, r, out.data_ptr(),
-                                                         capi.stream_ptr()))
+                                                         self._stream()))
         return out
 
     # ---- validation metrics (pl_torch_modules.py:302-345) ------------------------------------------
@@ -378,15 +474,12 @@ class DINOSeg(nn.Module):
         """Reference: probs = self(x); pred = argmax.  Here the per-batch confusion matrix is accumulated on device."""
         x, y = batch
         with torch.no_grad():
-            if x.dtype == torch.uint8:
-                logp, amax = self.forward_frames(x)
-            else:
-                logp = self.forward(x)
-                amax = logp.argmax(dim=-1).to(torch.int32)
+            xx, kind, B, r = self._prep_batch(x)
+            logp, amax, _ = self._run(xx, kind, B, r, want_logp=True, want_argmax=True)
             y = y.to(self.device).reshape(-1).long().contiguous()
             cm = torch.zeros((self.cfg.n_classes, self.cfg.n_classes), dtype=torch.int64, device=self.device)
             capi.check(capi.lib().dinoseg_op_confusion(amax.data_ptr(), y.data_ptr(), y.numel(), self.cfg.n_classes,
-                                                       cm.data_ptr(), capi.stream_ptr()))
+                                                       cm.data_ptr(), self._stream()))
         return {"pred": amax, "gt": y, "probs": logp, "confusion": cm}
 
     def validation_epoch_end(self, outputs, prefix="val"):
@@ -415,41 +508,109 @@ class DINOSeg(nn.Module):
         return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(capi.PROF_CLASSES)}
 
     # ---- fine-tune step --------------------------------------------------------------------------
-    def _sync_grads(self) -> None:
-        """Bind every trainable parameter's .grad buffer to the native handle (allocating it on first use);
-        parameters with requires_grad=False are unbound = frozen (freeze_bb / unfreeze_bb)."""
+    @staticmethod
+    def grad_stage(name: str, n_blocks: int) -> int:
+        """Backward stage after which the gradient of parameter `name` is final: 0 = head, 1 + k = final norm and block
+        n_blocks-1-k, n_blocks + 1 = embeddings (the order dinoseg_backward produces them; see dinoseg_stream_wait_grad_stage)."""
+        if name.startswith("clf."):
+            return 0
+        if name.startswith("dino.norm."):
+            return 1 if n_blocks > 0 else 1
+        if name.startswith("dino.blocks."):
+            return 1 + (n_blocks - 1 - int(name.split(".")[2]))
+        return n_blocks + 1
+
+    def _grad_buckets(self, slot: str, bucket_bytes: int = 8 << 20):
+        """Flat fp32 gradient buckets (dino_amd.parallel.make_flat_buckets) of the trainable parameters, cached per slot until
+        the trainable set, the device or the bucket size changes."""
+        from .parallel import make_flat_buckets
+        params = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        key = (bucket_bytes,) + tuple((n, p.numel(), str(p.device)) for n, p in params)
+        cache = self.__dict__.setdefault("_grad_bucket_cache", {})
+        if slot not in cache or cache[slot]["key"] != key:
+            cache[slot] = make_flat_buckets(params, lambda n: self.grad_stage(n, self.cfg.n_blocks), bucket_bytes)
+            cache[slot]["key"] = key
+        return cache[slot]
+
+    def grad_buckets(self, bucket_bytes: int = 8 << 20):
+        """The flat buckets behind the parameters' ``.grad`` (list of {'flat', 'names', 'stage'}, reverse registration order)."""
+        self._bucket_bytes = bucket_bytes
+        return self._grad_buckets("grad", bucket_bytes)["buckets"]
+
+    def stream_wait_grad_stage(self, stage: int, stream) -> None:
+        """Make `stream` (a torch.cuda.Stream on the model's device) wait for backward stage `stage` of the last step."""
+        capi.check(capi.lib().dinoseg_stream_wait_grad_stage(self._handle, int(stage), stream.cuda_stream))
+
+    def _sync_grads(self, slot: str = "grad") -> dict:
+        """Bind the gradient buffers of every trainable parameter to the native handle; parameters with requires_grad=False are
+        unbound = frozen (freeze_bb / unfreeze_bb).  slot 'grad': the buffers ARE the parameters' ``.grad`` (views into the flat
+        buckets); slot 'autograd': private buffers whose contents torch.autograd receives from DINOSeg.forward's backward."""
         lib = capi.lib()
-        sig = []
+        bk = self._grad_buckets(slot, getattr(self, "_bucket_bytes", 8 << 20))
+        sig = [slot]
         for name, p in self.named_parameters():
             if p.requires_grad:
-                if p.grad is None or p.grad.data_ptr() == 0:
-                    p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                sig.append((name, p.grad.data_ptr()))
+                view = bk["views"][name]
+                if slot == "grad" and (p.grad is None or p.grad.data_ptr() != view.data_ptr()):
+                    p.grad = view
+                sig.append((name, view.data_ptr()))
             else:
                 sig.append((name, None))
         sig = tuple(sig)
-        if sig == getattr(self, "_grad_sig", None):
-            return
-        for name, ptr in sig:
-            capi.check(lib.dinoseg_bind_grad(self._handle, name.encode(), ptr))
-        self._grad_sig = sig
+        if sig != self._grad_sig:
+            for name, ptr in sig[1:]:
+                capi.check(lib.dinoseg_bind_grad(self._handle, name.encode(), ptr))
+            self._grad_sig = sig
+        return bk
 
-    def training_step(self, batch, batch_idx=0):
-        """Reference semantics (pl_torch_modules.py:261-268): probs = self(x); loss = F.nll_loss(probs, y.reshape(-1)).
-        Forward and backward both run in the native library; on return every trainable parameter's ``.grad`` holds
-        d loss / d parameter of THIS call (overwritten, like zero_grad + backward), so any torch optimiser -- or
-        ``fused_adam_step`` -- can follow.  x: fp32 [B,3,r,r] (normalised) or uint8 [B,r,r,3]; y: int [B, (r/8)^2]."""
-        x, y = batch
-        self._require_gpu()
-        self._sync_weights()
-        self._sync_grads()
+    def _prep_batch(self, x: torch.Tensor):
         dev = self.device
         if x.dtype == torch.uint8:
+            if x.dim() != 4 or x.shape[3] != 3 or x.shape[1] != x.shape[2]:
+                raise ValueError(f"expected uint8 [B,r,r,3], got {tuple(x.shape)}")
             kind, B, r = capi.INPUT_U8_HWC, x.shape[0], x.shape[1]
             x = x.to(dev).contiguous()
         else:
+            if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3]:
+                raise ValueError(f"expected [B,3,r,r], got {tuple(x.shape)}")
             kind, B, r = capi.INPUT_F32_CHW, x.shape[0], x.shape[2]
             x = x.to(device=dev, dtype=torch.float32).contiguous()
+        if r % 8 != 0:
+            raise ValueError("Resolution should be a multiple of 8.")
+        return x, kind, B, r
+
+    def check_labels(self) -> None:
+        """Raise IndexError if a training step since the last check saw a label outside [0, n_classes) other than the
+        ignore_index -100 (F.nll_loss raises at the call; here the row is skipped on device and reported on request, so the
+        step stays asynchronous).  Synchronises the stream; ``fit()`` calls it once per epoch."""
+        if self._handle is None:
+            return
+        bad = C.c_int32(0)
+        capi.check(capi.lib().dinoseg_train_status(self._handle, C.byref(bad), self._stream()))
+        if bad.value:
+            raise IndexError(f"Target out of bounds: labels must be in [0, {self.cfg.n_classes}) or -100 (ignore_index)")
+
+    def training_step(self, batch, batch_idx=0):
+        """The reference's step verbatim (pl_torch_modules.py:261-268): ``probs = self(x); loss = F.nll_loss(probs, y)``.
+        ``loss`` carries an autograd graph whose backward runs in the native library (``loss.backward()`` ACCUMULATES into
+        ``.grad`` like any torch module, so zero_grad / optimizer.step around it work unchanged, Lightning included).
+        ``fused_training_step`` is the same arithmetic without the autograd round trip."""
+        x, y = batch
+        probs = self(x)
+        y = y.to(self.device).reshape((-1,)).long()
+        loss = torch.nn.functional.nll_loss(probs, y)
+        return {"loss": loss, "pred": probs.argmax(dim=-1).detach(), "gt": y, "probs": probs.detach()}
+
+    def fused_training_step(self, batch, batch_idx=0):
+        """zero_grad + forward + F.nll_loss + backward in one native call (``dinoseg_train_step``): on return every trainable
+        parameter's ``.grad`` holds d loss / d parameter of THIS call (overwritten), so ``fused_adam_step`` -- or any torch
+        optimiser -- can follow.  x: fp32 [B,3,r,r] (normalised) or uint8 [B,r,r,3]; y: int [B, (r/8)^2] (-100 = ignored)."""
+        x, y = batch
+        self._require_gpu()
+        self._sync_weights()
+        self._sync_grads("grad")
+        x, kind, B, r = self._prep_batch(x)
+        dev = self.device
         n = (r // 8) ** 2
         y = y.to(dev).reshape(-1).long().contiguous()
         if y.numel() != B * n:
@@ -457,36 +618,66 @@ class DINOSeg(nn.Module):
         loss = torch.zeros((), dtype=torch.float32, device=dev)
         logp = torch.empty((B * n, self.cfg.n_classes), dtype=torch.float32, device=dev)
         capi.check(capi.lib().dinoseg_train_step(self._handle, x.data_ptr(), kind, B, r, y.data_ptr(), loss.data_ptr(),
-                                                 logp.data_ptr(), capi.stream_ptr()))
+                                                 logp.data_ptr(), self._stream()))
+        self._fwd_epoch = getattr(self, "_fwd_epoch", 0) + 1
         return {"loss": loss, "pred": logp.argmax(dim=-1).detach(), "gt": y, "probs": logp}
 
+    def _autograd_forward(self, x: torch.Tensor, kind: int, B: int, r: int) -> torch.Tensor:
+        self._sync_weights()
+        n = (r // 8) ** 2
+        logp = torch.empty((B * n, self.cfg.n_classes), dtype=torch.float32, device=self.device)
+        capi.check(capi.lib().dinoseg_train_forward(self._handle, x.data_ptr(), kind, B, r, logp.data_ptr(), self._stream()))
+        self._fwd_epoch = getattr(self, "_fwd_epoch", 0) + 1
+        return logp
+
+    def _autograd_backward(self, dlogp: torch.Tensor, epoch: int, params):
+        if epoch != getattr(self, "_fwd_epoch", 0):
+            raise RuntimeError("DINOSeg.backward: the activations of this forward were overwritten by a later forward / "
+                               "training step (one saved forward per model; call backward before the next forward)")
+        bk = self._sync_grads("autograd")
+        dlogp = dlogp.to(device=self.device, dtype=torch.float32).contiguous()
+        capi.check(capi.lib().dinoseg_backward(self._handle, dlogp.data_ptr(), self._stream()))
+        by_ptr = {p.data_ptr(): n for n, p in self.named_parameters()}
+        # autograd may keep (not copy) what backward returns: hand out copies, the bound buffers are rewritten next time
+        return tuple(bk["views"][by_ptr[p.data_ptr()]].clone() if p.requires_grad else None for p in params)
+
     def fused_adam_step(self, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=None, grad_scale=1.0) -> None:
-        """Fused Adam / AdamW update of every trainable parameter from its .grad (torch.optim semantics; the
-        flavour follows self.optimizer: AdamW -> decoupled decay 0.01 by default, Adam -> none)."""
-        decoupled = 1 if self.optimizer is torch.optim.AdamW else 0
+        """Fused Adam / AdamW update of every trainable parameter from its .grad (torch.optim semantics, bias-corrected with a
+        step count kept PER PARAMETER like torch; the flavour follows self.optimizer: AdamW -> decoupled decay 0.01 by default,
+        Adam -> none).  Other optimizer classes have no fused kernel: use ``configure_optimizers()`` and torch's step."""
+        if self.optimizer is torch.optim.AdamW:
+            decoupled = 1
+        elif self.optimizer is torch.optim.Adam:
+            decoupled = 0
+        else:
+            raise NotImplementedError(f"fused_adam_step implements torch.optim.Adam and AdamW, not {self.optimizer!r}; "
+                                      "use model.configure_optimizers().step() on the .grad buffers instead")
         if weight_decay is None:
             weight_decay = 0.01 if decoupled else 0.0
         lr = self.lr if lr is None else lr
         state = self.__dict__.setdefault("_adam_state", {})
-        self._adam_t = getattr(self, "_adam_t", 0) + 1
-        ps, gs, ms, vs, ns = [], [], [], [], []
+        groups = {}
         for name, p in self.named_parameters():
             if not p.requires_grad or p.grad is None:
                 continue
-            if name not in state or state[name][0].data_ptr() == 0 or state[name][0].device != p.device:
-                state[name] = (torch.zeros_like(p), torch.zeros_like(p))
-            m, v = state[name]
-            ps.append(p.data_ptr()); gs.append(p.grad.data_ptr()); ms.append(m.data_ptr()); vs.append(v.data_ptr()); ns.append(p.numel())
-        k = len(ps)
-        if k:
+            st = state.get(name)
+            if st is None or st["m"].data_ptr() == 0 or st["m"].device != p.device:
+                st = state[name] = {"m": torch.zeros_like(p), "v": torch.zeros_like(p), "step": 0}
+            st["step"] += 1
+            groups.setdefault(st["step"], []).append((p, st))
+        for step, items in groups.items():      # one launch per distinct step count (one, unless tensors were unfrozen later)
+            k = len(items)
             arr = lambda xs: (C.c_void_p * k)(*xs)
-            capi.check(capi.lib().dinoseg_adam_step_multi(k, arr(ps), arr(gs), arr(ms), arr(vs), (C.c_int64 * k)(*ns), lr, betas[0], betas[1],
-                                                          eps, weight_decay, decoupled, self._adam_t, grad_scale, capi.stream_ptr()))
-        self._bound_sig = None      # weights changed: re-pack on the next forward / training_step
+            capi.check(capi.lib().dinoseg_adam_step_multi(
+                k, arr([p.data_ptr() for p, _ in items]), arr([p.grad.data_ptr() for p, _ in items]),
+                arr([st["m"].data_ptr() for _, st in items]), arr([st["v"].data_ptr() for _, st in items]),
+                (C.c_int64 * k)(*[p.numel() for p, _ in items]), lr, betas[0], betas[1], eps, weight_decay, decoupled, step,
+                grad_scale, self._stream()))
+        self.invalidate_weights()      # weights changed in place through raw pointers: re-pack on the next forward
 
     def fit(self, ck_file_name=None, train_dataloader=None, val_dataloader=None, test_dataloader=None, max_epochs=None):
         """The reference's ``fit`` (pl_torch_modules.py:367-431) without Lightning: freeze / unfreeze the backbone, train
-        ``max_epochs`` epochs with ``training_step`` + the fused optimizer step, validate after every epoch
+        ``max_epochs`` epochs with ``fused_training_step`` + the fused optimizer step, validate after every epoch
         (``check_val_every_n_epoch=1``), keep the checkpoint with the best ``val_acc`` (``ModelCheckpoint(monitor='val_acc',
         mode='max')``) at ``write_path/<ck_file_name>.ckpt`` in the PL-1.5 schema, then run the test split and set
         ``self.best_ck``.  The dataset / augmentation pipeline is out of scope, so the dataloaders are
@@ -511,14 +702,15 @@ class DINOSeg(nn.Module):
         for epoch in range(self.max_epochs if max_epochs is None else max_epochs):
             cms, losses = [], []
             for bi, (x, y) in enumerate(train_dataloader):
-                out = self.training_step((x, y), bi)
+                out = self.fused_training_step((x, y), bi)
                 self.fused_adam_step()
                 losses.append(out["loss"])
                 cm = torch.zeros((self.cfg.n_classes, self.cfg.n_classes), dtype=torch.int64, device=self.device)
                 capi.check(capi.lib().dinoseg_op_confusion(out["pred"].to(torch.int32).contiguous().data_ptr(), out["gt"].data_ptr(),
-                                                           out["gt"].numel(), self.cfg.n_classes, cm.data_ptr(), capi.stream_ptr()))
+                                                           out["gt"].numel(), self.cfg.n_classes, cm.data_ptr(), self._stream()))
                 cms.append({"confusion": cm})
                 step += 1
+            self.check_labels()
             metrics = self.validation_epoch_end(cms, prefix="train") if cms else {}
             metrics["train_loss"] = float(torch.stack(losses).mean()) if losses else float("nan")
             metrics.update(self.validation_epoch_end([self.validation_step(b, i) for i, b in enumerate(val_dataloader)]))

@@ -13,7 +13,7 @@ full mesh busy, and 5 buckets of <= 8 MiB cover the 22.1 MiB of the unfrozen 3-b
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Sequence, Tuple
+from typing import Callable, Iterable, List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -30,6 +30,37 @@ def shard_bounds(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
 def shard_batch(x: torch.Tensor, y: torch.Tensor, rank: int, world: int):
     lo, hi = shard_bounds(x.shape[0], rank, world)
     return x[lo:hi], y[lo:hi]
+
+
+def make_flat_buckets(named_params: Sequence[Tuple[str, torch.Tensor]], stage_of: Callable[[str], int] = None,
+                      bucket_bytes: int = 8 << 20) -> dict:
+    """Flat fp32 gradient buckets with one view per parameter.
+
+    Parameters are taken in REVERSE registration order -- head, final norm + last block, ..., embeddings: the order the
+    backward finishes them -- and packed into flat buffers of at most `bucket_bytes`; every view starts on a 256-byte
+    boundary.  The gradient kernels write straight into the views and the all-reduce works on the flat buffers: no
+    torch.cat, no copy-back.  Returns {'buckets': [{'flat', 'names', 'stage'}], 'views': {name: view}}; 'stage' is the last
+    backward stage any member waits for (DINOSeg.grad_stage / dinoseg_stream_wait_grad_stage)."""
+    groups, cur, size = [], [], 0
+    for n, p in reversed(list(named_params)):
+        padded = (p.numel() + 63) // 64 * 64
+        if cur and (size + padded) * 4 > bucket_bytes:
+            groups.append(cur)
+            cur, size = [], 0
+        cur.append((n, p, size))
+        size += padded
+    if cur:
+        groups.append(cur)
+    buckets, views = [], {}
+    for g in groups:
+        n_last, p_last, off_last = g[-1]
+        flat = torch.zeros(off_last + (p_last.numel() + 63) // 64 * 64, dtype=torch.float32, device=p_last.device)
+        names = []
+        for n, p, off in g:
+            views[n] = flat[off:off + p.numel()].view_as(p)
+            names.append(n)
+        buckets.append({"flat": flat, "names": names, "stage": max(stage_of(n) for n in names) if stage_of else 0})
+    return {"buckets": buckets, "views": views}
 
 
 def make_buckets(named_grads: Sequence[Tuple[str, torch.Tensor]], bucket_bytes: int = 8 << 20) -> List[List[Tuple[str, torch.Tensor]]]:
@@ -70,30 +101,86 @@ def allreduce_gradients(named_grads: Iterable[Tuple[str, torch.Tensor]], world: 
 
 
 class DataParallelFineTuner:
-    """Minimal fine-tune loop body for one rank: shard -> native training_step -> gradient all-reduce -> optimiser.
+    """Fine-tune loop body for one rank: shard -> native fused training step -> bucketed gradient all-reduce overlapped with the
+    rest of backward -> optimiser.
 
     Stands in for the Lightning ``Trainer.fit`` inner loop of the reference (pl_torch_modules.py:365-432), which is out
-    of scope; metrics / checkpointing callbacks are not reproduced."""
+    of scope; metrics / checkpointing callbacks are not reproduced.
 
-    def __init__(self, model, fused_optimizer: bool = True, bucket_bytes: int = 8 << 20):
+    The model's ``.grad`` tensors are views into a few flat buckets (``model.grad_buckets()``).  After the step has been
+    enqueued, each bucket is reduced with ONE collective on a side stream that waits (on the device, not the host) for the
+    backward stage that finishes the bucket -- head first, embeddings last -- so the reduction of the head / last-block
+    buckets runs under the backward of the earlier blocks; the compute stream then waits for the collectives before the
+    optimiser.  ``collective='rs_ag'`` splits each all-reduce into reduce-scatter + all-gather (every rank reduces 1/world of
+    the bucket: on the point-to-point xGMI mesh all 7 links of a GPU carry 1/8 of the bucket per phase instead of a ring's
+    single-link 2*(7/8) of it).  Neither form has been timed on a multi-GPU node from here.
+
+    `model` needs: fused_training_step(batch) -> {'loss': ...}, grad_buckets() -> list of {'flat','names','stage'},
+    stream_wait_grad_stage(stage, stream) (may be a no-op), fused_adam_step(grad_scale=...) or configure_optimizers()."""
+
+    def __init__(self, model, fused_optimizer: bool = True, bucket_bytes: int = 8 << 20, collective: str = "allreduce",
+                 overlap: bool = True, group=None):
+        if collective not in ("allreduce", "rs_ag"):
+            raise ValueError("collective must be 'allreduce' or 'rs_ag'")
         self.model = model
         self.fused = fused_optimizer
         self.bucket_bytes = bucket_bytes
+        self.collective = collective
+        self.overlap = overlap
+        self.group = group
         self.torch_opt = None if fused_optimizer else model.configure_optimizers()
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._comm_stream = None
+        self.last_collectives = 0
+
+    def _reduce_bucket(self, flat: torch.Tensor):
+        """Enqueue the sum-reduction of one flat bucket; returns the async work handles."""
+        if self.collective == "allreduce" or flat.numel() % self.world != 0:
+            return [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        shard = flat.numel() // self.world
+        mine = flat[self.rank * shard:(self.rank + 1) * shard]
+        w1 = dist.reduce_scatter_tensor(mine, flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        w1.wait()        # orders the all-gather behind the reduce-scatter on the current (communication) stream
+        return [dist.all_gather_into_tensor(flat, mine, group=self.group, async_op=True)]
+
+    def reduce_gradients(self) -> None:
+        """Sum the gradient buckets over the ranks (the mean's 1/world is applied by the optimiser step)."""
+        self.last_collectives = 0
+        if self.world == 1:
+            return
+        buckets = self.model.grad_buckets(self.bucket_bytes)
+        on_gpu = buckets and buckets[0]["flat"].is_cuda
+        works = []
+        if on_gpu and self.overlap:
+            dev = buckets[0]["flat"].device
+            if self._comm_stream is None or self._comm_stream.device != dev:
+                self._comm_stream = torch.cuda.Stream(device=dev)
+            for b in buckets:       # reverse registration order = the order backward finishes them
+                self.model.stream_wait_grad_stage(b["stage"], self._comm_stream)
+                with torch.cuda.stream(self._comm_stream):
+                    works += self._reduce_bucket(b["flat"])
+                self.last_collectives += 1
+        else:
+            for b in buckets:
+                works += self._reduce_bucket(b["flat"])
+                self.last_collectives += 1
+        for w in works:
+            w.wait()                # GPU: the compute stream waits for the collective; CPU (gloo): blocks the host
 
     def step(self, x_global: torch.Tensor, y_global: torch.Tensor) -> torch.Tensor:
         x, y = shard_batch(x_global, y_global, self.rank, self.world)
-        out = self.model.training_step((x, y), 0)
-        grads = [(n, p.grad) for n, p in self.model.named_parameters() if p.requires_grad]
-        allreduce_gradients(grads, self.world, self.bucket_bytes)
+        out = self.model.fused_training_step((x, y), 0)
+        self.reduce_gradients()
         if self.fused:
-            self.model.fused_adam_step()
+            self.model.fused_adam_step(grad_scale=1.0 / self.world)
         else:
+            if self.world > 1:
+                for b in self.model.grad_buckets(self.bucket_bytes):
+                    b["flat"].div_(self.world)
             self.torch_opt.step()
         loss = out["loss"].detach().clone()
         if self.world > 1:
-            dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
             loss /= self.world
         return loss

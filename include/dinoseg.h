@@ -95,6 +95,12 @@ int dinoseg_last_selfattention(dinoseg_handle* h, const void* x, int32_t x_kind,
 int dinoseg_forward_mask(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t r, const float* cls_mask, int32_t n_masks,
                          float* emb_out, float* attn_out, void* stream);
 
+/* Replaces VisionTransformer.forward(x, all=True, intermediate=k) (vision_transformer.py:237-248), i.e. `model.dino(x)`:
+ * tokens through n_blocks blocks (0 = all the handle has) and the final LayerNorm, tokens_out fp32 [B, (r/8)^2 + 1, embed_dim]
+ * (row 0 of every frame is the CLS token; DINOSeg.forward takes [:, 1:], pl_torch_modules.py:243). */
+int dinoseg_features(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, int32_t n_blocks,
+                     float* tokens_out, void* stream);
+
 /* Replaces the Resize(r, r) of get_transforms (pl_torch_modules.py:36-38, applied in predict at :291) for frames that are
  * not already r x r: uint8 HWC [sh, sw, 3] -> [dh, dw, 3] on device, restating cv2.resize(INTER_LINEAR)'s fixed-point
  * arithmetic (albumentations 1.1.0 -> opencv 4.5.5, third-party: parity unpinned) so that predict() keeps
@@ -113,11 +119,35 @@ int dinoseg_op_confusion(const int32_t* pred, const int64_t* gt, int64_t n, int3
 int dinoseg_bind_grad(dinoseg_handle* h, const char* name, float* dev_ptr);
 
 /* One training step on this rank's B frames: forward with saved activations, loss = F.nll_loss(log_probs, labels)
- * (mean over B*(r/8)^2 patches; labels int64 on device), backward.  Every bound gradient buffer is OVERWRITTEN with
+ * (mean over the patches whose label is not -100; labels int64 on device), backward.  Every bound gradient buffer is OVERWRITTEN with
  * d loss / d parameter; *loss_out (device float) receives the loss; logp_out (optional) the log-probabilities.
  * Call dinoseg_refresh_weights() after the optimiser changed the parameters. */
 int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, const int64_t* labels,
                        float* loss_out, float* logp_out, void* stream);
+
+/* The two halves of the step, for callers that own the loss (torch.autograd: `loss = F.nll_loss(model(x), y); loss.backward()`,
+ * pl_torch_modules.py:261-266).  dinoseg_train_forward = DINOSeg.forward with the activations kept (logp_out fp32
+ * [B*(r/8)^2, n_classes]); dinoseg_backward takes dlogp = d loss / d log-probabilities (same shape, fp32, device) and
+ * OVERWRITES every bound gradient buffer with d loss / d parameter.  The saved forward stays valid until the next
+ * dinoseg_train_forward / dinoseg_train_step on this handle.  dinoseg_train_step(labels) == train_forward + nll_loss +
+ * backward, through the same kernels (same d logits bit for bit). */
+int dinoseg_train_forward(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out, void* stream);
+int dinoseg_backward(dinoseg_handle* h, const float* dlogp, void* stream);
+
+/* Gradient stages of the backward, for overlapping the data-parallel all-reduce with it (no reference
+ * counterpart: the reference trains on one GPU).  dinoseg_backward / dinoseg_train_step record an event on their stream when the
+ * gradients of a stage are final: stage 0 = head (clf.*), stage 1 + k = dino.norm.* and dino.blocks[n_blocks-1-k].*,
+ * stage n_blocks + 1 = embeddings (cls_token, pos_embed, patch_embed).  dinoseg_grad_stages returns n_blocks + 2;
+ * dinoseg_stream_wait_grad_stage makes `stream` (e.g. the communication stream) wait for stage `stage` of the LAST backward
+ * enqueued on this handle, without blocking the host. */
+int dinoseg_grad_stages(const dinoseg_handle* h);
+int dinoseg_stream_wait_grad_stage(dinoseg_handle* h, int32_t stage, void* stream);
+
+/* Label check of the training steps since the last call.  F.nll_loss ignores rows labelled -100 (ignore_index; the mean is
+ * over the other rows) and raises for any other label outside [0, n_classes): the kernels treat such a row as ignored
+ * and latch a flag; *bad_labels receives it (1 = at least one out-of-range label was seen) and the flag is cleared.
+ * Synchronises `stream`. */
+int dinoseg_train_status(dinoseg_handle* h, int32_t* bad_labels, void* stream);
 
 /* Fused Adam (decoupled = 0: torch.optim.Adam, weight decay added to the gradient) / AdamW (decoupled = 1) update of
  * one tensor; step counts from 1; grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */

@@ -270,9 +270,15 @@ def predict(frame_u8: np.ndarray, W: Dict[str, Tensor], num_heads: int, resoluti
     return np.kron(low, np.ones((k, k), dtype=int))
 
 
-def nll_loss(logp: Tensor, labels: Tensor) -> Tensor:
-    """Mean negative log-likelihood over all B*n patches (F.nll_loss default reduction)."""
-    return -logp.gather(1, labels.reshape(-1, 1).long()).mean()
+def nll_loss(logp: Tensor, labels: Tensor, ignore_index: int = -100) -> Tensor:
+    """F.nll_loss with its defaults (pl_torch_modules.py:265): mean negative log-likelihood over the patches whose label is
+    not `ignore_index` (-100); any other label outside [0, C) is an error, as in torch."""
+    y = labels.reshape(-1).long()
+    keep = y != ignore_index
+    if bool(((y < 0) | (y >= logp.shape[1]))[keep].any()):
+        raise IndexError("Target out of bounds")
+    picked = -logp.gather(1, y.clamp(min=0).reshape(-1, 1)).reshape(-1)
+    return (picked * keep).sum() / keep.sum()
 
 
 def to_torch(state: Dict[str, np.ndarray], requires_grad: bool = False) -> Dict[str, Tensor]:

@@ -399,7 +399,37 @@ def g11():
     save("g11_forward_mask", **out)
 
 
-ALL = {"G11": g11, "G10": g10, "G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
+def g12():
+    """Fine-tune step at the benchmark resolution ("r=480 B=1") and F.nll_loss's ignore_index rows.
+    Separate file so that g6_finetune.npz stays byte-identical."""
+    out = {}
+    cases = (("vits8_L3_r480_B1", ViTConfig(n_blocks=3), 480, 1, 0.0), ("tiny_r64_B2_ignore", TINY, 64, 2, 0.25))
+    for tag, cfg, r, B, ignore_frac in cases:
+        sd = procedural_state_dict(cfg)
+        vit, head = ref_vit(cfg, sd), TorchHead(cfg, sd)
+        vit.train(); head.train()
+        frames = synthetic_frames(B, r, seed=121)
+        labels = synthetic_labels(B, (r // 8) ** 2, cfg.n_classes, seed=122).astype(np.int64)
+        if ignore_frac > 0:
+            drop = np.random.default_rng(123).random(labels.shape) < ignore_frac
+            labels[drop] = -100                                      # F.nll_loss default ignore_index
+            out[f"{tag}/labels"] = labels
+        y = torch.from_numpy(labels).reshape(-1).long()
+        params = {("dino." + k): p for k, p in vit.named_parameters()}
+        params.update({("clf." + k): p for k, p in head.named_parameters()})
+        loss = torch.nn.functional.nll_loss(ref_logp(vit, head, preprocess_np(frames)), y)     # pl_torch_modules.py:261-265
+        loss.backward()
+        out[f"{tag}/loss"] = np.float32(loss.item())
+        for i, (k, p) in enumerate(params.items()):
+            g = p.grad.detach().reshape(-1)
+            idx = _sample_idx(g.numel(), 64, seed=i)
+            out[f"{tag}/gnorm/{k}"] = np.float32(g.norm().item())
+            out[f"{tag}/gidx/{k}"] = idx
+            out[f"{tag}/gval/{k}"] = g[idx].numpy().copy()
+    save("g12_finetune_r480_ignore", **{k.replace("/", "|"): v for k, v in out.items()})
+
+
+ALL = {"G12": g12, "G11": g11, "G10": g10, "G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -256,7 +256,7 @@ def test_training_step_ragged_batch(cuda):
     m.unfreeze_bb()
     frames = synthetic_frames(3, 104, seed=5)
     labels = np.random.default_rng(6).integers(0, 7, (3, 169)).astype(np.int64)
-    out = m.training_step((torch.from_numpy(frames).cuda(), torch.from_numpy(labels).cuda()), 0)
+    out = m.fused_training_step((torch.from_numpy(frames).cuda(), torch.from_numpy(labels).cuda()), 0)
     W = O.to_torch(sd, requires_grad=True)
     loss = O.nll_loss(O.dinoseg_forward(O.preprocess(frames), W, cfg.num_heads), torch.from_numpy(labels))
     loss.backward()
@@ -286,3 +286,64 @@ def test_g11_forward_mask(cuda, golden_dir):
         assert full.shape == (1, cfg.num_heads, (r // 8) ** 2 + 1, (r // 8) ** 2 + 1)
     with pytest.raises(ValueError):
         m.forward_mask(x, torch.zeros((2, 3, 3)))
+
+
+# ------------------------------------------------------------------------------------------------ round 2 additions
+def test_dino_backbone_is_callable(cuda, golden_dir):
+    """model.dino(x)[:, 1:] is how the reference's forward starts (pl_torch_modules.py:243); G1 'final' holds the reference
+    VisionTransformer's output for the tiny ViT."""
+    g = load(golden_dir, "g1_tiny_vit_r64")
+    m, _, _ = build(TINY, "bf16x3")
+    x = O.preprocess(g["frames"]).cuda()
+    tok = m.dino(x)
+    assert tuple(tok.shape) == (2, 65, 128)
+    assert float((tok.cpu() - torch.from_numpy(g["final"])).abs().max()) <= 5e-4
+    assert float((m.dino(x, all=False).cpu() - torch.from_numpy(g["final"])[:, 0]).abs().max()) <= 5e-4
+    # intermediate=k: the final norm applied after k blocks (vision_transformer.py:240-242)
+    W = O.to_torch(procedural_state_dict(TINY))
+    with torch.no_grad():
+        t = O.prepare_tokens(O.preprocess(g["frames"]), W, 8)
+        t = O.block(t, W, 0, TINY.num_heads, 1e-6)
+        want = O.layer_norm(t, W["dino.norm.weight"], W["dino.norm.bias"], 1e-6)
+    assert float((m.dino(x, intermediate=1).cpu() - want).abs().max()) <= 5e-4
+    with pytest.raises(ValueError):
+        m.dino(x, intermediate=5)
+
+
+def test_model_copies_and_pickles_without_the_native_handle(cuda, tmp_path):
+    import copy
+    import pickle
+    m, _, _ = build(TINY, "bf16x3")
+    frames = torch.from_numpy(synthetic_frames(2, 64, seed=2)).cuda()
+    lp, _ = m.forward_frames(frames)
+    m2 = copy.deepcopy(m)
+    assert m2._handle is None and m2.dino._owner() is m2 and m.dino._owner() is m
+    with torch.no_grad():
+        m2.clf.layer_3.bias.add_(1.0)            # the copy is independent
+    assert torch.equal(m.forward_frames(frames)[0], lp)
+    assert not torch.equal(m2.forward_frames(frames)[0], lp)
+    blob = pickle.dumps(m)
+    m3 = pickle.loads(blob)
+    assert torch.equal(m3.forward_frames(frames)[0], lp)
+    torch.save(m, tmp_path / "whole_model.pt")
+    m4 = torch.load(tmp_path / "whole_model.pt", weights_only=False)
+    assert torch.equal(m4.dino.get_last_selfattention(O.preprocess(frames.cpu().numpy())[:1].cuda()),
+                       m.dino.get_last_selfattention(O.preprocess(frames.cpu().numpy())[:1].cuda()))
+    # p.data edits do not bump the version counter: invalidate_weights() makes them visible
+    m.clf.layer_3.bias.data.add_(1.0)
+    m.invalidate_weights()
+    assert not torch.equal(m.forward_frames(frames)[0], lp)
+
+
+def test_g4_960_batch8_frames_are_independent(cuda):
+    """@960 (14 401 tokens) at the BASELINE batch of 8 in the benchmark precision: every frame of the batch gets what it gets
+    alone (frames are independent: pl_torch_modules.py:253 flattens them), outputs are finite and the library's argmax is
+    torch's first-max argmax."""
+    m, _, _ = build(3, "bf16")
+    m.set_resolution(960)
+    frames = torch.from_numpy(synthetic_frames(8, 960, seed=40)).cuda()
+    lp, am = m.forward_frames(frames)
+    assert torch.isfinite(lp).all() and torch.equal(am.long(), lp.argmax(1))
+    for i in (0, 5, 7):
+        lp1, am1 = m.forward_frames(frames[i:i + 1])
+        assert torch.equal(lp[i * 14400:(i + 1) * 14400], lp1) and torch.equal(am[i * 14400:(i + 1) * 14400], am1)

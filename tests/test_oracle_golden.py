@@ -116,6 +116,30 @@ def test_g6_finetune_gradients(golden_dir):
             assert float((gv[idx] - torch.from_numpy(g[f"{tag}|gval|{k}"])).abs().max()) <= 2e-4 * gn + 1e-7, k
 
 
+def test_g12_finetune_r480_and_ignore_index(golden_dir):
+    """G12: the fine-tune step at the benchmark resolution (B=1, 3601 tokens) and with F.nll_loss's ignore_index rows."""
+    g = load(golden_dir, "g12_finetune_r480_ignore")
+    for tag, cfg, r, B in (("vits8_L3_r480_B1", ViTConfig(n_blocks=3), 480, 1), ("tiny_r64_B2_ignore", TINY, 64, 2)):
+        sd = procedural_state_dict(cfg)
+        W = O.to_torch(sd, requires_grad=True)
+        frames = synthetic_frames(B, r, seed=121)
+        key = f"{tag}|labels"
+        labels = torch.from_numpy(g[key] if key in g.files else synthetic_labels(B, (r // 8) ** 2, cfg.n_classes, seed=122))
+        if key in g.files:
+            assert int((labels == -100).sum()) > 10
+        loss = O.nll_loss(O.dinoseg_forward(O.preprocess(frames), W, cfg.num_heads), labels)
+        loss.backward()
+        assert abs(float(loss) - float(g[f"{tag}|loss"])) <= 2e-5
+        for k, p in W.items():
+            gv = p.grad.reshape(-1)
+            gn = float(g[f"{tag}|gnorm|{k}"])
+            assert abs(float(gv.norm()) - gn) <= 1e-4 * gn + 1e-7, k
+            idx = torch.from_numpy(g[f"{tag}|gidx|{k}"])
+            assert float((gv[idx] - torch.from_numpy(g[f"{tag}|gval|{k}"])).abs().max()) <= 2e-4 * gn + 1e-7, k
+    with pytest.raises(IndexError):
+        O.nll_loss(torch.zeros(4, 7), torch.tensor([0, 7, 1, 2]))
+
+
 def test_g10_last_selfattention(golden_dir):
     g = load(golden_dir, "g10_last_selfattention")
     W = O.to_torch(procedural_state_dict(TINY))

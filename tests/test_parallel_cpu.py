@@ -70,3 +70,99 @@ def test_shard_bounds_and_buckets():
     assert sum(len(b) for b in buckets) == 48 and 3 <= len(buckets) <= 6        # 22.1 MiB in <= 8 MiB buckets
     assert buckets[0][0][0] == "clf.layer_3.bias" and buckets[-1][-1][0] == "dino.cls_token"   # reverse order
     assert sum(g.numel() for b in buckets for _, g in b) == 5797903
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DataParallelFineTuner.step itself (world 2, gloo), with a stub model whose fused_training_step is the oracle + torch
+# autograd writing into the flat gradient buckets: after 2 steps every parameter equals the single-process run on the
+# whole batch.  What is under test: sharding, bucket views as .grad, one collective per bucket (both forms), the 1/world
+# scale, the optimiser hand-off.
+class _OracleStubModel:
+    def __init__(self):
+        from oracle import dinoseg_oracle as O
+        self.O = O
+        self.W = O.to_torch(procedural_state_dict(CFG), requires_grad=True)
+        self._bk = None
+        self.waited = []
+
+    def named_parameters(self):
+        return list(self.W.items())
+
+    def grad_buckets(self, bucket_bytes=8 << 20):
+        from dino_amd import DINOSeg
+        from dino_amd.parallel import make_flat_buckets
+        if self._bk is None:
+            self._bk = make_flat_buckets(self.named_parameters(), lambda n: DINOSeg.grad_stage(n, CFG.n_blocks), bucket_bytes)
+            for n, p in self.W.items():
+                p.grad = self._bk["views"][n]
+        return self._bk["buckets"]
+
+    def stream_wait_grad_stage(self, stage, stream):
+        self.waited.append(stage)
+
+    def fused_training_step(self, batch, batch_idx=0):
+        x, y = batch
+        self.grad_buckets(64 << 10)
+        for b in self._bk["buckets"]:
+            b["flat"].zero_()
+        loss = self.O.nll_loss(self.O.dinoseg_forward(self.O.preprocess(x.numpy()), self.W, CFG.num_heads), y)
+        grads = torch.autograd.grad(loss, list(self.W.values()))
+        for (n, p), g in zip(self.W.items(), grads):
+            self._bk["views"][n].copy_(g)
+            assert p.grad.data_ptr() == self._bk["views"][n].data_ptr()
+        return {"loss": loss.detach()}
+
+    def configure_optimizers(self):
+        return torch.optim.SGD(list(self.W.values()), lr=0.05)
+
+
+def _tuner_worker(rank, world, port, tmp, collective):
+    from dino_amd.parallel import DataParallelFineTuner
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    frames = torch.from_numpy(synthetic_frames(4, 32, seed=3))
+    labels = torch.from_numpy(synthetic_labels(4, 16, 7, seed=4))
+    model = _OracleStubModel()
+    tuner = DataParallelFineTuner(model, fused_optimizer=False, bucket_bytes=64 << 10, collective=collective)
+    losses = [float(tuner.step(frames, labels)) for _ in range(2)]
+    if rank == 0:
+        torch.save({"params": {k: v.detach().clone() for k, v in model.W.items()}, "losses": losses,
+                    "n_coll": tuner.last_collectives, "n_buckets": len(model.grad_buckets(64 << 10))},
+                   os.path.join(tmp, f"tuner_{world}_{collective}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("collective", ["allreduce", "rs_ag"])
+def test_fine_tuner_step_world2_equals_single_process(tmp_path, collective):
+    _tuner_worker(0, 1, 0, str(tmp_path), collective)
+    mp.spawn(_tuner_worker, args=(2, _free_port(), str(tmp_path), collective), nprocs=2, join=True)
+    one = torch.load(os.path.join(tmp_path, f"tuner_1_{collective}.pt"))
+    two = torch.load(os.path.join(tmp_path, f"tuner_2_{collective}.pt"))
+    assert two["n_coll"] == two["n_buckets"] >= 2 and one["n_coll"] == 0
+    for a, b in zip(one["losses"], two["losses"]):
+        assert abs(a - b) <= 1e-6 * abs(a) + 1e-7
+    for k, v in one["params"].items():
+        assert float((two["params"][k] - v).abs().max()) <= 2e-6 * (float(v.abs().max()) + 1e-6), k
+
+
+def test_flat_buckets_are_views_in_backward_order():
+    from dino_amd import DINOSeg
+    from dino_amd.parallel import make_flat_buckets
+    cfg = ViTConfig(n_blocks=3)
+    named = [(k, torch.zeros(v.shape)) for k, v in procedural_state_dict(cfg).items()]
+    bk = make_flat_buckets(named, lambda n: DINOSeg.grad_stage(n, 3), 8 << 20)
+    stages = [b["stage"] for b in bk["buckets"]]
+    assert stages == sorted(stages) and stages[-1] == 4 and 3 <= len(stages) <= 6
+    assert bk["buckets"][0]["names"][0] == "clf.layer_3.bias" and bk["buckets"][-1]["names"][-1] == "dino.cls_token"
+    for b in bk["buckets"]:
+        lo, hi = b["flat"].data_ptr(), b["flat"].data_ptr() + b["flat"].numel() * 4
+        assert b["flat"].numel() * 4 <= (8 << 20) + 256
+        for n in b["names"]:
+            v = bk["views"][n]
+            assert lo <= v.data_ptr() < hi and v.data_ptr() % 256 == lo % 256 and v.is_contiguous()
+    assert DINOSeg.grad_stage("clf.layer_1.weight", 3) == 0 and DINOSeg.grad_stage("dino.blocks.2.mlp.fc1.bias", 3) == 1
+    assert DINOSeg.grad_stage("dino.blocks.0.norm1.weight", 3) == 3 and DINOSeg.grad_stage("dino.pos_embed", 3) == 4

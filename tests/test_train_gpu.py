@@ -115,13 +115,13 @@ def test_train_step_matches_reference_gradients(cuda, golden_dir, tag, cfg):
     m.unfreeze_bb()
     frames = torch.from_numpy(synthetic_frames(2, 64, seed=61)).cuda()
     labels = torch.from_numpy(synthetic_labels(2, 64, cfg.n_classes, seed=62)).cuda()
-    out = m.training_step((frames, labels), 0)
+    out = m.fused_training_step((frames, labels), 0)
     assert abs(float(out["loss"]) - float(g[f"{tag}|loss"])) <= 2e-4
     _check_grads(m, g, tag, sd, rel=2e-3)
     # the fp32 CHW entry gives the same gradients as the uint8 entry
     x = O.preprocess(frames.cpu().numpy()).cuda()
     ref = {k: p.grad.clone() for k, p in m.named_parameters()}
-    out2 = m.training_step((x, labels), 0)
+    out2 = m.fused_training_step((x, labels), 0)
     assert abs(float(out2["loss"]) - float(out["loss"])) <= 1e-6
     for k, p in m.named_parameters():
         assert float((p.grad - ref[k]).abs().max()) <= 1e-5 * (float(ref[k].abs().max()) + 1e-6), k
@@ -134,7 +134,7 @@ def test_frozen_backbone_trains_only_the_head(cuda, golden_dir):
     m.freeze_bb()
     frames = torch.from_numpy(synthetic_frames(2, 64, seed=61)).cuda()
     labels = torch.from_numpy(synthetic_labels(2, 64, 7, seed=62)).cuda()
-    out = m.training_step((frames, labels), 0)
+    out = m.fused_training_step((frames, labels), 0)
     assert abs(float(out["loss"]) - float(g["vits8_L3_r64_B2|loss"])) <= 2e-4
     with_grad = [k for k, p in m.named_parameters() if p.grad is not None]
     assert sorted(with_grad) == sorted(k for k in sd if k.startswith("clf."))      # 6 tensors, as the reference (G9)
@@ -154,7 +154,7 @@ def test_two_optimizer_steps_match_reference(cuda, golden_dir, oname, opt, lr):
     labels = torch.from_numpy(synthetic_labels(2, 64, cfg.n_classes, seed=62)).cuda()
     losses = []
     for _ in range(2):
-        out = m.training_step((frames, labels), 0)
+        out = m.fused_training_step((frames, labels), 0)
         losses.append(float(out["loss"]))
         m.fused_adam_step()
     want = g[f"{tag}|{oname}|losses"]
@@ -180,7 +180,7 @@ def test_train_step_linear_head_vs_oracle_autograd(cuda):
     m.unfreeze_bb()
     frames = synthetic_frames(2, 96, seed=8)
     labels = synthetic_labels(2, 144, 7, seed=9)
-    out = m.training_step((torch.from_numpy(frames).cuda(), torch.from_numpy(labels).cuda()), 0)
+    out = m.fused_training_step((torch.from_numpy(frames).cuda(), torch.from_numpy(labels).cuda()), 0)
     W = O.to_torch(sd, requires_grad=True)
     loss = O.nll_loss(O.dinoseg_forward(O.preprocess(frames), W, cfg.num_heads), torch.from_numpy(labels))
     loss.backward()
@@ -216,3 +216,110 @@ def test_fit_loop_keeps_best_checkpoint(cuda, tmp_path):
         assert np.array_equal(m2.predict(frames[4].numpy()), m.predict(frames[4].numpy()))
     with pytest.raises(ValueError):
         m.fit()
+
+
+# ------------------------------------------------------------------------------------------------ round 2 additions
+def test_train_step_r480_matches_reference_gradients(cuda, golden_dir):
+    """G12: the step at the benchmark resolution (B=1, 3601 tokens: ragged flash-backward tiles, split-K weight gradients over
+    57 chunks, pos_embed gradient through the 28 -> 60 bicubic resample) against the reference ViT + torch autograd."""
+    g = load(golden_dir, "g12_finetune_r480_ignore")
+    tag, cfg = "vits8_L3_r480_B1", ViTConfig(n_blocks=3)
+    m, sd = build(cfg)
+    m.unfreeze_bb()
+    frames = torch.from_numpy(synthetic_frames(1, 480, seed=121)).cuda()
+    labels = torch.from_numpy(synthetic_labels(1, 3600, cfg.n_classes, seed=122)).cuda()
+    out = m.fused_training_step((frames, labels), 0)
+    assert abs(float(out["loss"]) - float(g[f"{tag}|loss"])) <= 2e-4
+    _check_grads(m, g, tag, sd, rel=2e-3)
+
+
+def test_ignore_index_rows_match_reference(cuda, golden_dir):
+    """F.nll_loss's default ignore_index=-100: ignored patches add nothing to the loss or the gradient and the mean is over the
+    others (G12 'tiny_r64_B2_ignore', captured from torch on the reference ViT); other out-of-range labels are reported."""
+    g = load(golden_dir, "g12_finetune_r480_ignore")
+    tag = "tiny_r64_B2_ignore"
+    m, sd = build(TINY)
+    m.unfreeze_bb()
+    frames = torch.from_numpy(synthetic_frames(2, 64, seed=121)).cuda()
+    labels = torch.from_numpy(g[f"{tag}|labels"]).cuda()
+    out = m.fused_training_step((frames, labels), 0)
+    assert abs(float(out["loss"]) - float(g[f"{tag}|loss"])) <= 2e-4
+    _check_grads(m, g, tag, sd, rel=2e-3)
+    m.check_labels()                                   # -100 is not an error
+    bad = labels.clone()
+    bad[0, 3] = 7                                      # n_classes = 7: out of range
+    m.fused_training_step((frames, bad), 0)
+    with pytest.raises(IndexError):
+        m.check_labels()
+    m.check_labels()                                   # the flag is cleared by the read
+
+
+@pytest.mark.parametrize("cfg", [TINY, ViTConfig(n_blocks=3)])
+def test_autograd_forward_backward_equals_fused_step(cuda, cfg):
+    """The reference's own step -- probs = self(x); loss = F.nll_loss(probs, y); loss.backward() (pl_torch_modules.py:261-266) --
+    through torch.autograd gives the gradients of fused_training_step: same kernels, same d logits.  Tensors whose gradient
+    is a plain store are bit-identical; those summed with fp32 atomics (LayerNorm gamma/beta, biases, pos_embed) agree to
+    summation order."""
+    m, sd = build(cfg)
+    m.unfreeze_bb()
+    frames = synthetic_frames(2, 64, seed=61)
+    labels = torch.from_numpy(synthetic_labels(2, 64, cfg.n_classes, seed=62)).cuda()
+    x = O.preprocess(frames).cuda()
+    fused = m.fused_training_step((x, labels), 0)
+    want = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for p in m.parameters():
+        p.grad = None
+    probs = m(x)
+    assert probs.requires_grad and probs.grad_fn is not None
+    loss = torch.nn.functional.nll_loss(probs, labels.reshape(-1))
+    loss.backward()
+    assert abs(float(loss) - float(fused["loss"])) <= 1e-6
+    exact = 0
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        scale = float(want[k].abs().max()) + 1e-12
+        assert float((p.grad - want[k]).abs().max()) <= 2e-5 * scale, k
+        exact += int(torch.equal(p.grad, want[k]))
+    assert exact >= len(want) // 2
+    # .backward() ACCUMULATES like any torch module; training_step() is the same path packaged as the reference's dict
+    out = m.training_step((x, labels), 0)
+    out["loss"].backward()
+    for k, p in m.named_parameters():
+        assert float((p.grad - 2 * want[k]).abs().max()) <= 5e-5 * (float(want[k].abs().max()) + 1e-12), k
+    # a stale graph refuses instead of differentiating the wrong activations
+    stale = torch.nn.functional.nll_loss(m(x), labels.reshape(-1))
+    m.fused_training_step((x, labels), 0)
+    with pytest.raises(RuntimeError):
+        stale.backward()
+    # inference mode: no graph
+    with torch.no_grad():
+        assert not m(x).requires_grad
+    m.freeze_bb()
+    for p in m.clf.parameters():
+        p.requires_grad = False
+    assert not m(x).requires_grad
+
+
+def test_unsupported_optimizer_raises_and_per_parameter_steps(cuda):
+    m, _ = build(TINY, optimizer=torch.optim.SGD, lr=1e-2)
+    m.unfreeze_bb()
+    frames = torch.from_numpy(synthetic_frames(2, 64, seed=61)).cuda()
+    labels = torch.from_numpy(synthetic_labels(2, 64, 7, seed=62)).cuda()
+    m.fused_training_step((frames, labels), 0)
+    with pytest.raises(NotImplementedError):
+        m.fused_adam_step()
+    # Adam with the backbone unfrozen one step later: the late tensors start their own bias correction at step 1 (torch keeps
+    # the step per parameter), so their first update is ~ lr * sign(g) like everybody's first update
+    m2, sd = build(TINY, optimizer=torch.optim.Adam, lr=1e-3)
+    m2.freeze_bb()
+    m2.fused_training_step((frames, labels), 0)
+    m2.fused_adam_step()
+    m2.unfreeze_bb()
+    m2.fused_training_step((frames, labels), 0)
+    g = m2.dino.blocks[0].mlp.fc1.weight.grad.clone()
+    before = m2.dino.blocks[0].mlp.fc1.weight.detach().clone()
+    m2.fused_adam_step()
+    d = (m2.dino.blocks[0].mlp.fc1.weight.detach() - before)
+    big = g.abs() > 0.1 * g.abs().mean()
+    assert float((d[big].abs() - 1e-3).abs().max()) <= 2e-5      # |update| = lr at step 1; the shared-step bug gave ~0.55 lr
+    assert m2._adam_state["clf.layer_1.weight"]["step"] == 2 and m2._adam_state["dino.blocks.0.mlp.fc1.weight"]["step"] == 1

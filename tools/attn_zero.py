@@ -11,11 +11,9 @@ ctx = torch.zeros((1, B * ntok, H * 64), dtype=torch.int16, device="cuda")
 data = {"random": [rand_bf16((1, B, H, npad, 64)) for _ in range(3)], "zeros": [torch.zeros((1, B, H, npad, 64), dtype=torch.int16, device="cuda") for _ in range(3)]}
 res = {}
 for rnd in range(4):
-    for rows64 in (0, 1):
-        lib.dinoseg_set_option(b"attn_rows64", rows64)
-        for name, (q, k, v) in data.items():
-            def run():
-                capi.check(lib.dinoseg_op_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), B*H*npad*64, ctx.data_ptr(), B*ntok*H*64, None, B, H, ntok, npad, 1, capi.stream_ptr()))
-            res.setdefault((rows64, name), []).append(timeit(run, iters=8, warm=2))
+    for name, (q, k, v) in data.items():
+        def run():
+            capi.check(lib.dinoseg_op_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), B*H*npad*64, ctx.data_ptr(), B*ntok*H*64, None, B, H, ntok, npad, 1, capi.stream_ptr()))
+        res.setdefault(name, []).append(timeit(run, iters=8, warm=2))
 for k, v in sorted(res.items()):
     print(k, "median %.1f us" % (sorted(v)[len(v)//2]*1e3))

@@ -68,14 +68,16 @@ def bench_gemm(quick=True):
     lib.dinoseg_set_option(b"gemm_dbg", 0)
 
 
+ATTN_VARIANTS = [int(v) for v in os.environ.get("ATTN_VARIANTS", "3").split(",")]
+
+
 def bench_attn():
     """Interleaved A/B rounds in one process (clocks drift by +-10 % between back-to-back measurements)."""
     lib = capi.lib()
     B, H, ntok = 32, 6, 3601
     npad = (ntok + 63) // 64 * 64
-    base = dict(attn_rows64=0, attn_waves=4, attn_variant=3)
-    variants = [("per-tile (3)", dict(base, attn_variant=3)),
-                ("pipelined (7)", dict(base, attn_variant=7))]
+    base = dict(attn_variant=3)
+    variants = [(f"variant {v}", dict(base, attn_variant=v)) for v in ATTN_VARIANTS]
     for planes in (1, 2):
         q = rand_bf16((planes, B, H, npad, 64))
         k = rand_bf16((planes, B, H, npad, 64))
