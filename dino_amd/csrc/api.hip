@@ -161,6 +161,7 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
                 h->wbuf_bytes = h->pos_cap = h->ws_bytes = 0;
                 h->ws_B = h->ws_r = h->tws_B = h->tws_r = h->tr_B = -1;
                 h->packed.clear();
+                h->packed_slab.clear();
                 h->bound.clear();
                 h->grads.clear();
             }
@@ -214,10 +215,16 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
             return -3;
         }
     const std::vector<LinSpec> specs = linear_specs(h);
+    auto ln_fed = [&](const LinSpec& sp) {        // qkv / fc1: also kept slab-major for the LayerNorm-fused kernel
+        const bool qkv = sp.wname.find("attn.qkv.weight") != std::string::npos;
+        const bool fc1 = sp.wname.find("mlp.fc1.weight") != std::string::npos;
+        return (qkv || fc1) && gemm_ln_supported(sp.K, sp.N, sp.planes, qkv ? EPI_QKV : EPI_GELU, h->cfg.embed_dim);
+    };
     size_t total = 0;
     for (const LinSpec& sp : specs) {
         total += align_up((size_t)sp.planes * sp.n_pad * sp.k_pad * sizeof(bf16_t), 256);
         if (sp.n_pad != sp.N) total += align_up((size_t)sp.n_pad * sizeof(float), 256);
+        if (ln_fed(sp)) total += align_up((size_t)gemm_ln_slab_elems(sp.N, sp.K, sp.planes) * sizeof(bf16_t), 256);
     }
     if (total > h->wbuf_bytes) {
         if (h->wbuf) DSEG_CHECK_HIP(hipFree(h->wbuf));
@@ -242,6 +249,12 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
                                           hipMemcpyDeviceToDevice, s));
         }
         h->packed[sp.wname] = pk;
+        if (ln_fed(sp)) {
+            bf16_t* slab = reinterpret_cast<bf16_t*>(h->wbuf + off);
+            off += align_up((size_t)gemm_ln_slab_elems(sp.N, sp.K, sp.planes) * sizeof(bf16_t), 256);
+            DSEG_TRY(launch_pack_slabs(W(h, sp.wname), sp.N, sp.K, sp.planes, slab, s));
+            h->packed_slab[sp.wname] = slab;
+        }
     }
     h->weights_ready = true;
     h->pos_r = -1;   // pos_embed may have changed (fine-tune)
@@ -418,6 +431,17 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     // ---- transformer blocks (vision_transformer.py:122-140) ----
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
+        const bool fuse_ln = options().gemm_ln != 0;
+        if (fuse_ln && h->packed_slab.count(b + "attn.qkv.weight")) {
+            // LN1 + qkv in one launch: X rows are normalised in the GEMM's prologue, no bf16 A round trip (gemm_ln.hip)
+            LnGemmParams g = {};
+            g.X = X; g.ldx = D; g.gamma = W(h, b + "norm1.weight"); g.beta = W(h, b + "norm1.bias"); g.eps = c.ln_eps;
+            g.W = h->packed_slab.at(b + "attn.qkv.weight"); g.bias = W(h, b + "attn.qkv.bias");
+            g.M = L.M; g.N = 3 * D; g.epi = EPI_QKV;
+            g.q = Q; g.k = Kb; g.v = V; g.qkv_plane = L.qkv_plane;
+            g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
+            DSEG_PROF(DINOSEG_PROF_QKV, DSEG_TRY(launch_gemm_ln(g, D, P, s)));
+        } else {
         DSEG_PROF(DINOSEG_PROF_LN, DSEG_TRY(launch_layernorm(X, W(h, b + "norm1.weight"), W(h, b + "norm1.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
                                   nullptr, 0, L.ntok, s)));
         {
@@ -430,6 +454,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.q = Q; g.k = Kb; g.v = V; g.qkv_plane = L.qkv_plane;
             g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
             DSEG_PROF(DINOSEG_PROF_QKV, DSEG_TRY(launch_gemm(g, s)));
+        }
         }
         if (attn_out && i == c.n_blocks - 1)      // get_last_selfattention: probabilities of the last block, then stop
             return launch_attn_probs(Q, Kb, L.qkv_plane, P, B, H, L.ntok, L.npad, attn_out, s);
@@ -480,6 +505,14 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.out_f32 = X; g.ldo_f32 = D;
             DSEG_PROF(DINOSEG_PROF_PROJ, DSEG_TRY(launch_gemm(g, s)));
         }
+        if (fuse_ln && h->packed_slab.count(b + "mlp.fc1.weight")) {
+            LnGemmParams g = {};
+            g.X = X; g.ldx = D; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
+            g.W = h->packed_slab.at(b + "mlp.fc1.weight"); g.bias = W(h, b + "mlp.fc1.bias");
+            g.M = L.M; g.N = F; g.epi = EPI_GELU;
+            g.out_bf16 = HB; g.out_plane = L.hb_plane; g.ldo = F;
+            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_gemm_ln(g, D, P, s)));
+        } else {
         DSEG_PROF(DINOSEG_PROF_LN, DSEG_TRY(launch_layernorm(X, W(h, b + "norm2.weight"), W(h, b + "norm2.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
                                   nullptr, 0, L.ntok, s)));
         {
@@ -491,6 +524,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.bias = W(h, b + "mlp.fc1.bias");
             g.out_bf16 = HB; g.out_plane = L.hb_plane; g.ldo = F;
             DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_gemm(g, s)));
+        }
         }
         {
             const PackedLinear& pk = h->packed.at(b + "mlp.fc2.weight");
@@ -606,6 +640,10 @@ Options& options() {
 
 extern "C" int dinoseg_set_option(const char* key, int32_t value) {
     if (!key) return -1;
+    if (strcmp(key, "gemm_ln") == 0) {
+        dseg::options().gemm_ln = value;
+        return 0;
+    }
     if (strcmp(key, "gemm_big") == 0) {
         dseg::options().gemm_big = value;
         return 0;
@@ -697,6 +735,34 @@ extern "C" int dinoseg_op_qkv_gemm(const void* A, int64_t a_plane, const void* W
     g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
     g.qkv_plane = qkv_plane; g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = D; g.qscale = qscale;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t dinoseg_op_ln_gemm_slab_elems(int32_t N, int32_t K, int32_t planes) {
+    return gemm_ln_supported(K, N, planes, EPI_GELU, 0) ? gemm_ln_slab_elems(N, K, planes) : -1;
+}
+
+extern "C" int dinoseg_op_pack_slabs(const float* Wsrc, int32_t N, int32_t K, int32_t planes, void* dst, void* stream) {
+    if (!Wsrc || !dst || !gemm_ln_supported(K, N, planes, EPI_GELU, 0)) {
+        dinoseg_set_error("dinoseg_op_pack_slabs: unsupported shape N=%d K=%d planes=%d", N, K, planes);
+        return -1;
+    }
+    return launch_pack_slabs(Wsrc, N, K, planes, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_ln_gemm(const float* X, const float* gamma, const float* beta, float eps, const void* Wp, int64_t w_plane,
+                                  const float* bias, int32_t M, int32_t N, int32_t K, int32_t planes, int32_t epi, void* out_bf16,
+                                  int64_t out_plane, void* q, void* k, void* v, int64_t qkv_plane, int32_t ntok, int32_t npad,
+                                  int32_t heads, float qscale, void* a_out, void* aux_out, void* stream) {
+    LnGemmParams g = {};
+    g.X = X; g.ldx = K; g.gamma = gamma; g.beta = beta; g.eps = eps;
+    g.W = reinterpret_cast<const bf16_t*>(Wp); g.w_plane = w_plane; g.bias = bias;
+    g.M = M; g.N = N; g.epi = epi;
+    g.out_bf16 = reinterpret_cast<bf16_t*>(out_bf16); g.out_plane = out_plane; g.ldo = N;
+    g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
+    g.qkv_plane = qkv_plane; g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = heads * 64; g.qscale = qscale;
+    g.a_out = reinterpret_cast<bf16_t*>(a_out); g.a_plane = (long)M * K;
+    g.aux_out = reinterpret_cast<bf16_t*>(aux_out); g.aux_plane = out_plane;
+    return launch_gemm_ln(g, K, planes, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int dinoseg_op_attention(const void* q, const void* k, const void* v, int64_t qkv_plane, void* ctx,

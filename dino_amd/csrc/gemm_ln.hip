@@ -1,0 +1,478 @@
+// LayerNorm-fused, A-stationary MFMA GEMM for the two LN-fed layers of a block (K = embed_dim):
+//     qkv = LN1(x) Wqkv^T + b  (vision_transformer.py:123 -> :75,82)      fc1: gelu(LN2(x) W1^T + b)  (:135 -> :60-61)
+//
+// Why: the separate LayerNorm kernel wrote bf16 A (88 MB per launch at B=32) that the 256x384 persistent GEMM then fetched
+// 3-4x from the fabric (one pass per column tile: its 32 workgroups per XCD keep 6 MB of A panels in flight against a 4 MB
+// L2) -- fc1 and qkv ran at 25-27 % of the MFMA peak while moving 5.6 TB/s.  Here a workgroup owns a row panel of X:
+//   * prologue: the panel's fp32 rows are read ONCE (16 B per lane, 16 lanes per row), normalised in registers -- two-pass
+//     statistics, the 16-lane sums by 4 DPP adds (the first version used wave-wide ds_bpermute butterflies: 12 serial LDS
+//     round trips per row made the prologue 37 % of the kernel) -- and written as bf16 (hi[/lo]) into a K-resident LDS image
+//     [K/32 slabs][BM rows][32 k] (96 KiB): no A in HBM, no LayerNorm launch;
+//   * main loop: only W streams, from a slab-major, pre-swizzled packed copy (launch_pack_slabs: one k-step of one column
+//     tile = one contiguous 16 KiB block, so every LDS-DMA piece is 1 KiB of consecutive bytes and the whole stream is a linear
+//     walk) through a 4-slot LDS ring; W is < 1.3 MB and L2-resident, every workgroup walks it in the same order;
+//   * operand roles are swapped (W rows on the MFMA rows): accumulator register r of lane (lr, lh) is output row lr, column
+//     (r&3) + 8(r>>2) + 4 lh -- four CONSECUTIVE columns per register quad -- so bf16 outputs are packed in the accumulator
+//     layout and two v_permlane32_swap per quad pair give every lane 8 consecutive columns = one 16-byte store, with no LDS
+//     round trip (the ring needs all the LDS that is left: 96 KiB image + 4 x 16 KiB = 160 KiB);
+//   * the bias enters as the accumulators' initial value through one extra MFMA per block (bias as a 3-term bf16 split times
+//     a ones fragment: exact), because with this layout it varies along the registers, not the lanes;
+//   * the epilogue of tile t (activation, packing, stores) is deferred: it runs in pieces between the k-steps of tile t+1,
+//     from a copy of the accumulators, so its VALU / store work overlaps the partner wave's MFMAs instead of serialising
+//     with the main loop;
+//   * waves are laid out 1 x WN: each owns 32 output columns of every row block, DMAs exactly the W rows it multiplies into a
+//     PRIVATE ring, and reads the shared (read-only) image -- so the k-loop has NO workgroup barrier: waves run free between
+//     panel boundaries and the two waves of a SIMD drift into complementary phases (one in its MFMA burst, the other waiting
+//     for LDS reads or draining an epilogue block).  The 2 x 4 layout with a shared ring and a barrier per k-step measured
+//     0.6 us per k-step for 0.24 us of matrix work: both waves of a SIMD read LDS together, then multiply together;
+//   * LDS-DMA completion needs one constant counted wait per k-step (see wait_next_stage): gfx9 retires loads, stores and
+//     LDS-DMA through one in-order vmcnt, and RING-1 younger stages are always behind the awaited one.
+// Training forwards get the normalised planes (a_out) and the fc1 pre-activation (aux_out) as by-products.
+#include "common.h"
+#include "kernels.h"
+
+namespace dseg {
+
+namespace aln {
+constexpr int BK = 32;
+// KD = K (compile-time: the A image is K-resident); PL = operand planes; WN waves side by side, each MI row blocks x 32 columns
+template <int KD_, int PL_, int MI_, int WN_, int RING_>
+struct Cfg {
+    static constexpr int KD = KD_, PL = PL_, WN = WN_, MI = MI_, RING = RING_;
+    static constexpr int NWAVES = WN, THREADS = NWAVES * 64;
+    static constexpr int BM = MI * 32, BN = WN * 32;
+    static constexpr int NK = KD / BK;
+    static constexpr int A_SLAB = BM * BK * 2;                       // one [BM][32] k-slab of one plane
+    static constexpr int A_PLANE = NK * A_SLAB, A_BYTES = PL * A_PLANE;
+    static constexpr int W_BLOCK = 32 * BK * 2;                      // [32 rows][32 k] of one plane = 2 KiB
+    static constexpr int W_WAVE = PL * W_BLOCK;                      // what one wave consumes per k-step
+    static constexpr int W_STAGE = WN * W_WAVE;                      // one k-step of one column tile, contiguous in the packed copy
+    static constexpr int PIECES = W_WAVE / 1024;                     // LDS-DMA pieces per wave and k-step
+    static constexpr int LDS_BYTES = A_BYTES + NWAVES * RING * W_WAVE;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static constexpr int RPW = BM / NWAVES;                          // rows each wave normalises in the prologue
+    static_assert(BM % NWAVES == 0 && RPW % 4 == 0 && KD % 64 == 0, "prologue shape: 4 rows per pass, 16 lanes x 4 columns per load");
+    static constexpr int NBLK = MI;                                  // 32x32 accumulator blocks per wave
+    static_assert(NK >= 3 * NBLK - 1 && NBLK <= 4, "the deferred epilogue takes one block every third k-step");
+};
+using Cfg384x1 = Cfg<384, 1, 4, 8, 4>;    // bf16:   128 x 256 tile, 8 waves of 128 x 32, private 4 x 2 KiB W rings
+using Cfg384x2 = Cfg<384, 2, 2, 4, 4>;    // bf16x3:  64 x 128 tile, 4 waves of  64 x 32, private 4 x 4 KiB W rings (hi+lo)
+
+__device__ __forceinline__ int off64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(float, moved);
+}
+// sum over the 16 lanes of a DPP row, result in all 16
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);      // row_half_mirror: the other quad of each 8
+    v = dpp_add<0x140>(v);      // row_mirror: the other 8
+    return v;
+}
+}  // namespace aln
+
+// ------------------------------------------------------------------------------------------------
+// fp32 W [N][K] -> slab-major bf16 planes for gemm_ln: dst[tile][kt][32-row block][plane][32 rows][32 k], rows >= N zero, the
+// four 16-byte chunks of each 64-byte row stored in the XOR-swizzled order of the LDS image (so the image is a linear copy
+// and the [plane][32][32] block of one wave is contiguous).
+__global__ __launch_bounds__(256) void pack_slabs_kernel(const float* __restrict__ src, int N, int K, int BN, int planes,
+                                                         bf16_t* __restrict__ dst, long total) {
+    const int nk = K / 32;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long t = idx;
+        const int e = (int)(t & 7); t >>= 3;
+        const int phys = (int)(t & 3); t >>= 2;
+        const int r = (int)(t & 31); t >>= 5;
+        const int pl = (int)(t % planes); t /= planes;
+        const int rb = (int)(t % (BN / 32)); t /= (BN / 32);
+        const int kt = (int)(t % nk);
+        const int tile = (int)(t / nk);
+        const int n = tile * BN + rb * 32 + r, k = kt * 32 + ((phys ^ ((r >> 2) & 3)) << 3) + e;
+        const float v = n < N ? src[(long)n * K + k] : 0.f;
+        const uint32_t hi = pack_bf16x2(v, 0.f);
+        dst[idx] = pl == 0 ? (bf16_t)(hi & 0xFFFF) : (bf16_t)(pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
+    }
+}
+
+int gemm_ln_tile_cols(int planes) { return planes == 1 ? aln::Cfg384x1::BN : aln::Cfg384x2::BN; }
+
+long gemm_ln_slab_elems(int N, int K, int planes) {
+    const int bn = gemm_ln_tile_cols(planes);
+    return (long)((N + bn - 1) / bn) * bn * K * planes;
+}
+
+int launch_pack_slabs(const float* src, int N, int K, int planes, bf16_t* dst, hipStream_t s) {
+    const long total = gemm_ln_slab_elems(N, K, planes);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_slabs_kernel, dim3(grid), dim3(256), 0, s, src, N, K, gemm_ln_tile_cols(planes), planes, dst, total);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int EPI, class C, bool DBG = false>
+__global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kernel(LnGemmParams p) {
+    using namespace aln;
+    constexpr int KD = C::KD, PL = C::PL, BM = C::BM, BN = C::BN, MI = C::MI, NK = C::NK, RING = C::RING;
+    constexpr int PIECES = C::PIECES, NBLK = C::NBLK, NI = 1;
+    const int dbg = DBG ? p.dbg : 0;            // ablations are compiled out of the production instantiation
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sA = smem;
+    char* const sW = smem + C::A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave;                        // this wave's 32-column block of every tile
+    const int lr = lane & 31, lh = lane >> 5;
+    char* const sWw = sW + wave * (RING * C::W_WAVE);       // this wave's private W ring
+
+    const int M = p.M, N = p.N;
+    const int nbn = (N + BN - 1) / BN, npanels = (M + BM - 1) / BM;
+    const int my_panels = ((int)blockIdx.x < npanels) ? (npanels - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int total_steps = my_panels * nbn * NK;
+    if (total_steps == 0) return;
+    const bool wave_cols_valid_last = (nbn - 1) * BN + wc * 32 < N;     // does this wave own real columns in the last (partial) tile?
+
+    // ---- W stream: a linear walk over nbn * NK contiguous stages, restarted for every panel
+    const uint32_t voff = (uint32_t)(lane * 16);
+    int is_step = 0;
+    long is_off = 0;
+    const long w_panel_bytes = (long)nbn * NK * C::W_STAGE;
+    int is_slot = 0;
+    auto issue_next = [&]() {
+        const char* wbase = reinterpret_cast<const char*>(p.W) + is_off + wave * C::W_WAVE;
+        char* sbase = sWw + is_slot * C::W_WAVE;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) glds16(wbase + i * 1024 + voff, sbase + i * 1024);
+        ++is_step;
+        is_off += C::W_STAGE;
+        if (is_off == w_panel_bytes) is_off = 0;
+        is_slot = is_slot + 1 == RING ? 0 : is_slot + 1;
+    };
+    // Wait for the stage that is read next.  gfx9 retires loads, stores and LDS-DMA through one in-order vmcnt: after a refill
+    // was issued, at least the (RING-1) * PIECES pieces of the three younger stages are behind the awaited one, so
+    // vmcnt((RING-1) * PIECES) always covers it.  Epilogue stores / bias loads that are younger still make the wait stricter
+    // than necessary by at most their count (it then also retires the oldest in-flight stage early, which was issued two
+    // k-steps ago anyway) -- cheaper than tracking exact counts: a 48-way wait ladder per k-step cost more than it saved.
+    // A drained block's stores stay younger than the awaited stage for three waits (the one of their own k-step and the next
+    // two); counting them keeps the wait from forcing the stage issued one k-step ago (measured: 38 us of the qkv launch).
+#ifndef ALN_STAGGER
+#define ALN_STAGGER 0       // measured (same box, tools/ab_ops.sh): no gain from the stagger
+#endif
+    const int drain_ofs = (ALN_STAGGER && wave >= C::NWAVES / 2) ? 1 : 0;
+    constexpr int DRAIN_STORES = 2 * PL;
+    (void)DRAIN_STORES;
+    int stores_young = 0;
+    auto wait_next_stage = [&](bool refilled) {
+        if (!refilled) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last RING k-steps of the kernel
+#ifdef ALN_STORE_AWARE_WAIT     // measured slower than the plain wait on the same box (parity mode: 7 %), kept for reference
+        else if (stores_young > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * PIECES + DRAIN_STORES) : "memory");
+#endif
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * PIECES) : "memory");
+        stores_young = stores_young > 0 ? stores_young - 1 : 0;
+    };
+
+    // ---- ring prologue: the first RING stages (fragments are read one k-step ahead, so a stage's slot is refilled while that
+    // stage is being multiplied from registers: RING-1 stages are in flight during every k-step)
+#pragma unroll
+    for (int s = 0; s < RING; ++s)
+        if (s < total_steps && !(dbg & 2)) issue_next();
+
+    // ---- accumulators.  acc = the tile being multiplied; accp = the finished previous tile, drained between the k-steps
+    f32x16 acc[MI][NI], accp[MI][NI];
+    bool have_prev = false;
+    int prev_m0 = 0, prev_n0 = 0;             // global row / column of the previous tile's wave block
+    bool prev_valid = false;                  // previous tile: does this wave own real columns?
+    // bias values of the CURRENT / NEXT tile (lane = column): loaded by asm (the compiler must not wait for them while the
+    // LDS-DMA ring is in flight: it would drain the ring); they are old by the time the next tile starts
+    float bias_cur[NI], bias_nxt[NI];
+    const uint4 ones_u = {lh == 0 ? 0x3F803F80u : 0u, lh == 0 ? 0x00003F80u : 0u, 0u, 0u};     // k = 0, 1, 2 are 1.0
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+    auto load_bias = [&](int bn, float* dst) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int n = bn * BN + wc * 32 + j * 32 + lr;
+            n = n < N ? n : N - 1;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(dst[j]) : "v"(p.bias + n) : "memory");
+        }
+    };
+    auto init_acc = [&](float* b) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            // b = hi + mid + lo exactly (three bf16 terms of an fp32); rows of the fragment = output columns
+            asm volatile("" : "+v"(b[j]));
+            const float bj = b[j];
+            const uint32_t hi = pack_bf16x2(bj, 0.f);
+            const float r1 = bj - bf16_lo_to_f32(hi);
+            const uint32_t mid = pack_bf16x2(r1, 0.f);
+            const uint32_t lo = pack_bf16x2(r1 - bf16_lo_to_f32(mid), 0.f);
+            const uint4 fu = {lh == 0 ? ((hi & 0xFFFFu) | (mid << 16)) : 0u, lh == 0 ? (lo & 0xFFFFu) : 0u, 0u, 0u};
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            z = mfma32(__builtin_bit_cast(bf16x8, fu), ones, z);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[i][j] = z;
+        }
+    };
+
+    // one 32x32 block of the previous tile: activation, bf16 packing, two 16-byte stores per plane (+ the pre-activation)
+    auto drain_block = [&](auto blk_tag) {
+        constexpr int blk = decltype(blk_tag)::value;
+        if (!prev_valid || ((dbg & 1) && accp[0][0][0] != 12345.678f)) return;
+        constexpr int i = blk, j = 0;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = accp[i][j][r];
+        int gm = prev_m0 + i * 32 + lr;
+        gm = gm < M ? gm : M - 1;                       // rows past M are copies of row M-1: identical bytes
+        const int nb = prev_n0 + j * 32;                // first column of the block (wave-uniform)
+        if (nb >= N) return;                            // padding columns of the last tile
+        bf16_t* base;
+        long pstride;
+        int which = 0;
+        if (EPI == EPI_QKV) {
+            which = nb / p.dmodel;                      // the block lies inside one head of one of Q / K / V
+            const int hcol = nb - which * p.dmodel;
+            const int bq = gm / p.ntok, tok = gm - bq * p.ntok;
+            base = (which == 0 ? p.q : (which == 1 ? p.k : p.v)) + ((long)(bq * p.heads + (hcol >> 6)) * p.npad + tok) * 64 + (hcol & 63);
+            pstride = p.qkv_plane;
+        } else {
+            base = p.out_bf16 + (long)gm * p.ldo + nb;
+            pstride = p.out_plane;
+        }
+        auto store_planes = [&](const float* val, bf16_t* dst, long plane_stride) {
+            uint2 hi[4], lo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                split_bf16x2(val[4 * q], val[4 * q + 1], hi[q].x, lo[q].x);
+                split_bf16x2(val[4 * q + 2], val[4 * q + 3], hi[q].y, lo[q].y);
+            }
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) {
+                uint2* w = pl == 0 ? hi : lo;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    // quads 2qq (columns 16qq + 4lh + 0..3) and 2qq+1 (+8): after the half swaps the lower lanes hold columns
+                    // 16qq + 0..7 and the upper lanes 16qq + 8..15
+                    const uint2 a = w[2 * qq], b = w[2 * qq + 1];
+                    const auto sx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+                    const uint4 o = {sx[0], sy[0], sx[1], sy[1]};
+                    *reinterpret_cast<uint4*>(dst + pl * plane_stride + qq * 16 + lh * 8) = o;
+                }
+            }
+        };
+        stores_young = RING - 1;        // (with aux_out there are more stores than counted: the waits are then merely stricter)
+        if (EPI == EPI_GELU && p.aux_out != nullptr) store_planes(v, p.aux_out + (long)gm * p.ldo + nb, p.aux_plane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (EPI == EPI_GELU) v[r] = PL == 1 ? gelu_fast(v[r]) : gelu_erf(v[r]);
+            if (EPI == EPI_QKV && which == 0) v[r] *= p.qscale;
+        }
+        store_planes(v, base, pstride);
+    };
+
+    int rd_slot = 0;                // ring slot of the stage whose fragments are read next
+    // s_waitcnt lgkmcnt(0) as the builtin (vmcnt 63, expcnt 7 = no wait): the compiler's own wait-count pass sees it and learns
+    // that the prefetched fragments have arrived; behind an inline-asm wait it re-waited for ALL LDS reads -- the prefetch just
+    // issued included -- in front of every MFMA group, which serialised reads and matrix work again
+    constexpr int LGKM0 = 0xC07F;
+    // fragments of half a k-step (16 of its 32 k): W block (A operand) and the MI row blocks of the image (B operand)
+    struct Half {
+        bf16x8 w[PL];
+        bf16x8 a[PL][MI];
+    };
+    Half h0, h1;
+    auto read_half = [&](Half& f, int kt, int kk) {
+        const char* sw = sWw + rd_slot * C::W_WAVE;
+        const char* sa = sA + kt * C::A_SLAB;
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) {
+            f.w[pl] = lds_frag(sw + pl * C::W_BLOCK + off64(lr, kk * 2 + lh));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) f.a[pl][i] = lds_frag(sa + pl * C::A_PLANE + off64(i * 32 + lr, kk * 2 + lh));
+        }
+    };
+    auto mfma_half = [&](const Half& f, bool cols_valid) {
+        if (!cols_valid || (DBG && (dbg & 8))) return;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {      // rows of the MFMA = W rows (output columns), columns = token rows
+            if (PL == 2) {
+                acc[i][0] = mfma32(f.w[PL - 1], f.a[0][i], acc[i][0]);
+                acc[i][0] = mfma32(f.w[0], f.a[PL - 1][i], acc[i][0]);
+            }
+            acc[i][0] = mfma32(f.w[0], f.a[0][i], acc[i][0]);
+        }
+    };
+    // one k-step.  On entry h0 holds the first half of this stage (read during the previous step's second half); LDS reads run
+    // half a step ahead of their MFMAs, so a wave's own read latency hides behind its own matrix work.
+    auto kstep = [&](int bn, int kt, bool cols_valid) {
+        read_half(h1, kt, 1);
+        mfma_half(h0, cols_valid);
+        if (kt == 0) {                      // bias of the NEXT tile (wraps to the first tile of the next panel)
+            const int bn_next = bn + 1 < nbn ? bn + 1 : 0;
+            load_bias(bn_next, bias_nxt);
+        }
+        // deferred epilogue of the previous tile: one block at k-steps 1, 4, 7, 10 (static register indexing per arm)
+        // (the second wave of each SIMD -- waves NWAVES/2.. -- drains one k-step later: SIMD partners run the same program from
+        //  the same barrier and would otherwise reach their VALU-heavy pieces together and leave the matrix pipe idle together)
+        if (have_prev) {
+            const int kd = kt - drain_ofs;
+            if (kd == 1) drain_block(std::integral_constant<int, 0>{});
+            if (NBLK > 1 && kd == 4) drain_block(std::integral_constant<int, 1 % NBLK>{});
+            if (NBLK > 2 && kd == 7) drain_block(std::integral_constant<int, 2 % NBLK>{});
+            if (NBLK > 3 && kd == 10) drain_block(std::integral_constant<int, 3 % NBLK>{});
+        }
+        __builtin_amdgcn_s_waitcnt(LGKM0);                      // h1 has arrived: this stage's slot is free
+        rd_slot = rd_slot + 1 == RING ? 0 : rd_slot + 1;
+        if (!(dbg & 2)) {
+            const bool refill = is_step < total_steps;
+            if (refill) issue_next();                           // refill it with stage step + RING
+            wait_next_stage(refill);                            // stage step + 1 has landed (its slot is private: no barrier)
+        } else {
+            ++is_step;
+        }
+        asm volatile("" ::: "memory");      // nothing below may be scheduled above the stage issue (the marks count on it)
+        const bool last_of_panel = bn + 1 == nbn && kt + 1 == NK;
+        if (!last_of_panel) read_half(h0, kt + 1 == NK ? 0 : kt + 1, 0);     // (else: the next panel's fill, from the new image)
+        mfma_half(h1, cols_valid);
+        __builtin_amdgcn_s_waitcnt(LGKM0);                      // h0 (next stage) has arrived
+    };
+    load_bias(0, bias_cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // once: the first tile's bias and the ring's first RING stages
+    for (int pi = 0; pi < my_panels; ++pi) {
+        const int panel = blockIdx.x + pi * gridDim.x;
+        // ================= LayerNorm prologue: rows of this panel -> bf16 planes in LDS (vision_transformer.py:303, eps 1e-6)
+        // (the only two workgroup barriers per panel: the image is rewritten once nobody reads the old one, and read once
+        //  everybody has written its rows; LDS-DMA into the private rings stays in flight across both)
+        __builtin_amdgcn_s_barrier();
+        if (!(dbg & 4)) {
+            constexpr int NT = KD / 64;                     // 16-byte loads per lane and row
+            const int g = lane >> 4, l = lane & 15;
+            f32x4 x[C::RPW / 4][NT];
+#pragma unroll
+            for (int ps = 0; ps < C::RPW / 4; ++ps) {
+                int gm = panel * BM + wave * C::RPW + ps * 4 + g;
+                gm = gm < M ? gm : M - 1;
+                const float* xr = p.X + (long)gm * p.ldx + l * 4;
+#pragma unroll
+                for (int it = 0; it < NT; ++it) x[ps][it] = *reinterpret_cast<const f32x4*>(xr + it * 64);
+            }
+#pragma unroll
+            for (int ps = 0; ps < C::RPW / 4; ++ps) {
+                float s = 0.f;
+#pragma unroll
+                for (int it = 0; it < NT; ++it) s += (x[ps][it][0] + x[ps][it][1]) + (x[ps][it][2] + x[ps][it][3]);
+                const float mean = row16_sum(s) * (1.0f / KD);
+                float qv = 0.f;
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[ps][it][e] -= mean;
+                        qv = fmaf(x[ps][it][e], x[ps][it][e], qv);
+                    }
+                const float rstd = 1.0f / sqrtf(row16_sum(qv) * (1.0f / KD) + p.eps);
+                const int row = wave * C::RPW + ps * 4 + g;
+                int gm = panel * BM + row;
+                gm = gm < M ? gm : M - 1;
+#pragma unroll
+                for (int it = 0; it < NT; ++it) {
+                    const f32x4 gam = *reinterpret_cast<const f32x4*>(p.gamma + it * 64 + l * 4);
+                    const f32x4 bet = *reinterpret_cast<const f32x4*>(p.beta + it * 64 + l * 4);
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = x[ps][it][e] * rstd * gam[e] + bet[e];
+                    uint2 hi, lo;
+                    split_bf16x2(y[0], y[1], hi.x, lo.x);
+                    split_bf16x2(y[2], y[3], hi.y, lo.y);
+                    // column c = it*64 + l*4: k-slab c >> 5, 16-byte chunk (c & 31) >> 3, byte (c & 7) * 2
+                    char* dst = sA + (it * 2 + (l >> 3)) * C::A_SLAB + off64(row, (l >> 1) & 3) + (l & 1) * 8;
+                    *reinterpret_cast<uint2*>(dst) = hi;
+                    if (PL == 2) *reinterpret_cast<uint2*>(dst + C::A_PLANE) = lo;
+                    if (p.a_out) {
+                        bf16_t* ao = p.a_out + (long)gm * KD + it * 64 + l * 4;
+                        *reinterpret_cast<uint2*>(ao) = hi;
+                        if (PL == 2) *reinterpret_cast<uint2*>(ao + p.a_plane) = lo;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's rows are in the image
+        }
+        __builtin_amdgcn_s_barrier();
+
+        // fill the fragment pipeline: the stage of this panel's first k-step was waited for already (kernel start / the last
+        // k-step of the previous panel); fragments are read one k-step ahead of their MFMAs from here on
+        read_half(h0, 0, 0);
+        __builtin_amdgcn_s_waitcnt(LGKM0);
+        for (int bn = 0; bn < nbn; ++bn) {
+            const bool cols_valid = bn + 1 < nbn || wave_cols_valid_last;      // wave-uniform
+            init_acc(bias_cur);
+#pragma unroll 1
+            for (int kt = 0; kt < NK; ++kt) kstep(bn, kt, cols_valid);
+            // ---- the tile is complete: hand it to the deferred epilogue
+#pragma unroll
+            for (int i = 0; i < MI; ++i) accp[i][0] = acc[i][0];
+            have_prev = true;
+            prev_valid = cols_valid;
+            prev_m0 = panel * BM;
+            prev_n0 = bn * BN + wc * 32;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bias_cur[j] = bias_nxt[j];
+        }
+    }
+
+    // ---- the last tile has no successor to hide behind
+    drain_block(std::integral_constant<int, 0>{});
+    if (NBLK > 1) drain_block(std::integral_constant<int, 1 % NBLK>{});
+    if (NBLK > 2) drain_block(std::integral_constant<int, 2 % NBLK>{});
+    if (NBLK > 3) drain_block(std::integral_constant<int, 3 % NBLK>{});
+}
+
+template <int EPI, class C>
+static int launch_ln_cfg(const LnGemmParams& p, hipStream_t s) {
+    static PerDeviceOnce once;
+    if (once.first()) {
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_kernel<EPI, C, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_kernel<EPI, C, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    }
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return -2;
+    const int npanels = (p.M + C::BM - 1) / C::BM;
+    const int grid = npanels < ncu ? npanels : ncu;
+    if (p.dbg) hipLaunchKernelGGL((gemm_ln_kernel<EPI, C, true>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, p);
+    else hipLaunchKernelGGL((gemm_ln_kernel<EPI, C, false>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, p);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+bool gemm_ln_supported(int K, int N, int planes, int epi, int dmodel) {
+    if (K != 384 || (planes != 1 && planes != 2) || (epi != EPI_QKV && epi != EPI_GELU) || N % 32 != 0) return false;
+    return epi != EPI_QKV || (dmodel % 64 == 0 && N == 3 * dmodel);
+}
+
+int launch_gemm_ln(const LnGemmParams& p0, int K, int planes, hipStream_t s) {
+    if (p0.M <= 0) return 0;
+    LnGemmParams p = p0;
+    p.dbg = options().gemm_dbg;
+    if (!gemm_ln_supported(K, p.N, planes, p.epi, p.dmodel) || p.ldx % 4 != 0) {
+        dinoseg_set_error("gemm_ln: unsupported shape K=%d N=%d planes=%d epi=%d ldx=%d", K, p.N, planes, p.epi, p.ldx);
+        return -1;
+    }
+    if (planes == 1) {
+        if (p.epi == EPI_QKV) return launch_ln_cfg<EPI_QKV, aln::Cfg384x1>(p, s);
+        return launch_ln_cfg<EPI_GELU, aln::Cfg384x1>(p, s);
+    }
+    if (p.epi == EPI_QKV) return launch_ln_cfg<EPI_QKV, aln::Cfg384x2>(p, s);
+    return launch_ln_cfg<EPI_GELU, aln::Cfg384x2>(p, s);
+}
+
+}  // namespace dseg

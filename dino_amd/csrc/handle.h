@@ -39,6 +39,7 @@ struct dinoseg_handle {
     char* wbuf = nullptr;
     size_t wbuf_bytes = 0;
     std::map<std::string, PackedLinear> packed;
+    std::map<std::string, bf16_t*> packed_slab;     // slab-major copies of the LN-fed weights (gemm_ln.hip), when supported
     bool weights_ready = false;
     // pos-embed cache
     float* pos_cache = nullptr;

@@ -48,8 +48,28 @@ int launch_gemm_small(const GemmParams& p, hipStream_t s); // 128x128 tile, bf16
 bool gemm_big_supported(const GemmParams& p);
 int launch_gemm_big(const GemmParams& p, hipStream_t s);   // 256x384 persistent tile, bf16 only (gemm_big.hip)
 
+// LayerNorm-fused A-stationary GEMM for qkv / fc1 (gemm_ln.hip): X fp32 rows are normalised in the prologue, W streams
+struct LnGemmParams {
+    const float* X; int ldx;                    // residual stream [M, K] fp32
+    const float* gamma; const float* beta; float eps;
+    const bf16_t* W; long w_plane;              // slab-major packed copy (launch_pack_slabs); w_plane unused
+    const float* bias;                          // [N]
+    int M, N;
+    int epi;                                    // EPI_QKV or EPI_GELU
+    bf16_t* out_bf16; long out_plane; int ldo;  // GELU: [planes][M][ldo]
+    bf16_t* q; bf16_t* k; bf16_t* v; long qkv_plane; int ntok, npad, heads, dmodel; float qscale;   // QKV
+    bf16_t* a_out; long a_plane;                // optional: the normalised planes [planes][M][K] (training: weight gradients)
+    bf16_t* aux_out; long aux_plane;            // optional (GELU): pre-activation planes [planes][M][ldo] (training: gelu')
+    int dbg;                                    // timing-only ablations (wrong results): 1 skip epilogue, 2 skip W DMA, 4 skip LN prologue
+};
+bool gemm_ln_supported(int K, int N, int planes, int epi, int dmodel);
+long gemm_ln_slab_elems(int N, int K, int planes);      // bf16 elements of the slab-major copy of W [N][K]
+int launch_pack_slabs(const float* src, int N, int K, int planes, bf16_t* dst, hipStream_t s);
+int launch_gemm_ln(const LnGemmParams& p, int K, int planes, hipStream_t s);
+
 // tuning knobs (dinoseg_set_option): see api.hip
 struct Options {
+    int gemm_ln = 1;         // qkv / fc1 through the LayerNorm-fused A-stationary kernel (gemm_ln.hip) where it applies
     int gemm_big = 1;        // use gemm_big.hip where it applies
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
     int attn_dbg = 0;        // same for AttnParams::dbg

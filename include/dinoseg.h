@@ -194,6 +194,21 @@ int dinoseg_op_qkv_gemm(const void* A, int64_t a_plane, const void* W, int64_t w
                         int32_t ntok, int32_t npad, int32_t heads, int32_t planes, float qscale, void* q, void* k,
                         void* v, int64_t qkv_plane, void* stream);
 
+/* Slab-major bf16 copy of an fp32 weight W [N][K] for dinoseg_op_ln_gemm (dst holds dinoseg_op_ln_gemm_slab_elems(N, K, planes)
+ * bf16 elements; -1 = unsupported shape): [column tile][k-step][plane][rows][32 k], pre-swizzled, zero padded. */
+int64_t dinoseg_op_ln_gemm_slab_elems(int32_t N, int32_t K, int32_t planes);
+int dinoseg_op_pack_slabs(const float* W, int32_t N, int32_t K, int32_t planes, void* dst, void* stream);
+
+/* LayerNorm (eps as given) fused into the GEMM that consumes it: out = epilogue(LN(X) W^T + bias), X fp32 [M, K] (K = 384);
+ * Wp = the slab-major copy made by dinoseg_op_pack_slabs (w_plane is ignored).
+ * epi 4 (QKV): scatter to q (x qscale), k, v [planes][B*heads][npad][64]; epi 2 (GELU): out_bf16 [planes][M][N].
+ * a_out / aux_out (nullable): the normalised planes [planes][M][K] / the pre-GELU planes, kept by training forwards.
+ * Replaces nn.LayerNorm + nn.Linear pairs vision_transformer.py:123 -> :75 and :135 -> :60-61. */
+int dinoseg_op_ln_gemm(const float* X, const float* gamma, const float* beta, float eps, const void* Wp, int64_t w_plane,
+                       const float* bias, int32_t M, int32_t N, int32_t K, int32_t planes, int32_t epi, void* out_bf16,
+                       int64_t out_plane, void* q, void* k, void* v, int64_t qkv_plane, int32_t ntok, int32_t npad,
+                       int32_t heads, float qscale, void* a_out, void* aux_out, void* stream);
+
 /* fused softmax(q k^T) v (vision_transformer.py:85,101,104); q must be pre-scaled by 64^-0.5 * log2(e).
  * q, k, v: [planes][B,heads,npad,64] (rows >= ntok zero); ctx: bf16 planes [planes][B*ntok][heads*64];
  * lse (optional): fp32 [B,heads,ntok], log2 domain. */

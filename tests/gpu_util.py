@@ -36,3 +36,13 @@ def quant_like(x: torch.Tensor, planes: int) -> torch.Tensor:
 def seeded(shape, seed, scale=1.0, device="cuda"):
     g = np.random.default_rng(seed)
     return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32)).to(device)
+
+
+def pack_slabs(W: torch.Tensor, planes: int) -> torch.Tensor:
+    """fp32 [N, K] device weight -> int16 view of the slab-major bf16 copy gemm_ln.hip streams."""
+    N, K = W.shape
+    n = capi.lib().dinoseg_op_ln_gemm_slab_elems(N, K, planes)
+    assert n > 0
+    out = torch.empty((n,), dtype=torch.int16, device=W.device)
+    capi.check(capi.lib().dinoseg_op_pack_slabs(W.contiguous().data_ptr(), N, K, planes, out.data_ptr(), capi.stream_ptr()))
+    return out

@@ -335,15 +335,21 @@ def test_model_copies_and_pickles_without_the_native_handle(cuda, tmp_path):
     assert not torch.equal(m.forward_frames(frames)[0], lp)
 
 
-def test_g4_960_batch8_frames_are_independent(cuda):
-    """@960 (14 401 tokens) at the BASELINE batch of 8 in the benchmark precision: every frame of the batch gets what it gets
-    alone (frames are independent: pl_torch_modules.py:253 flattens them), outputs are finite and the library's argmax is
-    torch's first-max argmax."""
-    m, _, _ = build(3, "bf16")
+@pytest.mark.parametrize("precision,tol,flip_frac", [("bf16x3", 1e-3, 0.0), ("bf16", 0.35, 0.03)])
+def test_g4_960_batch8_frames_are_independent(cuda, precision, tol, flip_frac):
+    """@960 (14 401 tokens) at the BASELINE batch of 8: every frame of the batch gets what it gets alone (frames are independent:
+    pl_torch_modules.py:253 flattens them) up to the GEMM dispatch -- batch 1 and batch 8 take different tile shapes = different
+    fp32 summation orders.  The parity mode holds the 1e-3 bar across that; the bf16 mode re-rounds activations to 8 bits and is
+    bounded like its distance to the reference (test_g3_vits8_480_bf16_mode_is_bounded).  Outputs are finite, the library's
+    argmax is torch's first-max argmax, and the same launch shapes are bit-reproducible."""
+    m, _, _ = build(3, precision)
     m.set_resolution(960)
     frames = torch.from_numpy(synthetic_frames(8, 960, seed=40)).cuda()
     lp, am = m.forward_frames(frames)
     assert torch.isfinite(lp).all() and torch.equal(am.long(), lp.argmax(1))
     for i in (0, 5, 7):
         lp1, am1 = m.forward_frames(frames[i:i + 1])
-        assert torch.equal(lp[i * 14400:(i + 1) * 14400], lp1) and torch.equal(am[i * 14400:(i + 1) * 14400], am1)
+        assert float((lp[i * 14400:(i + 1) * 14400] - lp1).abs().max()) <= tol
+        assert float((am[i * 14400:(i + 1) * 14400] != am1).float().mean()) <= flip_frac
+    lp2, am2 = m.forward_frames(frames)                     # same launch shapes: bit-identical
+    assert torch.equal(lp2, lp) and torch.equal(am2, am)

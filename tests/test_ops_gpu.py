@@ -8,7 +8,7 @@ import torch
 
 from dino_amd import capi
 from oracle import dinoseg_oracle as O
-from tests.gpu_util import pack, quant_like, seeded, unpack
+from tests.gpu_util import pack, pack_slabs, quant_like, seeded, unpack
 
 pytestmark = pytest.mark.gpu
 S = capi.stream_ptr
@@ -339,3 +339,70 @@ def test_attention_14401_tokens_sampled_rows(cuda, planes):
     assert torch.isfinite(unpack(ctx)).all()
     assert float((got - ref).abs().max()) <= (1.2e-2 if planes == 1 else 1e-4)
     assert float((lse.cpu()[:, :, rows] - ref_lse).abs().max()) <= (6e-3 if planes == 1 else 1e-4)
+
+
+def _ln_ref(X, g, b, eps=1e-6):
+    return O.layer_norm(X.cpu(), g.cpu(), b.cpu(), eps)
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+@pytest.mark.parametrize("M_,N", [(394, 768), (115, 768), (128 * 3, 1536), (128 * 300 + 77, 640)])
+def test_ln_gemm_gelu(cuda, planes, M_, N):
+    """LayerNorm fused into the fc1 GEMM (gemm_ln.hip): out = gelu(LN(X) W^T + b), plus the by-products a training forward
+    keeps (normalised planes, pre-activation planes); ragged last panel, single partial panel, whole panels."""
+    K = 384             # N = 640: a partial last column tile; M = 38 477: several panels per workgroup (persistent walk)
+    X = seeded((M_, K), 11) * 1.7 + 0.4
+    gam, bet = 1 + 0.2 * seeded((K,), 12), 0.1 * seeded((K,), 13)
+    W, bias = seeded((N, K), 14) * 0.1, seeded((N,), 15)
+    Wp = pack_slabs(W, planes)
+    out = torch.zeros((planes, M_, N), dtype=torch.int16, device="cuda")
+    aout = torch.zeros((planes, M_, K), dtype=torch.int16, device="cuda")
+    pre = torch.zeros((planes, M_, N), dtype=torch.int16, device="cuda")
+    capi.check(capi.lib().dinoseg_op_ln_gemm(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wp.data_ptr(), N * K, bias.data_ptr(),
+                                             M_, N, K, planes, capi.EPI_GELU, out.data_ptr(), M_ * N, None, None, None, 0, 0, 0, 6, 0.0,
+                                             aout.data_ptr(), pre.data_ptr(), S()))
+    A = _ln_ref(X, gam, bet)
+    tol = 2.0 ** -8 if planes == 1 else 2.0 ** -15
+    got_a = unpack(aout).cpu()
+    assert float((got_a - A).abs().max()) <= tol * float(A.abs().max()) + 1e-5
+    # the product of the operands the kernel saw (its own normalised planes)
+    z = (got_a.double() @ quant_like(W, planes).cpu().double().t() + bias.cpu().double()).float()
+    got_pre = unpack(pre).cpu()
+    assert float((got_pre - z).abs().max()) <= tol * float(z.abs().max()) + 2e-4
+    want = O.gelu_erf(z)
+    assert float((unpack(out).cpu() - want).abs().max()) <= tol * float(want.abs().max()) + 2e-4
+    # without the by-products: same output bits
+    out2 = torch.zeros_like(out)
+    capi.check(capi.lib().dinoseg_op_ln_gemm(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wp.data_ptr(), N * K, bias.data_ptr(),
+                                             M_, N, K, planes, capi.EPI_GELU, out2.data_ptr(), M_ * N, None, None, None, 0, 0, 0, 6, 0.0,
+                                             None, None, S()))
+    assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+@pytest.mark.parametrize("B,ntok", [(2, 197), (1, 65), (3, 130)])
+def test_ln_gemm_qkv_layout(cuda, planes, B, ntok):
+    """LayerNorm fused into the qkv GEMM: same [B,H,npad,64] scatter, Q pre-scaled, pad rows untouched (zero)."""
+    H, K = 6, 384
+    D, npad, M_ = 384, (ntok + 63) // 64 * 64, B * ntok
+    X = seeded((M_, K), 21) * 2.0 - 0.3
+    gam, bet = 1 + 0.2 * seeded((K,), 22), 0.1 * seeded((K,), 23)
+    W, bias = seeded((3 * D, K), 24) * 0.1, seeded((3 * D,), 25)
+    Wp = pack_slabs(W, planes)
+    plane = B * H * npad * 64
+    q = torch.zeros((planes, B, H, npad, 64), dtype=torch.int16, device="cuda")
+    k, vt = torch.zeros_like(q), torch.zeros_like(q)
+    qscale = 0.125 * LOG2E
+    capi.check(capi.lib().dinoseg_op_ln_gemm(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wp.data_ptr(), 3 * D * K,
+                                             bias.data_ptr(), M_, 3 * D, K, planes, 4, None, 0, q.data_ptr(), k.data_ptr(), vt.data_ptr(),
+                                             plane, ntok, npad, H, qscale, None, None, S()))
+    A = quant_like(_ln_ref(X, gam, bet).cuda(), planes)
+    ref = (A.double() @ quant_like(W, planes).double().t() + bias.double()).float()
+    ref = ref.reshape(B, ntok, 3, H, 64).permute(2, 0, 3, 1, 4)
+    # the kernel's own LayerNorm differs from the oracle's by fp32 rounding, which can move a bf16 rounding point of A
+    tol = (2.0 ** -7 if planes == 1 else 2.0 ** -14) * float(ref.abs().max()) + 1e-4
+    gq, gk, gv = unpack(q), unpack(k), unpack(vt)
+    assert float((gq[:, :, :ntok] - ref[0] * qscale).abs().max()) <= tol
+    assert float((gk[:, :, :ntok] - ref[1]).abs().max()) <= tol
+    assert float((gv[:, :, :ntok] - ref[2]).abs().max()) <= tol
+    assert torch.all(gq[:, :, ntok:] == 0) and torch.all(gk[:, :, ntok:] == 0) and torch.all(gv[:, :, ntok:] == 0)

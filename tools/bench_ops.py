@@ -68,6 +68,69 @@ def bench_gemm(quick=True):
     lib.dinoseg_set_option(b"gemm_dbg", 0)
 
 
+def bench_lngemm():
+    """LN + GEMM as two launches (layernorm_kernel + gemm_big) against the fused A-stationary kernel (gemm_ln.hip), interleaved."""
+    lib = capi.lib()
+    B, ntok, D, H = 32, 3601, 384, 6
+    M, npad = B * ntok, (ntok + 63) // 64 * 64
+    X = torch.randn((M, D), device="cuda") * 1.5 + 0.2
+    gam, bet = torch.rand(D, device="cuda") + 0.5, torch.randn(D, device="cuda") * 0.1
+    for planes in (1, 2):
+        A = torch.zeros((planes, M, D), dtype=torch.int16, device="cuda")
+        for name, N, epi in (("qkv", 3 * D, 4), ("fc1", 4 * D, capi.EPI_GELU)):
+            W = torch.stack([rand_bf16((N, D)) for _ in range(planes)])
+            Wf = torch.randn((N, D), device="cuda") * 0.5
+            nslab = lib.dinoseg_op_ln_gemm_slab_elems(N, D, planes)
+            Ws = torch.empty((nslab,), dtype=torch.int16, device="cuda")
+            capi.check(lib.dinoseg_op_pack_slabs(Wf.data_ptr(), N, D, planes, Ws.data_ptr(), capi.stream_ptr()))
+            bias = torch.randn(N, device="cuda")
+            out = torch.zeros((planes, M, N), dtype=torch.int16, device="cuda") if epi == capi.EPI_GELU else None
+            q = torch.zeros((planes, B, H, npad, 64), dtype=torch.int16, device="cuda")
+            k, vt = torch.zeros_like(q), torch.zeros_like(q)
+
+            def ln():
+                capi.check(lib.dinoseg_op_layernorm(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, M, D, A.data_ptr(), M * D, planes,
+                                                    None, 0, ntok, capi.stream_ptr()))
+
+            def gemm():
+                if epi == 4:
+                    capi.check(lib.dinoseg_op_qkv_gemm(A.data_ptr(), M * D, W.data_ptr(), N * D, bias.data_ptr(), B, ntok, npad, H, planes,
+                                                       0.125 * LOG2E, q.data_ptr(), k.data_ptr(), vt.data_ptr(), B * H * npad * 64,
+                                                       capi.stream_ptr()))
+                else:
+                    capi.check(lib.dinoseg_op_gemm(A.data_ptr(), M * D, D, W.data_ptr(), N * D, M, N, D, planes, epi, bias.data_ptr(), None,
+                                                   out.data_ptr(), M * N, N, capi.stream_ptr()))
+
+            def two():
+                ln()
+                gemm()
+
+            def fused():
+                capi.check(lib.dinoseg_op_ln_gemm(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Ws.data_ptr(), N * D, bias.data_ptr(), M, N,
+                                                  D, planes, epi, capi.ptr(out), M * N, q.data_ptr(), k.data_ptr(), vt.data_ptr(),
+                                                  B * H * npad * 64, ntok, npad, H, 0.125 * LOG2E, None, None, capi.stream_ptr()))
+            def ablate(bits):
+                def f():
+                    lib.dinoseg_set_option(b"gemm_dbg", bits)
+                    fused()
+                    lib.dinoseg_set_option(b"gemm_dbg", 0)
+                return f
+            cases = [("LN", ln), ("GEMM", gemm), ("LN+GEMM", two), ("fused", fused)]
+            if os.environ.get("LNGEMM_ONLY_FUSED"):
+                cases = [("fused", fused)]
+            else:
+                cases += [("no-epi", ablate(1)), ("no-dma", ablate(2)), ("no-ln", ablate(4)), ("no-epi-ln", ablate(5)),
+                      ("mfma-only", ablate(7)), ("no-mfma", ablate(8))]
+            res = {nm: [] for nm, _ in cases}
+            for rnd in range(5):
+                for nm, fn in cases:
+                    res[nm].append(timeit(fn, iters=8, warm=2))
+            fl = 2.0 * M * N * D
+            for nm, ts in res.items():
+                t = sorted(ts)[len(ts) // 2]
+                print(f"{name} planes={planes} {nm:8s}: {t * 1e3:7.1f} us  {fl / (t * 1e-3) / 1e12:7.1f} TFLOP/s", flush=True)
+
+
 ATTN_VARIANTS = [int(v) for v in os.environ.get("ATTN_VARIANTS", "3").split(",")]
 
 
@@ -105,4 +168,4 @@ def bench_attn():
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    {"gemm": bench_gemm, "attn": bench_attn}[what]()
+    {"gemm": bench_gemm, "attn": bench_attn, "lngemm": bench_lngemm}[what]()

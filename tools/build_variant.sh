@@ -1,0 +1,14 @@
+#!/bin/bash
+# bash tools/build_variant.sh <name> "<extra hipcc flags>"  ->  build/variants/lib_<name>.so   (A/B builds of the HIP library;
+# run side by side on one GPU box with DINOSEG_LIB=... : boxes differ by +-5 %)
+set -e
+NAME=$1; EXTRA=$2
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+B=$ROOT/build/variant_$NAME
+mkdir -p $B $ROOT/build/variants
+for f in api train_api gemm gemm_big gemm_ln gemm_tn attention attention_bwd elementwise train; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA -c $ROOT/dino_amd/csrc/$f.hip -o $B/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/variants/lib_$NAME.so $B/*.o
+echo built $ROOT/build/variants/lib_$NAME.so
