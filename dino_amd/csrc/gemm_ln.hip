@@ -120,6 +120,11 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
     using namespace aln;
     constexpr int KD = C::KD, PL = C::PL, BM = C::BM, BN = C::BN, MI = C::MI, NK = C::NK, RING = C::RING;
     constexpr int PIECES = C::PIECES, NBLK = C::NBLK, NI = 1;
+#ifndef ALN_DEFER_PL1
+#define ALN_DEFER_PL1 0
+#endif
+    // the deferred epilogue needs a second accumulator set: affordable at 4 waves per workgroup (512 registers per wave), not at 8
+    constexpr bool DEFER = PL == 2 || ALN_DEFER_PL1;
     const int dbg = DBG ? p.dbg : 0;            // ablations are compiled out of the production instantiation
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sA = smem;
@@ -154,26 +159,23 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
         if (is_off == w_panel_bytes) is_off = 0;
         is_slot = is_slot + 1 == RING ? 0 : is_slot + 1;
     };
-    // Wait for the stage that is read next.  gfx9 retires loads, stores and LDS-DMA through one in-order vmcnt: after a refill
-    // was issued, at least the (RING-1) * PIECES pieces of the three younger stages are behind the awaited one, so
-    // vmcnt((RING-1) * PIECES) always covers it.  Epilogue stores / bias loads that are younger still make the wait stricter
+    // Wait for the stage whose first half is read next (two stages after the one just multiplied).  gfx9 retires loads, stores
+    // and LDS-DMA through one in-order vmcnt: after a refill was issued, at least the (RING-2) * PIECES pieces of the two younger
+    // stages are behind the awaited one, so vmcnt((RING-2) * PIECES) always covers it.  Epilogue stores / bias loads that are younger still make the wait stricter
     // than necessary by at most their count (it then also retires the oldest in-flight stage early, which was issued two
     // k-steps ago anyway) -- cheaper than tracking exact counts: a 48-way wait ladder per k-step cost more than it saved.
     // A drained block's stores stay younger than the awaited stage for three waits (the one of their own k-step and the next
     // two); counting them keeps the wait from forcing the stage issued one k-step ago (measured: 38 us of the qkv launch).
-#ifndef ALN_STAGGER
-#define ALN_STAGGER 0       // measured (same box, tools/ab_ops.sh): no gain from the stagger
-#endif
-    const int drain_ofs = (ALN_STAGGER && wave >= C::NWAVES / 2) ? 1 : 0;
+    // (draining the second wave of each SIMD one k-step later than its partner measured no gain: tools/ab_ops.sh, same box)
     constexpr int DRAIN_STORES = 2 * PL;
     (void)DRAIN_STORES;
     int stores_young = 0;
     auto wait_next_stage = [&](bool refilled) {
         if (!refilled) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last RING k-steps of the kernel
 #ifdef ALN_STORE_AWARE_WAIT     // measured slower than the plain wait on the same box (parity mode: 7 %), kept for reference
-        else if (stores_young > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * PIECES + DRAIN_STORES) : "memory");
+        else if (stores_young > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * PIECES + DRAIN_STORES) : "memory");
 #endif
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * PIECES) : "memory");
         stores_young = stores_young > 0 ? stores_young - 1 : 0;
     };
 
@@ -278,28 +280,60 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
         store_planes(v, base, pstride);
     };
 
-    int rd_slot = 0;                // ring slot of the stage whose fragments are read next
-    // s_waitcnt lgkmcnt(0) as the builtin (vmcnt 63, expcnt 7 = no wait): the compiler's own wait-count pass sees it and learns
-    // that the prefetched fragments have arrived; behind an inline-asm wait it re-waited for ALL LDS reads -- the prefetch just
-    // issued included -- in front of every MFMA group, which serialised reads and matrix work again
-    constexpr int LGKM0 = 0xC07F;
-    // fragments of half a k-step (16 of its 32 k): W block (A operand) and the MI row blocks of the image (B operand)
+    // ---- fragment pipeline.  LDS reads run TWO half-steps (one half = 16 of a stage's 32 k) ahead of their MFMAs through three
+    // rotating register sets: with one half-step of lead (two sets) every MFMA group still waited ~400 cycles for its reads
+    // (8 waves read at once; measured: the bare loop ran the matrix pipe 45 % of the time, and reading a quarter of the bytes
+    // changed nothing -- latency, not bandwidth).  The reads are inline asm with hand-counted lgkmcnt (LDS returns in order): the
+    // compiler's own wait-count pass knows nothing of them and cannot put an lgkmcnt(0) in front of every MFMA group.
     struct Half {
         bf16x8 w[PL];
         bf16x8 a[PL][MI];
     };
-    Half h0, h1;
-    auto read_half = [&](Half& f, int kt, int kk) {
-        const char* sw = sWw + rd_slot * C::W_WAVE;
-        const char* sa = sA + kt * C::A_SLAB;
+    Half hs[3];
+    constexpr int RD = PL * (1 + MI);       // ds_read_b128 per half-step
+    static_assert(2 * RD <= 15, "lgkmcnt is a 4-bit counter");
+    static_assert(NK % 3 == 0, "the k-loop is unrolled by three k-steps = six half-steps = two turns of the three register sets");
+    const uint32_t lds_a = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)sA;
+    const uint32_t lds_w = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)sWw;
+    uint32_t la[2], lw[2];                  // per-lane fragment addresses of the two halves (image slab 0 / ring slot 0)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        la[kk] = lds_a + off64(lr, kk * 2 + lh);
+        lw[kk] = lds_w + off64(lr, kk * 2 + lh);
+    }
+    int cs_slot = 0;                        // ring slot of the stage being multiplied
+    auto issue_reads = [&](auto set_tag, int kt, int kk, int slot) {
+        constexpr int S = decltype(set_tag)::value;
+        Half& f = hs[S];
+        const uint32_t aw = lw[kk] + slot * C::W_WAVE;
+        const uint32_t aa = la[kk] + kt * C::A_SLAB;
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl) {
-            f.w[pl] = lds_frag(sw + pl * C::W_BLOCK + off64(lr, kk * 2 + lh));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(f.w[pl]) : "v"(aw + pl * C::W_BLOCK));
+            const uint32_t ap = aa + pl * C::A_PLANE;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(f.a[pl][0]) : "v"(ap));
+            if (MI > 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f.a[pl][1 % MI]) : "v"(ap));
+            if (MI > 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.a[pl][2 % MI]) : "v"(ap));
+            if (MI > 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f.a[pl][3 % MI]) : "v"(ap));
+        }
+        static_assert(MI <= 4, "extend the read list");
+    };
+    // the fragments of set S have arrived once at most `later` younger reads are outstanding; every register of the set passes
+    // through the statement so that no consumer can be scheduled above it
+    auto await_set = [&](auto set_tag, auto later_tag) {
+        constexpr int S = decltype(set_tag)::value, LATER = decltype(later_tag)::value;
+        Half& f = hs[S];
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LATER) : "memory");
 #pragma unroll
-            for (int i = 0; i < MI; ++i) f.a[pl][i] = lds_frag(sa + pl * C::A_PLANE + off64(i * 32 + lr, kk * 2 + lh));
+        for (int pl = 0; pl < PL; ++pl) {
+            asm volatile("" : "+v"(f.w[pl]));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(f.a[pl][i]));
         }
     };
-    auto mfma_half = [&](const Half& f, bool cols_valid) {
+    auto mfma_set = [&](auto set_tag, bool cols_valid) {
+        constexpr int S = decltype(set_tag)::value;
+        const Half& f = hs[S];
         if (!cols_valid || (DBG && (dbg & 8))) return;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {      // rows of the MFMA = W rows (output columns), columns = token rows
@@ -310,39 +344,54 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
             acc[i][0] = mfma32(f.w[0], f.a[0][i], acc[i][0]);
         }
     };
-    // one k-step.  On entry h0 holds the first half of this stage (read during the previous step's second half); LDS reads run
-    // half a step ahead of their MFMAs, so a wave's own read latency hides behind its own matrix work.
-    auto kstep = [&](int bn, int kt, bool cols_valid) {
-        read_half(h1, kt, 1);
-        mfma_half(h0, cols_valid);
-        if (kt == 0) {                      // bias of the NEXT tile (wraps to the first tile of the next panel)
+    // one half-step: MFMAs of half (kt, kk) from set U % 3 while the reads of the half two half-steps later go to set (U+2) % 3.
+    // `tail` = the last two half-steps of a panel issue no reads (the next panel's fill does, from the new image).
+    auto half_step = [&](auto u_tag, int bn, int kt, int kk, bool cols_valid, bool tail) {
+        constexpr int U = decltype(u_tag)::value;
+        using Cur = std::integral_constant<int, U % 3>;
+        using Nxt = std::integral_constant<int, (U + 2) % 3>;
+        if (!tail) {
+            issue_reads(Nxt{}, kt + 1 == NK ? 0 : kt + 1, kk, cs_slot + 1 == RING ? 0 : cs_slot + 1);
+            await_set(Cur{}, std::integral_constant<int, 2 * RD>{});
+        } else {
+            await_set(Cur{}, std::integral_constant<int, 0>{});
+        }
+        mfma_set(Cur{}, cols_valid);
+        if (kk == 1) {
+            // this stage's fragments are all in registers: refill its slot with stage step + RING, then make sure stage step + 2
+            // has landed (its first half is read at the next half-step); the private slot needs no barrier
+            if (!(dbg & 2)) {
+                const bool refill = is_step < total_steps;
+                if (refill) issue_next();
+                wait_next_stage(refill);
+            } else {
+                ++is_step;
+            }
+            asm volatile("" ::: "memory");
+            cs_slot = cs_slot + 1 == RING ? 0 : cs_slot + 1;
+        }
+    };
+    // three k-steps = six half-steps = two turns of the register sets; j-th group of a tile
+    auto kgroup = [&](int bn, int j, bool cols_valid) {
+        const int kt0 = 3 * j;
+        const bool last_group = bn + 1 == nbn && j + 1 == NK / 3;     // of the panel
+        half_step(std::integral_constant<int, 0>{}, bn, kt0, 0, cols_valid, false);
+        if (j == 0) {                       // bias of the NEXT tile (wraps to the first tile of the next panel)
             const int bn_next = bn + 1 < nbn ? bn + 1 : 0;
             load_bias(bn_next, bias_nxt);
         }
-        // deferred epilogue of the previous tile: one block at k-steps 1, 4, 7, 10 (static register indexing per arm)
-        // (the second wave of each SIMD -- waves NWAVES/2.. -- drains one k-step later: SIMD partners run the same program from
-        //  the same barrier and would otherwise reach their VALU-heavy pieces together and leave the matrix pipe idle together)
-        if (have_prev) {
-            const int kd = kt - drain_ofs;
-            if (kd == 1) drain_block(std::integral_constant<int, 0>{});
-            if (NBLK > 1 && kd == 4) drain_block(std::integral_constant<int, 1 % NBLK>{});
-            if (NBLK > 2 && kd == 7) drain_block(std::integral_constant<int, 2 % NBLK>{});
-            if (NBLK > 3 && kd == 10) drain_block(std::integral_constant<int, 3 % NBLK>{});
+        half_step(std::integral_constant<int, 1>{}, bn, kt0, 1, cols_valid, false);
+        half_step(std::integral_constant<int, 2>{}, bn, kt0 + 1, 0, cols_valid, false);
+        // deferred epilogue of the previous tile: block j between the halves of the group's middle k-step
+        if (DEFER && have_prev) {
+            if (j == 0) drain_block(std::integral_constant<int, 0>{});
+            if (NBLK > 1 && j == 1) drain_block(std::integral_constant<int, 1 % NBLK>{});
+            if (NBLK > 2 && j == 2) drain_block(std::integral_constant<int, 2 % NBLK>{});
+            if (NBLK > 3 && j == 3) drain_block(std::integral_constant<int, 3 % NBLK>{});
         }
-        __builtin_amdgcn_s_waitcnt(LGKM0);                      // h1 has arrived: this stage's slot is free
-        rd_slot = rd_slot + 1 == RING ? 0 : rd_slot + 1;
-        if (!(dbg & 2)) {
-            const bool refill = is_step < total_steps;
-            if (refill) issue_next();                           // refill it with stage step + RING
-            wait_next_stage(refill);                            // stage step + 1 has landed (its slot is private: no barrier)
-        } else {
-            ++is_step;
-        }
-        asm volatile("" ::: "memory");      // nothing below may be scheduled above the stage issue (the marks count on it)
-        const bool last_of_panel = bn + 1 == nbn && kt + 1 == NK;
-        if (!last_of_panel) read_half(h0, kt + 1 == NK ? 0 : kt + 1, 0);     // (else: the next panel's fill, from the new image)
-        mfma_half(h1, cols_valid);
-        __builtin_amdgcn_s_waitcnt(LGKM0);                      // h0 (next stage) has arrived
+        half_step(std::integral_constant<int, 3>{}, bn, kt0 + 1, 1, cols_valid, false);
+        half_step(std::integral_constant<int, 4>{}, bn, kt0 + 2, 0, cols_valid, last_group);
+        half_step(std::integral_constant<int, 5>{}, bn, kt0 + 2, 1, cols_valid, last_group);
     };
     load_bias(0, bias_cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // once: the first tile's bias and the ring's first RING stages
@@ -407,15 +456,15 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
         }
         __builtin_amdgcn_s_barrier();
 
-        // fill the fragment pipeline: the stage of this panel's first k-step was waited for already (kernel start / the last
-        // k-step of the previous panel); fragments are read one k-step ahead of their MFMAs from here on
-        read_half(h0, 0, 0);
-        __builtin_amdgcn_s_waitcnt(LGKM0);
+        // fill the fragment pipeline: this panel's first two stages were waited for already (kernel start / the last k-steps of
+        // the previous panel)
+        issue_reads(std::integral_constant<int, 0>{}, 0, 0, cs_slot);
+        issue_reads(std::integral_constant<int, 1>{}, 0, 1, cs_slot);
         for (int bn = 0; bn < nbn; ++bn) {
             const bool cols_valid = bn + 1 < nbn || wave_cols_valid_last;      // wave-uniform
             init_acc(bias_cur);
 #pragma unroll 1
-            for (int kt = 0; kt < NK; ++kt) kstep(bn, kt, cols_valid);
+            for (int j = 0; j < NK / 3; ++j) kgroup(bn, j, cols_valid);
             // ---- the tile is complete: hand it to the deferred epilogue
 #pragma unroll
             for (int i = 0; i < MI; ++i) accp[i][0] = acc[i][0];
@@ -423,16 +472,24 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
             prev_valid = cols_valid;
             prev_m0 = panel * BM;
             prev_n0 = bn * BN + wc * 32;
+            if (!DEFER) {       // straight away (the copy above is then only a renaming)
+                drain_block(std::integral_constant<int, 0>{});
+                if (NBLK > 1) drain_block(std::integral_constant<int, 1 % NBLK>{});
+                if (NBLK > 2) drain_block(std::integral_constant<int, 2 % NBLK>{});
+                if (NBLK > 3) drain_block(std::integral_constant<int, 3 % NBLK>{});
+            }
 #pragma unroll
             for (int j = 0; j < NI; ++j) bias_cur[j] = bias_nxt[j];
         }
     }
 
     // ---- the last tile has no successor to hide behind
-    drain_block(std::integral_constant<int, 0>{});
-    if (NBLK > 1) drain_block(std::integral_constant<int, 1 % NBLK>{});
-    if (NBLK > 2) drain_block(std::integral_constant<int, 2 % NBLK>{});
-    if (NBLK > 3) drain_block(std::integral_constant<int, 3 % NBLK>{});
+    if (DEFER) {
+        drain_block(std::integral_constant<int, 0>{});
+        if (NBLK > 1) drain_block(std::integral_constant<int, 1 % NBLK>{});
+        if (NBLK > 2) drain_block(std::integral_constant<int, 2 % NBLK>{});
+        if (NBLK > 3) drain_block(std::integral_constant<int, 3 % NBLK>{});
+    }
 }
 
 template <int EPI, class C>
