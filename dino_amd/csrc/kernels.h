@@ -74,7 +74,7 @@ struct Options {
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
     int attn_dbg = 0;        // same for AttnParams::dbg
     int attn_variant = 3;    // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
-                             // tile work
+                             // tile work; bit 2 (bf16 mode): the software-pipelined kernel (attention_pipe.hip)
 };
 Options& options();
 
@@ -87,6 +87,7 @@ struct AttnParams {
     int dbg;                           // timing-only ablations: bit0 skip max/exp, bit1 skip steady-state loads, bit2 skip PV
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
+int launch_attention_pipe(const AttnParams& p, hipStream_t s); // bf16 only: software-pipelined across tiles (attention_pipe.hip)
 
 // fp32 [rows, cols] -> bf16 planes [planes][rows_pad][cols_pad], zero padded
 int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,

@@ -168,7 +168,7 @@ def test_attention_rescale_branch(cuda, planes):
 
 
 @pytest.mark.parametrize("planes", [1, 2])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 7])
 def test_attention_kernel_variants(cuda, planes, variant):
     """dinoseg_set_option('attn_variant'): bit 0 = overflow check on the row sums instead of a per-tile row maximum, bit 1 =
     idle waves of the last q-tile skip the tile work.  Without a rescale after the first tile both bits do the same
@@ -186,7 +186,8 @@ def test_attention_kernel_variants(cuda, planes, variant):
         capi.check(lib.dinoseg_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT))
     tol = 1.2e-2 if planes == 1 else 1e-4
     lse_tol = 6e-3 if planes == 1 else 1e-4
-    assert torch.equal(got, base) and torch.equal(lse, lse0)
+    if planes == 2 or not (variant & 4):      # (the pipelined kernel sums the rows in a different order)
+        assert torch.equal(got, base) and torch.equal(lse, lse0)
     assert float((got - ref).abs().max()) <= tol and float((lse - ref_lse).abs().max()) <= lse_tol
     assert float((got2 - ref2).abs().max()) <= tol and float((got3 - ref3).abs().max()) <= tol
     assert float((lse2 - ref_lse2).abs().max()) <= lse_tol
