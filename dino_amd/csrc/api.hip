@@ -432,7 +432,8 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
         const bool fuse_ln = options().gemm_ln != 0;
-        if (fuse_ln && h->packed_slab.count(b + "attn.qkv.weight")) {
+        // (the fused kernel keeps 32-bit output row offsets)
+        if (fuse_ln && h->packed_slab.count(b + "attn.qkv.weight") && L.qkv_plane < (1L << 31)) {
             // LN1 + qkv in one launch: X rows are normalised in the GEMM's prologue, no bf16 A round trip (gemm_ln.hip)
             LnGemmParams g = {};
             g.X = X; g.ldx = D; g.gamma = W(h, b + "norm1.weight"); g.beta = W(h, b + "norm1.bias"); g.eps = c.ln_eps;
@@ -505,7 +506,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.out_f32 = X; g.ldo_f32 = D;
             DSEG_PROF(DINOSEG_PROF_PROJ, DSEG_TRY(launch_gemm(g, s)));
         }
-        if (fuse_ln && h->packed_slab.count(b + "mlp.fc1.weight")) {
+        if (fuse_ln && h->packed_slab.count(b + "mlp.fc1.weight") && L.hb_plane < (1L << 31)) {
             LnGemmParams g = {};
             g.X = X; g.ldx = D; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
             g.W = h->packed_slab.at(b + "mlp.fc1.weight"); g.bias = W(h, b + "mlp.fc1.bias");

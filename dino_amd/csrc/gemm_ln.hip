@@ -125,7 +125,10 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
 #endif
     // the deferred epilogue needs a second accumulator set: affordable at 4 waves per workgroup (512 registers per wave), not at 8
     constexpr bool DEFER = PL == 2 || ALN_DEFER_PL1;
-    const int dbg = DBG ? p.dbg : 0;            // ablations are compiled out of the production instantiation
+#ifndef ALN_ABL
+#define ALN_ABL 0           // compile-time ablation bits for A/B builds (tools/build_variant.sh): exact, unlike the runtime ones
+#endif
+    const int dbg = DBG ? p.dbg : ALN_ABL;      // ablations are compiled out of the production instantiation
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sA = smem;
     char* const sW = smem + C::A_BYTES;
@@ -160,20 +163,20 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
         is_slot = is_slot + 1 == RING ? 0 : is_slot + 1;
     };
     // Wait for the stage whose first half is read next (two stages after the one just multiplied).  gfx9 retires loads, stores
-    // and LDS-DMA through one in-order vmcnt: after a refill was issued, at least the (RING-2) * PIECES pieces of the two younger
-    // stages are behind the awaited one, so vmcnt((RING-2) * PIECES) always covers it.  Epilogue stores / bias loads that are younger still make the wait stricter
-    // than necessary by at most their count (it then also retires the oldest in-flight stage early, which was issued two
-    // k-steps ago anyway) -- cheaper than tracking exact counts: a 48-way wait ladder per k-step cost more than it saved.
-    // A drained block's stores stay younger than the awaited stage for three waits (the one of their own k-step and the next
-    // two); counting them keeps the wait from forcing the stage issued one k-step ago (measured: 38 us of the qkv launch).
-    // (draining the second wave of each SIMD one k-step later than its partner measured no gain: tools/ab_ops.sh, same box)
-    constexpr int DRAIN_STORES = 2 * PL;
-    (void)DRAIN_STORES;
+    // and LDS-DMA through one in-order vmcnt, so the wait names how many YOUNGER operations may stay in flight: the
+    // (RING-2) * PIECES pieces of the two later stages, plus -- for the two waits after an epilogue -- that epilogue's stores.
+    // Without the stores in the count the wait also retires the stage issued one k-step ago and most of the stores; an exact
+    // count (ALN_STORE_AWARE_WAIT) measured no faster, so the plain count is used.  The count must never exceed what was
+    // really issued after the awaited stage; `stores_young` is armed only by a drain that did store.
+    //   drain position               stores are younger than the awaited stage at the waits of
+    //   after step d's wait (tile end, or between the halves of step d+1)      steps d+1 and d+2
+    constexpr int TILE_STORES = DEFER ? 2 * PL : NBLK * 2 * PL;      // 16-byte stores one drain issues (without aux_out)
+    (void)TILE_STORES;
     int stores_young = 0;
     auto wait_next_stage = [&](bool refilled) {
         if (!refilled) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last RING k-steps of the kernel
-#ifdef ALN_STORE_AWARE_WAIT     // measured slower than the plain wait on the same box (parity mode: 7 %), kept for reference
-        else if (stores_young > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * PIECES + DRAIN_STORES) : "memory");
+#ifdef ALN_STORE_AWARE_WAIT      // measured (tools/ab_ops.sh, one box): no faster than the plain count -- off
+        else if (stores_young > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * PIECES + TILE_STORES) : "memory");
 #endif
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * PIECES) : "memory");
         stores_young = stores_young > 0 ? stores_young - 1 : 0;
@@ -188,7 +191,8 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
     // ---- accumulators.  acc = the tile being multiplied; accp = the finished previous tile, drained between the k-steps
     f32x16 acc[MI][NI], accp[MI][NI];
     bool have_prev = false;
-    int prev_m0 = 0, prev_n0 = 0;             // global row / column of the previous tile's wave block
+    int prev_n0 = 0;                          // first column of the previous tile's wave block
+    uint32_t row_off[MI], prev_row_off[MI];   // element offset of this lane's output row in each row block (current / drained panel)
     bool prev_valid = false;                  // previous tile: does this wave own real columns?
     // bias values of the CURRENT / NEXT tile (lane = column): loaded by asm (the compiler must not wait for them while the
     // LDS-DMA ring is in flight: it would drain the ring); they are old by the time the next tile starts
@@ -231,21 +235,20 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = accp[i][j][r];
-        int gm = prev_m0 + i * 32 + lr;
-        gm = gm < M ? gm : M - 1;                       // rows past M are copies of row M-1: identical bytes
         const int nb = prev_n0 + j * 32;                // first column of the block (wave-uniform)
         if (nb >= N) return;                            // padding columns of the last tile
         bf16_t* base;
         long pstride;
         int which = 0;
+        // this lane's output row offset was worked out once per panel (prev_row_off: one integer division per row block and
+        // panel instead of one per block and tile); the column part is wave-uniform
         if (EPI == EPI_QKV) {
             which = nb / p.dmodel;                      // the block lies inside one head of one of Q / K / V
             const int hcol = nb - which * p.dmodel;
-            const int bq = gm / p.ntok, tok = gm - bq * p.ntok;
-            base = (which == 0 ? p.q : (which == 1 ? p.k : p.v)) + ((long)(bq * p.heads + (hcol >> 6)) * p.npad + tok) * 64 + (hcol & 63);
+            base = (which == 0 ? p.q : (which == 1 ? p.k : p.v)) + prev_row_off[i] + ((long)(hcol >> 6) * p.npad * 64 + (hcol & 63));
             pstride = p.qkv_plane;
         } else {
-            base = p.out_bf16 + (long)gm * p.ldo + nb;
+            base = p.out_bf16 + prev_row_off[i] + nb;
             pstride = p.out_plane;
         }
         auto store_planes = [&](const float* val, bf16_t* dst, long plane_stride) {
@@ -270,8 +273,10 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
                 }
             }
         };
-        stores_young = RING - 1;        // (with aux_out there are more stores than counted: the waits are then merely stricter)
-        if (EPI == EPI_GELU && p.aux_out != nullptr) store_planes(v, p.aux_out + (long)gm * p.ldo + nb, p.aux_plane);
+        // (DEFER: one block per call; otherwise the NBLK calls of a tile end re-arm the same two waits.  With aux_out there are
+        //  more stores than counted: the waits are then merely stricter)
+        stores_young = 2;
+        if (EPI == EPI_GELU && p.aux_out != nullptr) store_planes(v, p.aux_out + prev_row_off[i] + nb, p.aux_plane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (EPI == EPI_GELU) v[r] = PL == 1 ? gelu_fast(v[r]) : gelu_erf(v[r]);
@@ -305,6 +310,7 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
     auto issue_reads = [&](auto set_tag, int kt, int kk, int slot) {
         constexpr int S = decltype(set_tag)::value;
         Half& f = hs[S];
+        if ((DBG || ALN_ABL) && (dbg & 32)) return;      // ablation: no fragment reads (stale registers)
         const uint32_t aw = lw[kk] + slot * C::W_WAVE;
         const uint32_t aa = la[kk] + kt * C::A_SLAB;
 #pragma unroll
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
     auto mfma_set = [&](auto set_tag, bool cols_valid) {
         constexpr int S = decltype(set_tag)::value;
         const Half& f = hs[S];
-        if (!cols_valid || (DBG && (dbg & 8))) return;
+        if (!cols_valid || ((DBG || ALN_ABL) && (dbg & 8))) return;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {      // rows of the MFMA = W rows (output columns), columns = token rows
             if (PL == 2) {
@@ -456,6 +462,18 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
         }
         __builtin_amdgcn_s_barrier();
 
+        // output row offsets of this panel (rows past M are copies of row M-1: their stores rewrite identical bytes)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            int gm = panel * BM + i * 32 + lr;
+            gm = gm < M ? gm : M - 1;
+            if (EPI == EPI_QKV) {
+                const int bq = gm / p.ntok, tok = gm - bq * p.ntok;
+                row_off[i] = (uint32_t)((bq * p.heads * p.npad + tok) * 64);
+            } else {
+                row_off[i] = (uint32_t)gm * (uint32_t)p.ldo;
+            }
+        }
         // fill the fragment pipeline: this panel's first two stages were waited for already (kernel start / the last k-steps of
         // the previous panel)
         issue_reads(std::integral_constant<int, 0>{}, 0, 0, cs_slot);
@@ -470,7 +488,8 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
             for (int i = 0; i < MI; ++i) accp[i][0] = acc[i][0];
             have_prev = true;
             prev_valid = cols_valid;
-            prev_m0 = panel * BM;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) prev_row_off[i] = row_off[i];
             prev_n0 = bn * BN + wc * 32;
             if (!DEFER) {       // straight away (the copy above is then only a renaming)
                 drain_block(std::integral_constant<int, 0>{});
@@ -520,7 +539,8 @@ int launch_gemm_ln(const LnGemmParams& p0, int K, int planes, hipStream_t s) {
     if (p0.M <= 0) return 0;
     LnGemmParams p = p0;
     p.dbg = options().gemm_dbg;
-    if (!gemm_ln_supported(K, p.N, planes, p.epi, p.dmodel) || p.ldx % 4 != 0) {
+    const long out_elems = p.epi == EPI_QKV ? p.qkv_plane : (long)p.M * p.ldo;      // 32-bit row offsets inside the kernel
+    if (!gemm_ln_supported(K, p.N, planes, p.epi, p.dmodel) || p.ldx % 4 != 0 || out_elems >= (1L << 31)) {
         dinoseg_set_error("gemm_ln: unsupported shape K=%d N=%d planes=%d epi=%d ldx=%d", K, p.N, planes, p.epi, p.ldx);
         return -1;
     }

@@ -16,7 +16,22 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     if "dseg::" in r["Kernel_Name"]:
         agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+dur = collections.defaultdict(list)
+try:
+    for r in csv.DictReader(open("$OUT/ops_kernel_trace.csv")):
+        if "dseg::" in r["Kernel_Name"]:
+            dur[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+except Exception as e:
+    print("no kernel trace:", e)
 for k, d in agg.items():
-    print(k, {c: round(sum(v) / len(v)) for c, v in d.items()}, "n=%d" % len(next(iter(d.values()))))
+    line = {c: round(sum(v) / len(v)) for c, v in d.items()}
+    extra = ""
+    if k in dur:
+        ns = sum(dur[k]) / len(dur[k])
+        extra = " avg_us=%.1f" % (ns / 1e3)
+        if "GRBM_GUI_ACTIVE" in line:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md 'DVFS give-back')
+            extra += " clock_GHz=%.3f" % (line["GRBM_GUI_ACTIVE"] / 8 / ns)
+    print(k, line, "n=%d" % len(next(iter(d.values()))), extra)
 PY
 rm -f $OUT/ops_kernel_trace.csv
