@@ -286,6 +286,18 @@ static int train_forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, 
         float* Xout = l + 1 < NB ? F32(L.Xin + o + L.blk_stride) : F32(L.Xfin);
         bf16_t *A1 = B16(L.A1 + o), *Q = B16(L.Q + o), *Kb = B16(L.K + o), *V = B16(L.V + o), *CTX = B16(L.CTX + o);
         bf16_t *A2 = B16(L.A2 + o), *HPRE = B16(L.HPRE + o), *HB = B16(L.HB + o);
+        const bool fuse_ln = options().gemm_ln != 0 && L.qkv_plane < (1L << 31) && L.f_plane < (1L << 31);
+        if (fuse_ln && h->packed_slab.count(b + "attn.qkv.weight")) {
+            // LN1 + qkv in one launch; the normalised planes the weight gradient needs are a by-product (a_out)
+            LnGemmParams g = {};
+            g.X = Xin; g.ldx = D; g.gamma = W(h, b + "norm1.weight"); g.beta = W(h, b + "norm1.bias"); g.eps = c.ln_eps;
+            g.W = h->packed_slab.at(b + "attn.qkv.weight"); g.bias = W(h, b + "attn.qkv.bias");
+            g.M = L.M; g.N = 3 * D; g.epi = EPI_QKV;
+            g.q = Q; g.k = Kb; g.v = V; g.qkv_plane = L.qkv_plane;
+            g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
+            g.a_out = A1; g.a_plane = L.a_plane;
+            DSEG_TRY(launch_gemm_ln(g, D, P, s));
+        } else {
         DSEG_TRY(launch_layernorm(Xin, W(h, b + "norm1.weight"), W(h, b + "norm1.bias"), c.ln_eps, L.M, D, A1, L.a_plane, P,
                                   nullptr, 0, L.ntok, s));
         {
@@ -296,6 +308,7 @@ static int train_forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, 
             g.q = Q; g.k = Kb; g.v = V; g.qkv_plane = L.qkv_plane;
             g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
             DSEG_TRY(launch_gemm(g, s));
+        }
         }
         {
             AttnParams a = {};
@@ -312,6 +325,16 @@ static int train_forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, 
             g.resid = Xin; g.out_f32 = Xmid; g.ldo_f32 = D;
             DSEG_TRY(launch_gemm(g, s));
         }
+        if (fuse_ln && h->packed_slab.count(b + "mlp.fc1.weight")) {
+            LnGemmParams g = {};
+            g.X = Xmid; g.ldx = D; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
+            g.W = h->packed_slab.at(b + "mlp.fc1.weight"); g.bias = W(h, b + "mlp.fc1.bias");
+            g.M = L.M; g.N = F; g.epi = EPI_GELU;
+            g.out_bf16 = HB; g.out_plane = L.f_plane; g.ldo = F;
+            g.a_out = A2; g.a_plane = L.a_plane;
+            g.aux_out = HPRE; g.aux_plane = L.f_plane;
+            DSEG_TRY(launch_gemm_ln(g, D, P, s));
+        } else {
         DSEG_TRY(launch_layernorm(Xmid, W(h, b + "norm2.weight"), W(h, b + "norm2.bias"), c.ln_eps, L.M, D, A2, L.a_plane, P,
                                   nullptr, 0, L.ntok, s));
         {
@@ -321,6 +344,7 @@ static int train_forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, 
             g.M = L.M; g.N = F; g.K = D; g.planes = P; g.epi = EPI_GELU; g.bias = W(h, b + "mlp.fc1.bias");
             g.out_bf16 = HB; g.out_plane = L.f_plane; g.ldo = F; g.aux_out = HPRE; g.aux_plane = L.f_plane;
             DSEG_TRY(launch_gemm(g, s));
+        }
         }
         {
             const PackedLinear& pk = h->packed.at(b + "mlp.fc2.weight");

@@ -2,10 +2,12 @@
 many times on identical inputs, with other kernels in flight on a second stream to perturb timing, and every output must be
 bit-identical to the first run and (for the GEMMs) agree with the other GEMM kernel.  python tools/race_screen.py [repeats]"""
 import sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from dino_amd import capi
-from gpu_util import pack, seeded, unpack
+from gpu_util import pack, pack_slabs, quant_like, seeded, unpack
 lib = capi.lib()
 S = capi.stream_ptr
 REP = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -64,19 +66,57 @@ for (M, N, K) in [(115232, 384, 384), (115232, 1536, 384), (28808, 384, 1536), (
     del A, W, Ap, Wp
 capi.check(lib.dinoseg_set_option(b"gemm_big", 1))
 
-import test_ops_gpu as T
-for (B, H, ntok, planes) in [(32, 6, 3601, 1), (2, 6, 3601, 2), (4, 2, 197, 1), (3, 3, 64, 1), (1, 1, 129, 2), (8, 6, 14401, 1)]:
-    npad = (ntok + 63) // 64 * 64
-    q = (torch.randn((planes, B, H, npad, 64), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
-    k = (torch.randn((planes, B, H, npad, 64), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
-    v = (torch.randn((planes, B, H, npad, 64), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
-    k[..., ntok:, :] = 0; v[..., ntok:, :] = 0
-    ctx = torch.zeros((planes, B * ntok, H * 64), dtype=torch.int16, device="cuda")
-    lse = torch.zeros((B, H, ntok), device="cuda")
+# LayerNorm-fused A-stationary GEMM (gemm_ln.hip): private LDS-DMA rings with counted vmcnt, inline-asm LDS reads with counted
+# lgkmcnt, two barriers per panel; also against LayerNorm + the 128x128 kernel on the same operands
+LOG2E = 1.4426950408889634
+for (Bq, ntok, planes) in [(32, 3601, 1), (8, 3601, 2), (3, 197, 1), (1, 65, 2), (5, 1031, 1)]:
+    Hh, D = 6, 384
+    M, npad = Bq * ntok, (ntok + 63) // 64 * 64
+    X = seeded((M, D), 31) * 1.3 + 0.2
+    gam, bet = 1 + 0.2 * seeded((D,), 32), 0.1 * seeded((D,), 33)
+    for name, N, epi in (("qkv", 3 * D, 4), ("fc1", 4 * D, capi.EPI_GELU)):
+        W, bias = seeded((N, D), 34) * 0.1, seeded((N,), 35)
+        Ws = pack_slabs(W, planes)
+        out = torch.zeros((planes, M, N), dtype=torch.int16, device="cuda")
+        q = torch.zeros((planes, Bq, Hh, npad, 64), dtype=torch.int16, device="cuda")
+        k, vt = torch.zeros_like(q), torch.zeros_like(q)
 
-    def run():
-        capi.check(lib.dinoseg_op_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), B * H * npad * 64, ctx.data_ptr(),
-                                            B * ntok * H * 64, lse.data_ptr(), B, H, ntok, npad, planes, S()))
-    screen(f"attention B={B} H={H} N={ntok} planes={planes}", run, lambda: [ctx, lse])
+        def run():
+            capi.check(lib.dinoseg_op_ln_gemm(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Ws.data_ptr(), 0, bias.data_ptr(), M, N, D,
+                                              planes, epi, out.data_ptr(), M * N, q.data_ptr(), k.data_ptr(), vt.data_ptr(),
+                                              Bq * Hh * npad * 64, ntok, npad, Hh, 0.125 * LOG2E, None, None, S()))
+        screen(f"gemm_ln {name} B={Bq} N={ntok} planes={planes}", run, (lambda: [q, k, vt]) if epi == 4 else (lambda: [out]))
+        if epi != 4:
+            A = torch.zeros((planes, M, D), dtype=torch.int16, device="cuda")
+            capi.check(lib.dinoseg_op_layernorm(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, M, D, A.data_ptr(), M * D, planes, None, 0,
+                                                ntok, S()))
+            Wp = pack(W, planes)
+            ref = torch.zeros_like(out)
+            capi.check(lib.dinoseg_set_option(b"gemm_big", 0))
+            capi.check(lib.dinoseg_op_gemm(A.data_ptr(), M * D, D, Wp.data_ptr(), N * D, M, N, D, planes, epi, bias.data_ptr(), None,
+                                           ref.data_ptr(), M * N, N, S()))
+            capi.check(lib.dinoseg_set_option(b"gemm_big", 1))
+            err = float((unpack(out) - unpack(ref)).abs().max()) / max(float(unpack(ref).abs().max()), 1e-6)
+            tol = 2.0 ** -6 if planes == 1 else 2.0 ** -13
+            print(f"    vs LayerNorm + 128x128 kernel: rel max diff {err:.2e} {'OK' if err <= tol else 'MISMATCH'}", flush=True)
+            bad += err > tol
+
+import test_ops_gpu as T
+for variant in (3, 7):
+  capi.check(lib.dinoseg_set_option(b"attn_variant", variant))
+  for (B, H, ntok, planes) in [(32, 6, 3601, 1), (2, 6, 3601, 2), (4, 2, 197, 1), (3, 3, 64, 1), (1, 1, 129, 2), (8, 6, 14401, 1)]:
+      npad = (ntok + 63) // 64 * 64
+      q = (torch.randn((planes, B, H, npad, 64), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
+      k = (torch.randn((planes, B, H, npad, 64), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
+      v = (torch.randn((planes, B, H, npad, 64), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
+      k[..., ntok:, :] = 0; v[..., ntok:, :] = 0
+      ctx = torch.zeros((planes, B * ntok, H * 64), dtype=torch.int16, device="cuda")
+      lse = torch.zeros((B, H, ntok), device="cuda")
+
+      def run():
+          capi.check(lib.dinoseg_op_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), B * H * npad * 64, ctx.data_ptr(),
+                                              B * ntok * H * 64, lse.data_ptr(), B, H, ntok, npad, planes, S()))
+      screen(f"attention variant {variant} B={B} H={H} N={ntok} planes={planes}", run, lambda: [ctx, lse])
+capi.check(lib.dinoseg_set_option(b"attn_variant", 3))
 print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad})")
 sys.exit(1 if bad else 0)
