@@ -291,6 +291,7 @@ def main():
     achieved = att_flops / (att_avg_ms * 1e-3) / 1e12 if att_n else None
 
     traffic = None
+    clock = None
     tpath = os.path.join(ROOT, "profiles", "attention_traffic.json")
     if os.path.exists(tpath):
         # HBM bytes per attention launch from the committed rocprofv3 PMC passes of this same command
@@ -299,6 +300,7 @@ def main():
         if (tj.get("batch"), tj.get("resolution"), tj.get("precision")) == (a.batch, a.res, a.precision) \
                 and a.arch == "vit_small":
             traffic = tj["hbm_bytes_per_launch"]
+            clock = tj.get("clock_ghz_under_load")
 
     if rank == 0:
         out = {
@@ -318,9 +320,12 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (fused QK^T-softmax-PV, head_dim 64)",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / peak, 4),
-                         "peak_note": "2.5 PFLOP/s = dense bf16 MFMA at the nominal 2.4 GHz (MI355X_MICROARCH.md); the clock this "
-                                      "chip holds under MFMA load is measured per round with PMC (GRBM_GUI_ACTIVE) and quoted in "
-                                      "profiles/ and DESIGN.md section 5",
+                         "peak_note": "peak = dense bf16 MFMA at the nominal 2.4 GHz (MI355X_MICROARCH.md).  clock_ghz_under_load = what "
+                                      "this kernel was measured to hold (rocprofv3 PMC GRBM_GUI_ACTIVE / 8 / duration, committed in "
+                                      "profiles/attention_traffic.json); peak_at_measured_clock scales the peak by it",
+                         "clock_ghz_under_load": clock,
+                         "peak_at_measured_clock": None if clock is None else round(peak * clock / 2.4, 1),
+                         "frac_at_measured_clock": None if (clock is None or achieved is None) else round(achieved / (peak * clock / 2.4), 4),
                          "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/attention_traffic.json)",
                          "algorithmic_bytes_per_launch": 4 * a.batch * cfg.num_heads * ((a.res // 8) ** 2 + 1) * 64 * 2

@@ -30,6 +30,9 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
+    old_traffic = {}
+    if os.path.exists(os.path.join(dst, "attention_traffic.json")):
+        old_traffic = json.load(open(os.path.join(dst, "attention_traffic.json")))
 
     rows = list(csv.DictReader(open(os.path.join(src, "trace", "bench_kernel_stats.csv"))))
     keep = [r for r in rows if "dseg::" in r["Name"]] + [r for r in rows if "dseg::" not in r["Name"]][:3]
@@ -74,6 +77,14 @@ def main():
                    "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = 2*FETCH_SIZE*1024 + "
                              "WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction)"},
                   open(os.path.join(dst, "attention_traffic.json"), "w"), indent=1)
+        # (the clock fields are measured by a different pass -- tools/pmc_ops.sh -- and carried over)
+
+    if old_traffic:
+        tj = json.load(open(os.path.join(dst, "attention_traffic.json")))
+        for key, val in old_traffic.items():
+            if key.startswith("clock_"):
+                tj[key] = val
+        json.dump(tj, open(os.path.join(dst, "attention_traffic.json"), "w"), indent=1)
 
     with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
         f.write(f"# rocprofv3 summary `{tag}`\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 "
