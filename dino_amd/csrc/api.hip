@@ -431,7 +431,11 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     // ---- transformer blocks (vision_transformer.py:122-140) ----
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
-        const bool fuse_ln = options().gemm_ln != 0;
+        // gemm_ln: 0 never fused, 2 always, 1 (default) by measurement: bf16 fused; bf16x3 fused only for small batches -- with
+        // >= 512 tiles of 128 x 384 the separate LayerNorm + the hi+lo configuration of the persistent GEMM is faster
+        // (B = 32: fc1 30 + 534 us against 670 fused; the fused kernel's 64-row panels run one wave per SIMD)
+        const bool big_x3 = P == 2 && options().gemm_big && (long)((L.M + 127) / 128) * 3 >= 512;
+        const bool fuse_ln = options().gemm_ln == 2 || (options().gemm_ln == 1 && !big_x3);
         // (the fused kernel keeps 32-bit output row offsets)
         if (fuse_ln && h->packed_slab.count(b + "attn.qkv.weight") && L.qkv_plane < (1L << 31)) {
             // LN1 + qkv in one launch: X rows are normalised in the GEMM's prologue, no bf16 A round trip (gemm_ln.hip)

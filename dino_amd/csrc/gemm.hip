@@ -273,7 +273,9 @@ int launch_gemm(const GemmParams& p0, hipStream_t s) {
         // or the K loop is long; attn.proj (451 tiles, K = 384) is faster on the 128x128 kernel (tile quantisation)
         // A small batch (single-frame predict: M = 3601 -> 15 row panels) leaves most CUs without a 256x384 tile:
         // below 128 tiles the 128x128 kernel has 3-6x more workgroups to spread (fc2 at B = 1: 60 -> 40 us).
-        const long tiles = (long)((p.M + 255) / 256) * (p.N / 384);
+        // (planes == 2: 128-row tiles of three times the work)
+        const int bm_big = p.planes == 2 ? 128 : 256;
+        const long tiles = (long)((p.M + bm_big - 1) / bm_big) * (p.N / 384);
         if (options().gemm_big > 1 || p.K % BK != 0 || (tiles >= 128 && (tiles >= 512 || p.K >= 1024))) return launch_gemm_big(p, s);
     }
     return launch_gemm_small(p, s);

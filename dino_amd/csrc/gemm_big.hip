@@ -26,12 +26,13 @@ namespace dseg {
 namespace big {
 constexpr int BK = 32;
 // WM x WN waves, each MI x NI accumulators of 32x32; STAGES ring slots; WGS = persistent workgroups per CU
-template <int WM_, int WN_, int MI_, int NI_, int STAGES_, int WGS_>
+template <int WM_, int WN_, int MI_, int NI_, int STAGES_, int WGS_, int PL_ = 1>
 struct Cfg {
-    static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, STAGES = STAGES_, WGS = WGS_;
+    static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, STAGES = STAGES_, WGS = WGS_, PL = PL_;
     static constexpr int NWAVES = WM * WN, THREADS = NWAVES * 64;
     static constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
-    static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int A_PLANE_BYTES = BM * BK * 2, W_PLANE_BYTES = BN * BK * 2;        // one operand plane of one k-slab
+    static constexpr int A_BYTES = PL * A_PLANE_BYTES, W_BYTES = PL * W_PLANE_BYTES, STAGE_BYTES = A_BYTES + W_BYTES;
     static constexpr int A_PIECES = A_BYTES / 1024;
     static constexpr int PIECES_PER_WAVE = (STAGE_BYTES / 1024) / NWAVES;
     static_assert((STAGE_BYTES / 1024) % NWAVES == 0, "LDS-DMA pieces must divide evenly over the waves");
@@ -39,6 +40,9 @@ struct Cfg {
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES + NWAVES * 4096;   // ring + one 32x32 fp32 patch per wave
 };
 using Cfg256x384 = Cfg<2, 4, 4, 3, 3, 1>;   // 120 KiB ring + 32 KiB epilogue patches, 1 workgroup / CU, 154 FLOP per staged byte
+// bf16x3 (hi + lo planes of both operands, 3 MFMAs per product): 128 x 384 tile, wave tile 64 x 96, 2 slots of 64 KiB -- one
+// slab in flight behind the one being multiplied, which takes three times as long as a bf16 slab (144 FLOP per staged byte)
+using Cfg128x384x2 = Cfg<2, 4, 2, 3, 2, 1, 2>;
 // (Cfg<2,2,2,2,2,3> = 128x128 and Cfg<2,2,2,3,2,3> = 128x192 with 3 workgroups per CU were measured: 15-25 % slower;
 //  Cfg<1,4,4,3,2,2> = 128x384 with 2 workgroups per CU: 2-28 % slower -- the two workgroups stay in phase, main loop and
 //  epilogue times simply add up as with one)
@@ -52,7 +56,7 @@ template <int EPI, class C>
 __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel(GemmParams p) {
     using namespace big;
     constexpr int BM = C::BM, BN = C::BN, STAGES = C::STAGES, STAGE_BYTES = C::STAGE_BYTES, A_BYTES = C::A_BYTES;
-    constexpr int PIECES_PER_WAVE = C::PIECES_PER_WAVE, MI = C::MI, NI = C::NI;
+    constexpr int PIECES_PER_WAVE = C::PIECES_PER_WAVE, MI = C::MI, NI = C::NI, PL = C::PL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -97,13 +101,17 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
         const int prow = lane >> 2;                         // row inside a 16-row piece
 #pragma unroll
         for (int i = 0; i < PIECES_PER_WAVE; ++i) {
-            const int piece = wave * PIECES_PER_WAVE + i;   // first A_PIECES pieces: A rows, then W rows
+            const int piece = wave * PIECES_PER_WAVE + i;   // first A_PIECES pieces: A rows (plane by plane), then W rows
             const bool is_a = piece < C::A_PIECES;          // wave-uniform
-            const int row = (is_a ? piece : piece - C::A_PIECES) * 16 + prow;
+            const int idx = is_a ? piece : piece - C::A_PIECES;
+            const int per_plane = (is_a ? C::A_PLANE_BYTES : C::W_PLANE_BYTES) / 1024;
+            const int pl = idx / per_plane;
+            const int row = (idx - pl * per_plane) * 16 + prow;
             const int c = (lane & 3) ^ ((row >> 2) & 3);
             int gm = bm_i * BM + row;
             gm = gm < M ? gm : M - 1;
-            voff[i] = (uint32_t)(((is_a ? gm * p.lda : row * K) + c * 8) * 2);
+            const long e = is_a ? pl * p.a_plane + (long)gm * p.lda : pl * p.w_plane + (long)row * K;
+            voff[i] = (uint32_t)((e + c * 8) * 2);      // < 2^32: checked by gemm_big_supported
         }
     };
     auto issue_next = [&]() {
@@ -176,15 +184,26 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
         cs_slot = cs_slot + 1 == STAGES ? 0 : cs_slot + 1;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[MI], wf[NI];
+            bf16x8 af[PL][MI], wf[PL][NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = lds_frag(sa + off64(wr * MI * 32 + i * 32 + lr, kk * 2 + lh));
+            for (int pl = 0; pl < PL; ++pl) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) wf[j] = lds_frag(sw + off64(wc * NI * 32 + j * 32 + lr, kk * 2 + lh));
+                for (int i = 0; i < MI; ++i)
+                    af[pl][i] = lds_frag(sa + pl * C::A_PLANE_BYTES + off64(wr * MI * 32 + i * 32 + lr, kk * 2 + lh));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    wf[pl][j] = lds_frag(sw + pl * C::W_PLANE_BYTES + off64(wc * NI * 32 + j * 32 + lr, kk * 2 + lh));
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);   // lane: column n, registers: rows m
+                for (int j = 0; j < NI; ++j) {      // lane: column n, registers: rows m
+                    if (PL == 2) {                  // small terms first, as in gemm.hip
+                        acc[i][j] = mfma32(af[PL - 1][i], wf[0][j], acc[i][j]);
+                        acc[i][j] = mfma32(af[0][i], wf[PL - 1][j], acc[i][j]);
+                    }
+                    acc[i][j] = mfma32(af[0][i], wf[0][j], acc[i][j]);
+                }
             if (kk == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (do_issue && issue_late) issue_next();
@@ -325,19 +344,27 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
                             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                if (EPI == EPI_GELU) v[e] = gelu_fast(v[e]);     // bf16 fast mode only (planes == 1)
+                                if (EPI == EPI_GELU) v[e] = PL == 1 ? gelu_fast(v[e]) : gelu_erf(v[e]);
                                 if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
                                 if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
                             }
-                            const uint4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                             pack_bf16x2(v[6], v[7])};
+                            uint4 o[2];
+                            split_bf16x2(v[0], v[1], o[0].x, o[1].x);
+                            split_bf16x2(v[2], v[3], o[0].y, o[1].y);
+                            split_bf16x2(v[4], v[5], o[0].z, o[1].z);
+                            split_bf16x2(v[6], v[7], o[0].w, o[1].w);
+                            bf16_t* dst;
+                            long pstride;
                             if (EPI == EPI_QKV) {
                                 const int bq = gm / p.ntok, tok = gm - bq * p.ntok;
-                                *reinterpret_cast<uint4*>(qkv_base + ((long)(bq * p.heads + (hcol >> 6)) * p.npad + tok) * 64 +
-                                                          (hcol & 63)) = o;
+                                dst = qkv_base + ((long)(bq * p.heads + (hcol >> 6)) * p.npad + tok) * 64 + (hcol & 63);
+                                pstride = p.qkv_plane;
                             } else {
-                                *reinterpret_cast<uint4*>(p.out_bf16 + (long)gm * p.ldo + gn) = o;
+                                dst = p.out_bf16 + (long)gm * p.ldo + gn;
+                                pstride = p.out_plane;
                             }
+                            *reinterpret_cast<uint4*>(dst) = o[0];
+                            if (PL == 2) *reinterpret_cast<uint4*>(dst + pstride) = o[1];
                         }
                     }
                 }
@@ -373,13 +400,17 @@ static int launch_big_cfg(const GemmParams& p, hipStream_t s) {
 
 template <int EPI>
 static int launch_big_one(const GemmParams& p, hipStream_t s) {
+    if (p.planes == 2) return launch_big_cfg<EPI, big::Cfg128x384x2>(p, s);
     return launch_big_cfg<EPI, big::Cfg256x384>(p, s);
 }
 
 bool gemm_big_supported(const GemmParams& p) {
-    return p.planes == 1 && p.bias != nullptr && p.epi <= EPI_QKV && p.resid == nullptr && p.aux_out == nullptr &&
+    static_assert(big::Cfg128x384x2::BN == big::Cfg256x384::BN && big::Cfg128x384x2::LDS_BYTES <= 160 * 1024, "one N rule, LDS budget");
+    const long a_span = (long)(p.planes - 1) * p.a_plane + (long)p.M * p.lda;                  // elements a lane offset can reach
+    const long w_span = (long)(p.planes - 1) * p.w_plane + (long)big::Cfg256x384::BN * p.K;
+    return (p.planes == 1 || p.planes == 2) && p.bias != nullptr && p.epi <= EPI_QKV && p.resid == nullptr && p.aux_out == nullptr &&
            p.ksplit <= 1 && p.N % big::Cfg256x384::BN == 0 && p.K % big::BK == 0 && p.lda % 8 == 0 && p.M >= 1 &&
-           (long)p.M * p.lda * 2 < (1L << 32) && (long)big::Cfg256x384::BN * p.K * 2 < (1L << 32) &&     // 32-bit lane offsets
+           a_span * 2 < (1L << 32) && w_span * 2 < (1L << 32) &&     // 32-bit lane offsets
 
            (p.epi != EPI_QKV || (p.dmodel % big::Cfg256x384::BN == 0 && p.N == 3 * p.dmodel));
 }

@@ -69,7 +69,7 @@ int launch_gemm_ln(const LnGemmParams& p, int K, int planes, hipStream_t s);
 
 // tuning knobs (dinoseg_set_option): see api.hip
 struct Options {
-    int gemm_ln = 1;         // qkv / fc1 through the LayerNorm-fused A-stationary kernel (gemm_ln.hip) where it applies
+    int gemm_ln = 1;         // qkv / fc1 through the LayerNorm-fused kernel (gemm_ln.hip): 0 never, 2 wherever it applies, 1 = by measurement (api.hip)
     int gemm_big = 1;        // use gemm_big.hip where it applies
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
     int attn_dbg = 0;        // same for AttnParams::dbg

@@ -350,6 +350,10 @@ def test_g4_960_batch8_frames_are_independent(cuda, precision, tol, flip_frac):
     for i in (0, 5, 7):
         lp1, am1 = m.forward_frames(frames[i:i + 1])
         assert float((lp[i * 14400:(i + 1) * 14400] - lp1).abs().max()) <= tol
-        assert float((am[i * 14400:(i + 1) * 14400] != am1).float().mean()) <= flip_frac
+        flips = am[i * 14400:(i + 1) * 14400] != am1
+        assert float(flips.float().mean()) <= max(flip_frac, 2e-4)
+        if flip_frac == 0.0 and bool(flips.any()):      # parity mode: only genuine ties may flip (top-2 margin inside the bar)
+            top2 = lp1[flips].topk(2, dim=1).values
+            assert float((top2[:, 0] - top2[:, 1]).max()) <= 2 * tol
     lp2, am2 = m.forward_frames(frames)                     # same launch shapes: bit-identical
     assert torch.equal(lp2, lp) and torch.equal(am2, am)

@@ -261,32 +261,39 @@ def test_head_final(cuda, C, K, ld):
     assert torch.equal(am.cpu().long(), ref.argmax(dim=1))
 
 
-def test_gemm_big_matches_small_kernel(cuda):
-    """Same operands through both GEMM kernels (dinoseg_set_option('gemm_big', 0/1)): identical up to fp32 summation order."""
-    M, N, K = 3000, 1152, 384         # 11.7 row panels of 256: the last one is ragged (plain residual path)
+@pytest.mark.parametrize("planes,M", [(1, 3000), (2, 3000), (2, 1409)])
+def test_gemm_big_matches_small_kernel(cuda, planes, M):
+    """Same operands through both GEMM kernels (dinoseg_set_option('gemm_big', 0/1/2)): identical up to fp32 summation order.
+    planes = 2: the 128x384 hi+lo configuration of the persistent kernel (three MFMAs per product)."""
+    N, K = 1152, 384                  # M = 3000: 11.7 row panels of 256 / 23.4 of 128 -- the last one is ragged (plain residual path)
     A, W, bias = seeded((M, K), 31), seeded((N, K), 32) * 0.1, seeded((N,), 33)
-    Ap, Wp = pack(A, 1), pack(W, 1)
+    Ap, Wp = pack(A, planes), pack(W, planes)
     lib = capi.lib()
     outs = []
     X0 = seeded((M, N), 34)
-    for big in (0, 1, 2):          # 0: 128x128 kernel; 1: auto (256x384 persistent here); 2: persistent kernel wherever it applies
+    for big in (0, 1, 2):          # 0: 128x128 kernel; 1: auto; 2: persistent kernel wherever it applies
         capi.check(lib.dinoseg_set_option(b"gemm_big", big))
         out = torch.zeros((M, N), device="cuda")
-        capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, 1, capi.EPI_PLAIN,
+        capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, planes, capi.EPI_PLAIN,
                                        bias.data_ptr(), out.data_ptr(), None, 0, 0, S()))
         X = X0.clone()
-        capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, 1, capi.EPI_RESID,
+        capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, planes, capi.EPI_RESID,
                                        bias.data_ptr(), X.data_ptr(), None, 0, 0, S()))
-        g = torch.zeros((1, M, N), dtype=torch.int16, device="cuda")
-        capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, 1, capi.EPI_GELU,
+        g = torch.zeros((planes, M, N), dtype=torch.int16, device="cuda")
+        capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, planes, capi.EPI_GELU,
                                        bias.data_ptr(), None, g.data_ptr(), M * N, N, S()))
         outs.append((out, X, unpack(g)))
     capi.check(lib.dinoseg_set_option(b"gemm_big", 1))
     scale = float(outs[0][0].abs().max())
+    ref = (unpack(Ap).double() @ unpack(Wp).double().t() + bias.double())
     for big in (1, 2):
         assert float((outs[0][0] - outs[big][0]).abs().max()) <= 2e-5 * scale, big
         assert float((outs[0][1] - outs[big][1]).abs().max()) <= 2e-5 * scale, big
-        assert float((outs[0][2] - outs[big][2]).abs().max()) <= 2.0 ** -7 * float(outs[0][2].abs().max()), big
+        gtol = 2.0 ** -7 if planes == 1 else 2.0 ** -14      # planes = 1: one kernel uses the fitted GELU, the other the erf form
+        assert float((outs[0][2] - outs[big][2]).abs().max()) <= gtol * float(outs[0][2].abs().max()), big
+    # against fp64 on the packed operands (fp32 accumulation; planes = 2 drops only the lo*lo terms), and no worse than the 128x128 kernel
+    err_big, err_small = (float((outs[i][0].double() - ref).abs().max()) for i in (2, 0))
+    assert err_big <= 2e-5 * scale and err_big <= 2.0 * err_small + 1e-7 * scale, (err_big, err_small, scale)
 
 
 @pytest.mark.gpu

@@ -68,6 +68,33 @@ def bench_gemm(quick=True):
     lib.dinoseg_set_option(b"gemm_dbg", 0)
 
 
+def bench_gemm_planes2():
+    """bf16x3 (hi + lo planes): the 128x128 kernel against the 128x384 configuration of the persistent kernel"""
+    lib = capi.lib()
+    B, ntok, D = 32, 3601, 384
+    M = B * ntok
+    for name, N, K, epi in [("proj", D, D, capi.EPI_RESID), ("fc2", D, 4 * D, capi.EPI_RESID), ("fc1", 4 * D, D, capi.EPI_GELU)]:
+        A, W = rand_bf16((2, M, K)), rand_bf16((2, N, K))
+        bias = torch.randn(N, device="cuda")
+        X = torch.zeros((M, N), device="cuda") if epi == capi.EPI_RESID else None
+        O = torch.zeros((2, M, N), dtype=torch.int16, device="cuda") if epi == capi.EPI_GELU else None
+        for big in (0, 2):
+            for dbg in (0, 1):
+                capi.check(lib.dinoseg_set_option(b"gemm_big", big))
+                capi.check(lib.dinoseg_set_option(b"gemm_dbg", dbg))
+
+                def run():
+                    capi.check(lib.dinoseg_op_gemm(A.data_ptr(), M * K, K, W.data_ptr(), N * K, M, N, K, 2, epi,
+                                                   bias.data_ptr(), capi.ptr(X), capi.ptr(O), M * N, N, capi.stream_ptr()))
+                ms = timeit(run)
+                tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+                print(f"{name:5s} planes=2 N={N:5d} K={K:5d} kernel={('small', 'auto', 'big')[big]:6s} skip_epilogue={dbg}: "
+                      f"{ms * 1e3:8.1f} us  {tf:7.1f} TFLOP/s ({3 * tf:7.1f} MFMA-equivalent)", flush=True)
+        del A, W, X, O
+    lib.dinoseg_set_option(b"gemm_big", 1)
+    lib.dinoseg_set_option(b"gemm_dbg", 0)
+
+
 def bench_lngemm():
     """LN + GEMM as two launches (layernorm_kernel + gemm_big) against the fused A-stationary kernel (gemm_ln.hip), interleaved."""
     lib = capi.lib()
@@ -169,4 +196,4 @@ def bench_attn():
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    {"gemm": bench_gemm, "attn": bench_attn, "lngemm": bench_lngemm}[what]()
+    {"gemm": bench_gemm, "gemm2": bench_gemm_planes2, "attn": bench_attn, "lngemm": bench_lngemm}[what]()
