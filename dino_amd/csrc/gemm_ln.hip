@@ -218,12 +218,17 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
             const uint32_t mid = pack_bf16x2(r1, 0.f);
             const uint32_t lo = pack_bf16x2(r1 - bf16_lo_to_f32(mid), 0.f);
             const uint4 fu = {lh == 0 ? ((hi & 0xFFFFu) | (mid << 16)) : 0u, lh == 0 ? (lo & 0xFFFFu) : 0u, 0u, 0u};
+            // one MFMA per row block with C = 0 (an inline constant): computing the block once and copying it cost 16 v_mov for
+            // the zeros + 16 per copy -- 80 VALU issues per tile and wave behind an MFMA result, with the matrix pipe idle
             f32x16 z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            z = mfma32(__builtin_bit_cast(bf16x8, fu), ones, z);
+            bf16x8 one_frag = ones;
 #pragma unroll
-            for (int i = 0; i < MI; ++i) acc[i][j] = z;
+            for (int i = 0; i < MI; ++i) {
+                asm volatile("" : "+v"(one_frag));      // opaque: MI separate MFMAs, not one result copied MI times
+                acc[i][j] = mfma32(__builtin_bit_cast(bf16x8, fu), one_frag, z);
+            }
         }
     };
 
@@ -337,57 +342,71 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
             for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(f.a[pl][i]));
         }
     };
-    auto mfma_set = [&](auto set_tag, bool cols_valid) {
-        constexpr int S = decltype(set_tag)::value;
+    // the MFMAs of row block I of one half-step (rows of the MFMA = W rows = output columns, columns = token rows)
+    auto mfma_block = [&](auto set_tag, auto i_tag) {
+        constexpr int S = decltype(set_tag)::value, I = decltype(i_tag)::value;
         const Half& f = hs[S];
-        if (!cols_valid || ((DBG || ALN_ABL) && (dbg & 8))) return;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {      // rows of the MFMA = W rows (output columns), columns = token rows
-            if (PL == 2) {
-                acc[i][0] = mfma32(f.w[PL - 1], f.a[0][i], acc[i][0]);
-                acc[i][0] = mfma32(f.w[0], f.a[PL - 1][i], acc[i][0]);
-            }
-            acc[i][0] = mfma32(f.w[0], f.a[0][i], acc[i][0]);
+        if ((DBG || ALN_ABL) && (dbg & 8)) return;
+        if (PL == 2) {
+            acc[I][0] = mfma32(f.w[PL - 1], f.a[0][I], acc[I][0]);
+            acc[I][0] = mfma32(f.w[0], f.a[PL - 1][I], acc[I][0]);
         }
+        acc[I][0] = mfma32(f.w[0], f.a[0][I], acc[I][0]);
     };
     // one half-step: MFMAs of half (kt, kk) from set U % 3 while the reads of the half two half-steps later go to set (U+2) % 3.
     // `tail` = the last two half-steps of a panel issue no reads (the next panel's fill does, from the new image).
-    auto half_step = [&](auto u_tag, int bn, int kt, int kk, bool cols_valid, bool tail) {
+    // Everything that is not an MFMA is placed BETWEEN the MFMAs of the half-step (pinned by scheduling barriers).  A wave issues
+    // in order, at most one instruction every four cycles, and its next MFMA waits for the pipe: with the half-step laid out as
+    // [reads, wait, MFMA x MI, bookkeeping + LDS-DMA issue] the ~30 non-MFMA instructions ran only after the wave's last MFMA had
+    // issued, the partner wave of the SIMD was in the same place of the same code, and the matrix pipe idled ~90 of every ~350
+    // cycles (ablation: MFMAs + loop skeleton 74 us against 53 us of pure pipe time).  Between two MFMAs of one wave the pipe
+    // is busy with the partner's MFMA for 32 cycles = 8 issue slots, which is where these instructions now go.
+    // VALID = false: a wave whose 32 columns lie past N in the last tile keeps the stream, the reads and the waits, without MFMAs.
+    auto half_step = [&](auto valid_tag, auto u_tag, int bn, int kt, int kk, bool tail) {
         constexpr int U = decltype(u_tag)::value;
+        constexpr bool VALID = decltype(valid_tag)::value;
         using Cur = std::integral_constant<int, U % 3>;
         using Nxt = std::integral_constant<int, (U + 2) % 3>;
-        if (!tail) {
-            issue_reads(Nxt{}, kt + 1 == NK ? 0 : kt + 1, kk, cs_slot + 1 == RING ? 0 : cs_slot + 1);
-            await_set(Cur{}, std::integral_constant<int, 2 * RD>{});
-        } else {
-            await_set(Cur{}, std::integral_constant<int, 0>{});
+        // sets U and U+1 are outstanding: U has arrived once at most the RD reads of U+1 are left
+        if (!tail) await_set(Cur{}, std::integral_constant<int, RD>{});
+        else await_set(Cur{}, std::integral_constant<int, 0>{});
+        if (VALID) mfma_block(Cur{}, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (!tail) issue_reads(Nxt{}, kt + 1 == NK ? 0 : kt + 1, kk, cs_slot + 1 == RING ? 0 : cs_slot + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (VALID && MI > 1) mfma_block(Cur{}, std::integral_constant<int, 1 % MI>{});
+        __builtin_amdgcn_sched_barrier(0);
+        bool refill = false;
+        if (kk == 1 && !(dbg & 2)) {
+            // this stage's fragments are all in registers (set U was its second half): refill its slot with stage step + RING;
+            // the private slot needs no barrier
+            refill = is_step < total_steps;
+            if (refill) issue_next();
         }
-        mfma_set(Cur{}, cols_valid);
+        __builtin_amdgcn_sched_barrier(0);
+        if (VALID && MI > 2) mfma_block(Cur{}, std::integral_constant<int, 2 % MI>{});
+        if (VALID && MI > 3) mfma_block(Cur{}, std::integral_constant<int, 3 % MI>{});
+        static_assert(MI <= 4, "extend the MFMA list");
+        __builtin_amdgcn_sched_barrier(0);
         if (kk == 1) {
-            // this stage's fragments are all in registers: refill its slot with stage step + RING, then make sure stage step + 2
-            // has landed (its first half is read at the next half-step); the private slot needs no barrier
-            if (!(dbg & 2)) {
-                const bool refill = is_step < total_steps;
-                if (refill) issue_next();
-                wait_next_stage(refill);
-            } else {
-                ++is_step;
-            }
+            // make sure stage step + 2 has landed (its first half is read at the next half-step)
+            if (!(dbg & 2)) wait_next_stage(refill);
+            else ++is_step;
             asm volatile("" ::: "memory");
             cs_slot = cs_slot + 1 == RING ? 0 : cs_slot + 1;
         }
     };
     // three k-steps = six half-steps = two turns of the register sets; j-th group of a tile
-    auto kgroup = [&](int bn, int j, bool cols_valid) {
+    auto kgroup = [&](auto valid_tag, int bn, int j) {
         const int kt0 = 3 * j;
         const bool last_group = bn + 1 == nbn && j + 1 == NK / 3;     // of the panel
-        half_step(std::integral_constant<int, 0>{}, bn, kt0, 0, cols_valid, false);
+        half_step(valid_tag, std::integral_constant<int, 0>{}, bn, kt0, 0, false);
         if (j == 0) {                       // bias of the NEXT tile (wraps to the first tile of the next panel)
             const int bn_next = bn + 1 < nbn ? bn + 1 : 0;
             load_bias(bn_next, bias_nxt);
         }
-        half_step(std::integral_constant<int, 1>{}, bn, kt0, 1, cols_valid, false);
-        half_step(std::integral_constant<int, 2>{}, bn, kt0 + 1, 0, cols_valid, false);
+        half_step(valid_tag, std::integral_constant<int, 1>{}, bn, kt0, 1, false);
+        half_step(valid_tag, std::integral_constant<int, 2>{}, bn, kt0 + 1, 0, false);
         // deferred epilogue of the previous tile: block j between the halves of the group's middle k-step
         if (DEFER && have_prev) {
             if (j == 0) drain_block(std::integral_constant<int, 0>{});
@@ -395,9 +414,9 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
             if (NBLK > 2 && j == 2) drain_block(std::integral_constant<int, 2 % NBLK>{});
             if (NBLK > 3 && j == 3) drain_block(std::integral_constant<int, 3 % NBLK>{});
         }
-        half_step(std::integral_constant<int, 3>{}, bn, kt0 + 1, 1, cols_valid, false);
-        half_step(std::integral_constant<int, 4>{}, bn, kt0 + 2, 0, cols_valid, last_group);
-        half_step(std::integral_constant<int, 5>{}, bn, kt0 + 2, 1, cols_valid, last_group);
+        half_step(valid_tag, std::integral_constant<int, 3>{}, bn, kt0 + 1, 1, false);
+        half_step(valid_tag, std::integral_constant<int, 4>{}, bn, kt0 + 2, 0, last_group);
+        half_step(valid_tag, std::integral_constant<int, 5>{}, bn, kt0 + 2, 1, last_group);
     };
     load_bias(0, bias_cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // once: the first tile's bias and the ring's first RING stages
@@ -481,8 +500,13 @@ __global__ __launch_bounds__(C::THREADS, (C::NWAVES + 3) / 4) void gemm_ln_kerne
         for (int bn = 0; bn < nbn; ++bn) {
             const bool cols_valid = bn + 1 < nbn || wave_cols_valid_last;      // wave-uniform
             init_acc(bias_cur);
+            if (cols_valid) {
 #pragma unroll 1
-            for (int j = 0; j < NK / 3; ++j) kgroup(bn, j, cols_valid);
+                for (int j = 0; j < NK / 3; ++j) kgroup(std::true_type{}, bn, j);
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < NK / 3; ++j) kgroup(std::false_type{}, bn, j);
+            }
             // ---- the tile is complete: hand it to the deferred epilogue
 #pragma unroll
             for (int i = 0; i < MI; ++i) accp[i][0] = acc[i][0];
