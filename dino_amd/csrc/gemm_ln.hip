@@ -28,7 +28,7 @@
 //   * LDS-DMA completion needs one constant counted wait per k-step (see wait_next_stage): gfx9 retires loads, stores and
 //     LDS-DMA through one in-order vmcnt, and RING-1 younger stages are always behind the awaited one.
 // Training forwards get the normalised planes (a_out) and the fc1 pre-activation (aux_out) as by-products.
-#include "common.h"
+#include "gemm_ln_common.h"
 #include "kernels.h"
 
 namespace dseg {
@@ -58,21 +58,6 @@ struct Cfg {
 using Cfg384x1 = Cfg<384, 1, 4, 8, 4>;    // bf16:   128 x 256 tile, 8 waves of 128 x 32, private 4 x 2 KiB W rings
 using Cfg384x2 = Cfg<384, 2, 2, 4, 4>;    // bf16x3:  64 x 128 tile, 4 waves of  64 x 32, private 4 x 4 KiB W rings (hi+lo)
 
-__device__ __forceinline__ int off64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
-    return v + __builtin_bit_cast(float, moved);
-}
-// sum over the 16 lanes of a DPP row, result in all 16
-__device__ __forceinline__ float row16_sum(float v) {
-    v = dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);      // row_half_mirror: the other quad of each 8
-    v = dpp_add<0x140>(v);      // row_mirror: the other 8
-    return v;
-}
 }  // namespace aln
 
 // ------------------------------------------------------------------------------------------------
@@ -98,14 +83,17 @@ __global__ __launch_bounds__(256) void pack_slabs_kernel(const float* __restrict
     }
 }
 
-int gemm_ln_tile_cols(int planes) { return planes == 1 ? aln::Cfg384x1::BN : aln::Cfg384x2::BN; }
+// planes == 1 runs the 12-wave kernel of gemm_ln12.hip, which has its own packed layout
+int gemm_ln_tile_cols(int planes) { return planes == 1 ? LN12_BN : aln::Cfg384x2::BN; }
 
 long gemm_ln_slab_elems(int N, int K, int planes) {
+    if (planes == 1) return gemm_ln12_slab_elems(N, K);
     const int bn = gemm_ln_tile_cols(planes);
     return (long)((N + bn - 1) / bn) * bn * K * planes;
 }
 
 int launch_pack_slabs(const float* src, int N, int K, int planes, bf16_t* dst, hipStream_t s) {
+    if (planes == 1) return launch_pack_slabs12(src, N, K, dst, s);
     const long total = gemm_ln_slab_elems(N, K, planes);
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
@@ -568,10 +556,7 @@ int launch_gemm_ln(const LnGemmParams& p0, int K, int planes, hipStream_t s) {
         dinoseg_set_error("gemm_ln: unsupported shape K=%d N=%d planes=%d epi=%d ldx=%d", K, p.N, planes, p.epi, p.ldx);
         return -1;
     }
-    if (planes == 1) {
-        if (p.epi == EPI_QKV) return launch_ln_cfg<EPI_QKV, aln::Cfg384x1>(p, s);
-        return launch_ln_cfg<EPI_GELU, aln::Cfg384x1>(p, s);
-    }
+    if (planes == 1) return launch_gemm_ln12(p, s);
     if (p.epi == EPI_QKV) return launch_ln_cfg<EPI_QKV, aln::Cfg384x2>(p, s);
     return launch_ln_cfg<EPI_GELU, aln::Cfg384x2>(p, s);
 }

@@ -98,7 +98,7 @@ def bench_gemm_planes2():
 def bench_lngemm():
     """LN + GEMM as two launches (layernorm_kernel + gemm_big) against the fused A-stationary kernel (gemm_ln.hip), interleaved."""
     lib = capi.lib()
-    B, ntok, D, H = 32, 3601, 384, 6
+    B, ntok, D, H = int(os.environ.get("LNGEMM_B", "32")), 3601, 384, 6
     M, npad = B * ntok, (ntok + 63) // 64 * 64
     X = torch.randn((M, D), device="cuda") * 1.5 + 0.2
     gam, bet = torch.rand(D, device="cuda") + 0.5, torch.randn(D, device="cuda") * 0.1
