@@ -198,6 +198,10 @@ def main():
                     help="BASELINE.json configs: headline = [1] ViT-S/8 @480 batch 32 bf16 (default); parity = the same in bf16x3; "
                          "960 = [2] @960 batch 8; vitb = [4] ViT-B/8 @480 batch 16/GPU; finetune = [3] 3-block step, batch 8/GPU")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 sub-record of the headline line")
+    ap.add_argument("--no-two-stream", action="store_true", help="skip the two-stream sub-record")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2: time the batch as two half-batches on two streams (library option 'streams'); the roofline leg is "
+                         "then measured on overlapping launches")
     a = ap.parse_args()
     if a.config == "parity":
         a.precision = "bf16x3"
@@ -244,6 +248,8 @@ def main():
     # synthetic frames, already r x r (resize = identity), resident in HBM before the timed region
     frames = torch.from_numpy(synthetic_frames(a.batch, a.res, seed=1000 + rank)).to(dev)
     torch.cuda.synchronize()
+
+    capi.check(capi.lib().dinoseg_set_option(b"streams", a.streams))
 
     def step():
         return model.forward_frames(frames, want_logp=True)
@@ -352,12 +358,45 @@ def main():
             torch.cuda.synchronize()
             pel = time.perf_counter() - t1
             pfps = a.batch * psteps / pel
+            pfps2 = None
+            if a.streams == 1 and a.batch >= 16 and not a.no_two_stream:
+                capi.check(capi.lib().dinoseg_set_option(b"streams", 2))
+                for _ in range(2):
+                    pm.forward_frames(frames, want_logp=True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(psteps):
+                    pm.forward_frames(frames, want_logp=True)
+                torch.cuda.synchronize()
+                pfps2 = a.batch * psteps / (time.perf_counter() - t1)
+                capi.check(capi.lib().dinoseg_set_option(b"streams", 1))
             out["parity_mode"] = {"precision": "bf16x3 (bf16 hi+lo operand planes, 3 MFMAs per product, fp32 accumulate)",
                                   "value": round(pfps, 2), "unit": "frames/s (this rank)", "steps": psteps,
                                   "ms_per_step": round(pel / psteps * 1e3, 4),
                                   "mfma_issue_frac": round(3 * pfps * fl["total"] / 1e12 / peak, 4),
+                                  "two_stream_value": None if pfps2 is None else round(pfps2, 2),
                                   "parity": golden_check(pm, a.arch, a.blocks, a.res)}
             del pm
+        if a.streams == 1 and a.batch >= 16 and not a.no_two_stream:
+            # the same batch as two half-batches on two HIP streams (library option "streams" = 2): kernels of different layers
+            # overlap.  Not the headline: with two kernels sharing the chip a per-launch duration is no longer the kernel's own,
+            # and the roofline object above is defined on exclusive launches.
+            capi.check(capi.lib().dinoseg_set_option(b"streams", 2))
+            for _ in range(3):
+                lp2, am2 = step()
+            torch.cuda.synchronize()
+            tsteps = max(3, a.steps // 2)
+            t2 = time.perf_counter()
+            for _ in range(tsteps):
+                lp2, am2 = step()
+            torch.cuda.synchronize()
+            tel = time.perf_counter() - t2
+            capi.check(capi.lib().dinoseg_set_option(b"streams", 1))
+            out["two_stream"] = {"value": round(a.batch * tsteps / tel, 2), "unit": "frames/s (this rank)", "steps": tsteps,
+                                 "ms_per_step": round(tel / tsteps * 1e3, 4),
+                                 "outputs_identical_to_one_stream": bool(torch.equal(lp2, logp) and torch.equal(am2, amax)),
+                                 "how": "dinoseg_set_option('streams', 2): halves of the batch on the caller's stream and on an "
+                                        "internal stream, forked / joined by events; same kernels, same per-frame arithmetic"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, a.res)
         print(json.dumps(out), flush=True)

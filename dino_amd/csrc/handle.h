@@ -49,6 +49,12 @@ struct dinoseg_handle {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     int ws_B = -1, ws_r = -1;
+    // second half-batch of a split forward (option "streams" = 2): its own workspace, an internal stream, fork / join events
+    char* ws2 = nullptr;
+    size_t ws2_bytes = 0;
+    int ws2_B = -1, ws2_r = -1;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
     // fine-tune step state (train_api.hip)
     std::map<std::string, float*> grads;   // bound gradient buffers (absent / null = frozen tensor)

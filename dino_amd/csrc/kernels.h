@@ -73,6 +73,8 @@ struct Options {
     int gemm_big = 1;        // use gemm_big.hip where it applies
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
     int attn_dbg = 0;        // same for AttnParams::dbg
+    int streams = 1;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
+    int split_min = 16;
     int attn_variant = 3;    // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
                              // tile work; bit 2 (bf16 mode): the software-pipelined kernel (attention_pipe.hip)
 };

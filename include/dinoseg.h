@@ -169,8 +169,14 @@ enum { DINOSEG_PROF_PATCH = 0, DINOSEG_PROF_LN = 1, DINOSEG_PROF_QKV = 2, DINOSE
 int dinoseg_profile(dinoseg_handle* h, int32_t level);
 int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
 
-/* Process-wide tuning knobs (A/B testing of kernel variants).  Keys: "gemm_big" (1 = use the 256x384
- * persistent GEMM where it applies [default], 0 = always the 128x128 kernel). */
+/* Process-wide switches.  Keys:
+ *   "streams"    1 [default] / 2: dinoseg_forward runs a batch of >= "split_min" (default 16) frames as two half-batches, the
+ *                first on the caller's stream, the second on an internal stream forked from / joined to it by events (the
+ *                call stays stream-ordered and capturable; outputs identical; +5 % frames/s at B = 32 on MI355X);
+ *   "gemm_big"   1 [default] = the persistent 256x384 (bf16) / 128x384 (bf16x3) GEMM where it applies, 0 = always the 128x128
+ *                kernel, 2 = wherever its shape rules allow;
+ *   "gemm_ln"    1 [default] = qkv / fc1 through the LayerNorm-fused kernels where measured faster, 0 never, 2 wherever supported;
+ *   "attn_variant", "gemm_dbg", "attn_dbg": kernel A/B and timing-ablation switches (tools/bench_ops.py). */
 int dinoseg_set_option(const char* key, int32_t value);
 
 /* Bytes of library-owned device memory a (B, r) forward needs (activations + packed weights). */

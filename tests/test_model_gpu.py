@@ -357,3 +357,29 @@ def test_g4_960_batch8_frames_are_independent(cuda, precision, tol, flip_frac):
             assert float((top2[:, 0] - top2[:, 1]).max()) <= 2 * tol
     lp2, am2 = m.forward_frames(frames)                     # same launch shapes: bit-identical
     assert torch.equal(lp2, lp) and torch.equal(am2, am)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("B", [16, 17])
+def test_two_stream_split_equals_one_stream(cuda, precision, B):
+    """Option 'streams' = 2 (api.hip: dinoseg_forward): a batch of >= 16 frames runs as two half-batches on two streams.  Frames are
+    independent (pl_torch_modules.py:253), the kernels and the per-row arithmetic are the same: identical outputs, also for an odd
+    batch, also when the call is repeated (workspaces / events reused) and when other work is queued on the caller's stream."""
+    import dino_amd
+    m, _, _ = build(2, precision)
+    m.set_resolution(112)
+    frames = torch.from_numpy(synthetic_frames(B, 112, seed=77)).cuda()
+    lp1, am1 = m.forward_frames(frames)
+    lp1, am1 = lp1.clone(), am1.clone()
+    small1 = m.forward_frames(frames[:3])[0].clone()
+    dino_amd.set_option("streams", 2)
+    try:
+        noise = torch.randn(2048, 2048, device="cuda")
+        for _ in range(3):
+            noise = noise @ noise * 1e-3                       # the fork must wait for what is already queued, the join for both halves
+            lp2, am2 = m.forward_frames(frames)
+            assert torch.equal(lp2, lp1) and torch.equal(am2, am1)
+        small, _ = m.forward_frames(frames[:3])                # below split_min: the ordinary path
+        assert torch.equal(small, small1)
+    finally:
+        dino_amd.set_option("streams", 1)

@@ -8,21 +8,24 @@ cfg = ViTConfig(n_blocks=12); sd = procedural_state_dict(cfg)
 def mk():
     m = DINOSeg(head="mlp", n_blocks=12, precision="bf16", arch=cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); return m.to("cuda:0")
-m0, m1, m2 = mk(), mk(), mk()
+NS = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+m0 = mk()
+ms = [mk() for _ in range(NS)]
 fr = torch.from_numpy(synthetic_frames(32, 480, seed=1)).cuda()
 def single():
     return m0.forward_frames(fr)
-s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-def dual(nsplit=2):
+ss = [torch.cuda.Stream() for _ in range(NS)]
+per = 32 // NS
+def dual():
     cur = torch.cuda.current_stream()
     outs = []
-    for i, (m, s) in enumerate(((m1, s1), (m2, s2))):
+    for i, (m, s) in enumerate(zip(ms, ss)):
         s.wait_stream(cur)
         with torch.cuda.stream(s):
-            outs.append(m.forward_frames(fr[i * 16:(i + 1) * 16]))
-    cur.wait_stream(s1); cur.wait_stream(s2)
+            outs.append(m.forward_frames(fr[i * per:(i + 1) * per]))
+    for s in ss: cur.wait_stream(s)
     return outs
-for fn, name in ((single, "single B=32"), (dual, "2 streams x B=16"), (single, "single B=32"), (dual, "2 streams x B=16")):
+for fn, name in ((single, "single B=32"), (dual, f"{NS} streams x B={per}"), (single, "single B=32"), (dual, f"{NS} streams x B={per}")):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): fn()
