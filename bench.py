@@ -293,7 +293,8 @@ def main():
     peak = MFMA_PEAK_TFLOPS[a.precision]
     att_ms, att_n = prof["attention"]
     att_avg_ms = att_ms / max(att_n, 1)
-    att_flops = fl["attention"] * a.batch                      # algorithmic FLOPs of one attention launch
+    split = a.streams == 2 and a.batch >= 16                   # then every layer is two launches of half the batch each
+    att_flops = fl["attention"] * a.batch / (2 if split else 1)    # algorithmic FLOPs of one attention launch (mean of the halves)
     achieved = att_flops / (att_avg_ms * 1e-3) / 1e12 if att_n else None
 
     traffic = None
@@ -305,7 +306,7 @@ def main():
         tj = json.load(open(tpath))
         if (tj.get("batch"), tj.get("resolution"), tj.get("precision")) == (a.batch, a.res, a.precision) \
                 and a.arch == "vit_small":
-            traffic = tj["hbm_bytes_per_launch"]
+            traffic = None if split else tj["hbm_bytes_per_launch"]
             clock = tj.get("clock_ghz_under_load")
 
     if rank == 0:
@@ -335,7 +336,8 @@ def main():
                          "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/attention_traffic.json)",
                          "algorithmic_bytes_per_launch": 4 * a.batch * cfg.num_heads * ((a.res // 8) ** 2 + 1) * 64 * 2
-                         * (2 if a.precision == "bf16x3" else 1),
+                         * (2 if a.precision == "bf16x3" else 1) // (2 if split else 1),
+                         "overlapped_launches": split,      # --streams 2: durations include time shared with the other stream's kernels
                          "launches_timed": att_n, "avg_launch_ms": round(att_avg_ms, 4),
                          "gflop_per_launch": round(att_flops / 1e9, 1)},
         }

@@ -9,6 +9,7 @@ def mk():
     m = DINOSeg(head="mlp", n_blocks=12, precision="bf16", arch=cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); return m.to("cuda:0")
 NS = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+DELAY = int(sys.argv[2]) if len(sys.argv) > 2 else 0       # GPU cycles the second stream spins before its half (phase offset)
 m0 = mk()
 ms = [mk() for _ in range(NS)]
 fr = torch.from_numpy(synthetic_frames(32, 480, seed=1)).cuda()
@@ -22,6 +23,8 @@ def dual():
     for i, (m, s) in enumerate(zip(ms, ss)):
         s.wait_stream(cur)
         with torch.cuda.stream(s):
+            if i > 0 and DELAY:
+                torch.cuda._sleep(DELAY * i)
             outs.append(m.forward_frames(fr[i * per:(i + 1) * per]))
     for s in ss: cur.wait_stream(s)
     return outs
