@@ -84,6 +84,16 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_tn_kernel(TnP
         return attn::tr_frag(a0, a1);
     };
 
+    // optional bias gradient (Linear.bias.grad = column sums of dY): the workgroups of the first k-tile multiply their dY
+    // fragments with a ones fragment as well -- one extra MFMA per 16 batch rows and wave (wave (wr, wc) sums n-block wc of its
+    // 64 rows) instead of a separate pass over dY (transpose_planes_kernel read all of dY for these sums: 37 us per layer)
+    const bool do_sum = p.colsum != nullptr && tk == 0;       // workgroup-uniform
+    f32x16 bsum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bsum[r] = 0.f;
+    const uint4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+
     stage(0, c_begin);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -130,11 +140,22 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_tn_kernel(TnP
                     }
                     acc[i][j] = mfma32(a[0][i], b[0][j], acc[i][j]);
                 }
+            if (do_sum) {
+                if (PLANES == 2) bsum = mfma32(wc ? a[PLANES - 1][1] : a[PLANES - 1][0], ones, bsum);
+                bsum = mfma32(wc ? a[0][1] : a[0][0], ones, bsum);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
+    if (do_sum && lr == 0) {        // every column of bsum holds the same sums: column 0 adds them
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gn = n0 + wr * 64 + wc * 32 + acc_row(r, lh);
+            if (gn < p.N && bsum[r] != 0.f) atomicAdd(p.colsum + gn, bsum[r]);
+        }
+    }
     // ---- partial tile: accumulators through LDS C[128][128] fp32, then 16-byte row segments ----
     float* C = reinterpret_cast<float*>(smem);
 #pragma unroll

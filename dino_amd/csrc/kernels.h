@@ -142,14 +142,17 @@ int launch_transpose_planes(const float* src_f32, const bf16_t* src_pl, long src
 // labels != null: F.nll_loss (mean over rows whose label is not -100) + d logits; labels == null: d logits from the caller's dlogp
 int launch_nll_loss_grad(const float* logp, const int64_t* labels, const float* dlogp, int M, int C, float* acc, int* flags,
                          float* loss, bf16_t* dz, long dz_plane, int ldz, hipStream_t s);
+// dxp / colsum (optional): the final dx rows as bf16 planes [planes][M][D] and their column sums (train.hip)
 int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int M, int D, float* dx,
-                         int accumulate, float* dgamma, float* dbeta, int drop_cls, int ntok, hipStream_t s);
+                         int accumulate, float* dgamma, float* dbeta, int drop_cls, int ntok, hipStream_t s,
+                         bf16_t* dxp = nullptr, long dxp_plane = 0, int planes = 1, float* colsum = nullptr);
 // Weight gradient on row-major operands (gemm_tn.hip): part[slice][n][k] = sum over the slice's batch rows of Y[m][n] X[m][k]
 struct TnParams {
     const bf16_t* Y; long y_plane; int ldy;     // dY planes [planes][M][ldy], columns n < N (N % 128 == 0 not required: rows guarded)
     const bf16_t* X; long x_plane; int ldx;     // layer input planes [planes][M][ldx], columns k < Kc (Kc % 128 == 0)
     int M, N, Kc, planes;
     float* part; int ld_part; long split_stride; int ksplit;
+    float* colsum;                              // optional [N]: += column sums of dY over the M rows (the layer's bias gradient)
 };
 int launch_gemm_tn(const TnParams& p, hipStream_t s);
 int launch_splitk_reduce(const float* part, int ks, long stride, int rows, int ld_part, float* out, int ldo, int cols, hipStream_t s);

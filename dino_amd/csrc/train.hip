@@ -167,23 +167,38 @@ int launch_nll_loss_grad(const float* logp, const int64_t* labels, const float* 
 // LayerNorm backward (native_layer_norm_backward).  One wavefront per row; x is the saved LN input.
 //   g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dgamma += dy * xhat;  dbeta += dy
 // dx is added to (accumulate = 1) or written to (0) the residual-stream gradient.  drop_cls: dy has no CLS rows.
+// By-products for the layer the gradient flows into next (fc2 / attn.proj of the backward walk): the final dx rows as bf16
+// hi[/lo] planes dxp[planes][M][D] -- the operand of its two gradient GEMMs -- and their column sums colsum[D] += sum_m dx[m]
+// (its bias gradient).  A separate pack + column-sum pass over dx cost 37 us per layer (transpose_planes_kernel).
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, float eps, int M,
                                                             float* __restrict__ dx, int accumulate,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int drop_cls, int ntok) {
+                                                            int drop_cls, int ntok, bf16_t* __restrict__ dxp, long dxp_plane,
+                                                            int planes, float* __restrict__ colsum) {
     constexpr int D = 128 * NV;
-    __shared__ float red[2][4][D];
+    __shared__ float red[3][4][D];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wid = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
-    f32x2 g[NV], dg[NV], db[NV];
+    f32x2 g[NV], dg[NV], db[NV], dn[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         g[i] = *reinterpret_cast<const f32x2*>(gamma + i * 128 + lane * 2);
         dg[i] = f32x2{0.f, 0.f};
         db[i] = f32x2{0.f, 0.f};
+        dn[i] = f32x2{0.f, 0.f};
     }
+    auto emit = [&](int m, int i, f32x2 r) {      // by-products of one finished pair of dx columns
+        dn[i] += r;
+        if (dxp) {
+            uint32_t hi, lo;
+            split_bf16x2(r[0], r[1], hi, lo);
+            bf16_t* o = dxp + (long)m * D + i * 128 + lane * 2;
+            *reinterpret_cast<uint32_t*>(o) = hi;
+            if (planes == 2) *reinterpret_cast<uint32_t*>(o + dxp_plane) = lo;
+        }
+    };
     for (int m = wid; m < M; m += nw) {
         long drow = m;
         bool has_dy = true;
@@ -194,9 +209,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
         float* dxr = dx + (long)m * D;
         if (!has_dy) {
-            if (!accumulate) {
 #pragma unroll
-                for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x2*>(dxr + i * 128 + lane * 2) = f32x2{0.f, 0.f};
+            for (int i = 0; i < NV; ++i) {
+                f32x2* dst = reinterpret_cast<f32x2*>(dxr + i * 128 + lane * 2);
+                const f32x2 r = accumulate ? *dst : f32x2{0.f, 0.f};
+                if (!accumulate) *dst = r;
+                if (dxp || colsum) emit(m, i, r);
             }
             continue;
         }
@@ -244,6 +262,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             f32x2* dst = reinterpret_cast<f32x2*>(dxr + i * 128 + lane * 2);
             if (accumulate) r += *dst;
             *dst = r;
+            if (dxp || colsum) emit(m, i, r);
         }
     }
     // block-level reduction of the parameter gradients, then one atomic per column per block
@@ -253,6 +272,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         red[0][wv][i * 128 + lane * 2 + 1] = dg[i][1];
         red[1][wv][i * 128 + lane * 2] = db[i][0];
         red[1][wv][i * 128 + lane * 2 + 1] = db[i][1];
+        red[2][wv][i * 128 + lane * 2] = dn[i][0];
+        red[2][wv][i * 128 + lane * 2 + 1] = dn[i][1];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
@@ -260,11 +281,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
         if (dgamma) atomicAdd(dgamma + c, a);
         if (dbeta) atomicAdd(dbeta + c, b);
+        if (colsum) {
+            const float n = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
+            if (n != 0.f) atomicAdd(colsum + c, n);
+        }
     }
 }
 
 int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int M, int D, float* dx,
-                         int accumulate, float* dgamma, float* dbeta, int drop_cls, int ntok, hipStream_t s) {
+                         int accumulate, float* dgamma, float* dbeta, int drop_cls, int ntok, hipStream_t s, bf16_t* dxp,
+                         long dxp_plane, int planes, float* colsum) {
     if (D % 128 != 0 || D > 1024) {
         dinoseg_set_error("layernorm_bwd: D=%d must be a multiple of 128 and <= 1024", D);
         return -1;
@@ -274,7 +300,7 @@ int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, fl
 #define DSEG_LNB(NV)                                                                                                  \
     case NV:                                                                                                          \
         hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(grid), dim3(256), 0, s, dy, x, gamma, eps, M, dx, accumulate, \
-                           dgamma, dbeta, drop_cls, ntok);                                                            \
+                           dgamma, dbeta, drop_cls, ntok, dxp, dxp_plane, planes, colsum);                            \
         break;
     switch (D / 128) { DSEG_LNB(1) DSEG_LNB(2) DSEG_LNB(3) DSEG_LNB(4) DSEG_LNB(5) DSEG_LNB(6) DSEG_LNB(7) DSEG_LNB(8) }
 #undef DSEG_LNB

@@ -522,8 +522,13 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
     };
     auto pad128 = [](int v) { return (v + 127) / 128 * 128; };
     // weight gradient straight from the row-major dY and layer-input planes (gemm_tn.hip): no operand transposes
+    // dbias (optional): the layer's bias gradient = column sums of Y, taken inside the weight-gradient kernel; when that kernel
+    // does not run (frozen weight, narrow layer) a pack pass over Y produces them
     auto wgrad_tn = [&](const bf16_t* Y, long y_plane, int ldy, const bf16_t* X, long x_plane, int ldx, int m_rows, int n_rows,
-                        int k_cols, int planes, float* dW) -> int {
+                        int k_cols, int planes, float* dW, float* dbias = nullptr) -> int {
+        if (dbias && (!dW || k_cols % 128 != 0))
+            DSEG_TRY(launch_transpose_planes(nullptr, Y, y_plane, ldy, m_rows, n_rows, nullptr, 0, pad128(n_rows), L.Mpad, nullptr, 0, 0,
+                                             dbias, planes, 0, 0, s));
         if (!dW) return 0;
         if (k_cols % 128 != 0) {        // narrow layers (embed_dim not a multiple of 128): transposed operands + the NT kernel
             bf16_t* T1f = B16(L.T1);
@@ -543,6 +548,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
         if (ks < 1) ks = 1;
         const int per = (nchunks + ks - 1) / ks, used = (nchunks + per - 1) / per;
         g.part = F32(L.SPLITK); g.ld_part = k_cols; g.split_stride = (long)row_tiles * 128 * k_cols; g.ksplit = ks;
+        g.colsum = dbias;
         DSEG_TRY(launch_gemm_tn(g, s));
         return launch_splitk_reduce(g.part, used, g.split_stride, n_rows, k_cols, dW, k_cols, k_cols, s);
     };
@@ -591,10 +597,13 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
 
     // ---- final norm (CLS rows get no gradient from the head)
     auto gsink = [&](const std::string& name) { float* g = grad(name); return g ? g : sink; };
-    DSEG_TRY(launch_layernorm_bwd(dA, Xfin, W(h, "dino.norm.weight"), c.ln_eps, L.M, D, dX, 0, gsink("dino.norm.weight"),
-                                  gsink("dino.norm.bias"), 1, L.ntok, s));
-
+    // (every LayerNorm backward also leaves its dX rows as bf16 planes dXp and their column sums = the bias gradient of the
+    //  layer the walk reaches next: mlp.fc2 of the last block here)
     bf16_t* dXp = B16(L.dXp);
+    DSEG_TRY(launch_layernorm_bwd(dA, Xfin, W(h, "dino.norm.weight"), c.ln_eps, L.M, D, dX, 0, gsink("dino.norm.weight"),
+                                  gsink("dino.norm.bias"), 1, L.ntok, s, dXp, L.a_plane, P,
+                                  NB > 0 ? grad("dino.blocks." + std::to_string(NB - 1) + ".mlp.fc2.bias") : nullptr));
+
     bf16_t* dCTX = B16(L.dCTX);
     for (int l = NB - 1; l >= 0; --l) {
         const std::string b = "dino.blocks." + std::to_string(l) + ".";
@@ -602,25 +611,18 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
         bf16_t *A1 = B16(L.A1 + o), *Q = B16(L.Q + o), *Kb = B16(L.K + o), *V = B16(L.V + o), *CTX = B16(L.CTX + o);
         bf16_t *A2 = B16(L.A2 + o), *HPRE = B16(L.HPRE + o), *HB = B16(L.HB + o);
         // ---- mlp.fc2 : X_out = X_mid + H W2^T + b
-        // (fp32 dX -> bf16 planes dXp for the two GEMMs + the bias gradient; no transposed copy: the weight gradient reads
-        //  dXp and HB row-major)
-        DSEG_TRY(launch_transpose_planes(dX, nullptr, 0, D, L.M, D, nullptr, 0, pad128(D), L.Mpad, dXp, L.a_plane, D, grad(b + "mlp.fc2.bias"),
-                                         P, 0, 0, s));
+        // (dXp = bf16 planes of dX and the fc2 bias gradient were left by the LayerNorm backward that produced dX; the weight
+        //  gradient reads dXp and HB row-major)
         DSEG_TRY(wgrad_tn(dXp, L.a_plane, D, HB, L.f_plane, F, L.M, D, F, P, grad(b + "mlp.fc2.weight")));
         // dHpre = (dX . W2) * gelu'(Hpre)
         DSEG_TRY(dgrad(dXp, L.a_plane, D, L.M, D, tw.at(b + "mlp.fc2.weight"), F, P, EPI_DGELU, nullptr, G, (long)L.M * F, HPRE, L.f_plane));
         // ---- mlp.fc1 : Hpre = A2 W1^T + b
-        if (grad(b + "mlp.fc1.bias"))
-            DSEG_TRY(launch_transpose_planes(nullptr, G, (long)L.M * F, F, L.M, F, nullptr, 0, pad128(F), L.Mpad, nullptr, 0, 0,
-                                             grad(b + "mlp.fc1.bias"), P, 0, 0, s));
-        DSEG_TRY(wgrad_tn(G, (long)L.M * F, F, A2, L.a_plane, D, L.M, F, D, P, grad(b + "mlp.fc1.weight")));
+        DSEG_TRY(wgrad_tn(G, (long)L.M * F, F, A2, L.a_plane, D, L.M, F, D, P, grad(b + "mlp.fc1.weight"), grad(b + "mlp.fc1.bias")));
         DSEG_TRY(dgrad(G, (long)L.M * F, F, L.M, F, tw.at(b + "mlp.fc1.weight"), D, P, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
         // ---- norm2 (input X_mid); the residual branch keeps dX
         DSEG_TRY(launch_layernorm_bwd(dA, F32(L.Xmid + o), W(h, b + "norm2.weight"), c.ln_eps, L.M, D, dX, 1, gsink(b + "norm2.weight"),
-                                      gsink(b + "norm2.bias"), 0, L.ntok, s));
+                                      gsink(b + "norm2.bias"), 0, L.ntok, s, dXp, L.a_plane, P, grad(b + "attn.proj.bias")));
         // ---- attn.proj : X_mid = X_in + ctx Wp^T + b
-        DSEG_TRY(launch_transpose_planes(dX, nullptr, 0, D, L.M, D, nullptr, 0, pad128(D), L.Mpad, dXp, L.a_plane, D, grad(b + "attn.proj.bias"),
-                                         P, 0, 0, s));
         DSEG_TRY(wgrad_tn(dXp, L.a_plane, D, CTX, L.a_plane, D, L.M, D, D, P, grad(b + "attn.proj.weight")));
         DSEG_TRY(dgrad(dXp, L.a_plane, D, L.M, D, tw.at(b + "attn.proj.weight"), D, P, EPI_BF16, nullptr, dCTX, L.a_plane, nullptr, 0));
         // ---- attention
@@ -634,14 +636,14 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
             DSEG_TRY(launch_attention_bwd(a, s));
         }
         // ---- attn.qkv : qkv = A1 Wqkv^T + b
-        if (grad(b + "attn.qkv.bias"))
-            DSEG_TRY(launch_transpose_planes(nullptr, G, (long)L.M * 3 * D, 3 * D, L.M, 3 * D, nullptr, 0, pad128(3 * D), L.Mpad, nullptr, 0, 0,
-                                             grad(b + "attn.qkv.bias"), P, 0, 0, s));
-        DSEG_TRY(wgrad_tn(G, (long)L.M * 3 * D, 3 * D, A1, L.a_plane, D, L.M, 3 * D, D, P, grad(b + "attn.qkv.weight")));
+        DSEG_TRY(wgrad_tn(G, (long)L.M * 3 * D, 3 * D, A1, L.a_plane, D, L.M, 3 * D, D, P, grad(b + "attn.qkv.weight"),
+                          grad(b + "attn.qkv.bias")));
         DSEG_TRY(dgrad(G, (long)L.M * 3 * D, 3 * D, L.M, 3 * D, tw.at(b + "attn.qkv.weight"), D, P, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
         // ---- norm1 (input X_in)
+        // (by-products for mlp.fc2 of block l-1; the embedding step after block 0 packs dX itself: it drops the CLS rows)
         DSEG_TRY(launch_layernorm_bwd(dA, F32(L.Xin + o), W(h, b + "norm1.weight"), c.ln_eps, L.M, D, dX, 1, gsink(b + "norm1.weight"),
-                                      gsink(b + "norm1.bias"), 0, L.ntok, s));
+                                      gsink(b + "norm1.bias"), 0, L.ntok, s, l > 0 ? dXp : nullptr, L.a_plane, P,
+                                      l > 0 ? grad("dino.blocks." + std::to_string(l - 1) + ".mlp.fc2.bias") : nullptr));
         DSEG_TRY(stage_mark(1 + (NB - 1 - l)));
     }
 
