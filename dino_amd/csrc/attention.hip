@@ -214,7 +214,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
         // move the reference: everything still measured against the old one is rescaled exactly once (S', O, l, negm)
         auto rescale = [&](float mx) {
             const float delta = (t == 0) ? mx : fmaxf(mx, 0.f);
-            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            // (first tile: O and l are still zero -- and 2^-delta overflows for a row whose scores all lie below -128: 0 * inf)
+            const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-delta);
             m_run += delta;
             l_run *= alpha;
 #pragma unroll
@@ -377,6 +378,7 @@ int launch_attention(const AttnParams& p0, hipStream_t s) {
         return -1;
     }
     if (p.dbg != 0 && p.planes == 1) return launch_attn<1, 4, true, 0>(p, s);      // ablation build (tools/bench_ops.py)
+    if (p.planes == 1 && (options().attn_variant & 8)) return launch_attention_z(p, s);      // zero-reference, 4 waves / SIMD
     if (p.planes == 1 && (options().attn_variant & 4)) return launch_attention_pipe(p, s);
     if (p.planes == 1) return launch_attn_planes<1>(p, s);
     if (p.planes == 2) return launch_attn_planes<2>(p, s);

@@ -1,0 +1,306 @@
+// Fused multi-head attention forward, "zero-reference" variant: four waves per SIMD.
+//
+// Same tiling, LDS image, operand orientation and loaders as attention.hip (read its header first); what changes is the softmax
+// bookkeeping, to get from 165 to <= 128 registers per wave -- one more resident workgroup per CU.  Why that matters: a wave
+// issues at most one MFMA per ~64 cycles and spends most of a tile waiting (LDS fragments, the tile barrier, v_exp results);
+// with three waves per SIMD the matrix pipe is busy 53 % and the vector port 60 % -- the kernel is latency-bound, and the one
+// thing that has raised its throughput every time is more resident waves.
+//   * no running reference: probabilities are 2^S against the FIXED reference 0, S = q.k * scale * log2(e).  fp32 (and bf16, same
+//     exponent range) hold 2^S for |S| < 126, i.e. raw logits up to +-87 * 8 / 1.44 -- far outside anything a trained ViT
+//     produces -- so the score accumulators start from the inline constant 0 (no 16-register -m_run operand), there is no
+//     per-tile overflow check, no rescale path in the loop;
+//   * a row whose sum overflowed (inf / NaN) or vanished (every 2^S flushed to 0) is detected ONCE, after the last tile; the
+//     workgroup then recomputes exactly: one pass for the row maxima (scores only), one pass with S - max subtracted on the
+//     VALU (32 extra v_sub per tile, only on this path).  Hit only by adversarial inputs (tests force it);
+//   * the K fragments of a tile are read in two windows of four (16 registers instead of 32).
+// lse = log2(sum) (+ max on the exact path), as before.
+#include <type_traits>
+
+#include "attn_common.h"
+#include "kernels.h"
+
+namespace dseg {
+
+namespace az {
+constexpr int QW = 32, KB = 64, NW = 4, QB = NW * QW;
+constexpr int KV_TILE = attn::KV_TILE_BYTES;
+}  // namespace az
+
+template <int PLANES, int WPS>     // WPS = resident waves per SIMD the register budget is cut for
+__global__ __launch_bounds__(az::NW * 64, WPS) void attn_fwd_z_kernel(AttnParams p) {
+    using namespace az;
+    using attn::sigma23;
+    using attn::tr_frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE_BYTES = PLANES * 2 * KV_TILE;   // per plane: K slab + V slab
+    static_assert(NW * 4096 <= STAGE_BYTES, "the O-store epilogue gives every wave a 4 KiB patch of one ring slot");
+    int* const redo_flag = reinterpret_cast<int*>(smem + 2 * STAGE_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // XCD-aware order: all q-tiles of one (batch, head) run on one XCD back-to-back (K/V stay in that L2).
+    const int nq = (p.ntok + QB - 1) / QB;
+    const int npairs = p.B * p.heads;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = (slot / nq) * 8 + xcd, qt = slot % nq;
+    if (pair >= npairs) return;
+    if (tid == 0) *redo_flag = 0;
+
+    const int ntok = p.ntok, npad = p.npad;
+    const long pair_off = (long)pair * npad * 64;       // Q, K, V are [B*H][npad][64]
+    const bf16_t* Qg = p.q + pair_off;
+    const bf16_t* Kg = p.k + pair_off;
+    const bf16_t* Vg = p.v + pair_off;
+
+    // ---- Q fragments (B operand: k = d, col = query) straight from global into registers ----
+    const int qrow = qt * QB + wave * QW + lr;
+    const int qrow_c = qrow < ntok ? qrow : ntok - 1;
+    bf16x8 qf[PLANES][4];
+#pragma unroll
+    for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[pl][s] = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const uint4*>(Qg + pl * p.qkv_plane + (long)qrow_c * 64 + s * 16 + lh * 8));
+    // the compiler must not carry "Q loads pending" into the tile loop (its vmcnt waits would drain the LDS-DMA prefetch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[pl][s]));
+
+    // K/V tile loader (scalar base + constant lane offset; see attention.hip)
+    constexpr int NPIECE = 16 / NW;
+    uint32_t soff[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int row = ((wave + i * NW) & 7) * 8 + (lane >> 3);
+        soff[i] = (uint32_t)((row * 64 + attn::swz(row, lane & 7) * 8) * 2);
+    }
+    auto stage = [&](int st, int key0) {
+        char* sbase = smem + st * STAGE_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) {
+            const char* kb = reinterpret_cast<const char*>(Kg + pl * p.qkv_plane + (long)key0 * 64);
+            const char* vb = reinterpret_cast<const char*>(Vg + pl * p.qkv_plane + (long)key0 * 64);
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i) {
+                const int piece = wave + i * NW;              // 0..7: K rows, 8..15: V rows
+                // (readfirstlane: all of this is wave-uniform, but the compiler's divergence analysis loses that in the two-plane
+                //  instantiation and would hand the asm vector registers)
+                const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
+                    (uint32_t)(size_t)(__attribute__((address_space(3))) char*)(sbase + pl * 2 * KV_TILE + piece * 1024));
+                const uint64_t src = reinterpret_cast<uint64_t>(piece < 8 ? kb : vb);
+                const uint64_t src_u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)src) |
+                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(src >> 32)) << 32);
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(soff[i]), "s"(src_u), "s"(lds_dst)
+                             : "memory");
+            }
+        }
+    };
+
+    const int ntiles = (ntok + KB - 1) / KB;
+    const bool wave_active = qt * QB + wave * QW < ntok;     // wave-uniform
+    const int krow_perm = sigma23(lr);
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_gl = (lane >> 4) & 1;
+    int ka[4], va[2][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ka[s] = attn::tile_off(krow_perm, s * 2 + lh);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            va[db][h] = KV_TILE + attn::tile_off(lh * 8 + tr_q + 4 * h, db * 4 + tr_gl * 2 + (tr_p >> 1)) + (tr_p & 1) * 8;
+
+    f32x16 o[2];
+    float l_run, m_ref = 0.f;
+
+    // MODE 0: 2^S against the reference 0 (the fast pass).  MODE 1: row maxima only.  MODE 2: 2^(S - m_ref), exact.
+    auto tile = [&](auto mode_tag, int t, auto slot_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr int SLOT = decltype(slot_tag)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();      // everyone's pieces of tile t landed; everyone is done reading slot (t-1)&1
+        if (t + 1 < ntiles) stage(SLOT ^ 1, (t + 1) * KB);
+        if (!wave_active) return;
+        const char* sb = smem + SLOT * STAGE_BYTES;
+
+        // ---- S^T[key][q] = K . Q^T, the K fragments in two windows of four ----
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 kf[PLANES][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                kf[0][s] = lds_frag(sb + ka[s] + kb * 4096);
+                if (PLANES == 2) kf[PLANES - 1][s] = lds_frag(sb + ka[s] + kb * 4096 + 2 * KV_TILE);
+            }
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (PLANES == 2) {
+                    z = mfma32(kf[PLANES - 1][s], qf[0][s], z);
+                    z = mfma32(kf[0][s], qf[PLANES - 1][s], z);
+                }
+                z = mfma32(kf[0][s], qf[0][s], z);
+            }
+            sacc[kb] = z;
+        }
+        // lane (query lr, half lh): sacc[kb][8*s2 + j] is key  t*64 + kb*32 + s2*16 + lh*8 + j
+        if ((t + 1) * KB > ntok) {   // ragged last tile: mask keys >= ntok (wave-uniform branch)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KB + kb * 32 + (r >> 3) * 16 + lh * 8 + (r & 7);
+                    if (key >= ntok) sacc[kb][r] = -INFINITY;
+                }
+        }
+        if (MODE == 1) {
+            float mx = m_ref;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+            m_ref = mx;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            return;
+        }
+        // ---- P = 2^S (in place), this lane's partial row sum ----
+        float ps = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sv = MODE == 2 ? sacc[kb][r] - m_ref : sacc[kb][r];
+                sacc[kb][r] = __builtin_amdgcn_exp2f(sv);
+                ps += sacc[kb][r];
+            }
+        l_run += ps;
+
+        // ---- P fragments (B operand: k = key, col = query): registers 8*s2..8*s2+7 of sacc[kb] ----
+        bf16x8 pf[PLANES][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint4 hi, lo;
+                split_bf16x2(sacc[kb][s2 * 8 + 0], sacc[kb][s2 * 8 + 1], hi.x, lo.x);
+                split_bf16x2(sacc[kb][s2 * 8 + 2], sacc[kb][s2 * 8 + 3], hi.y, lo.y);
+                split_bf16x2(sacc[kb][s2 * 8 + 4], sacc[kb][s2 * 8 + 5], hi.z, lo.z);
+                split_bf16x2(sacc[kb][s2 * 8 + 6], sacc[kb][s2 * 8 + 7], hi.w, lo.w);
+                pf[0][kb * 2 + s2] = __builtin_bit_cast(bf16x8, hi);
+                if (PLANES == 2) pf[PLANES - 1][kb * 2 + s2] = __builtin_bit_cast(bf16x8, lo);
+            }
+
+        // ---- O^T[d][q] += V^T . P^T  (V^T fragments by transposing LDS reads) ----
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off0 = va[db][0] + ks * 2048, off1 = va[db][1] + ks * 2048;
+                const bf16x8 vhi = tr_frag(sb + off0, sb + off1);
+                if (PLANES == 2) {
+                    const bf16x8 vlo = tr_frag(sb + 2 * KV_TILE + off0, sb + 2 * KV_TILE + off1);
+                    o[db] = mfma32(vlo, pf[0][ks], o[db]);
+                    o[db] = mfma32(vhi, pf[PLANES - 1][ks], o[db]);
+                }
+                o[db] = mfma32(vhi, pf[0][ks], o[db]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of tile t are complete
+    };
+    auto pass = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        if (MODE != 1) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+            l_run = 0.f;
+        }
+        stage(0, 0);
+        int t = 0;
+        for (; t + 1 < ntiles; t += 2) {
+            tile(mode_tag, t, std::integral_constant<int, 0>{});
+            tile(mode_tag, t + 1, std::integral_constant<int, 1>{});
+        }
+        if (t < ntiles) tile(mode_tag, t, std::integral_constant<int, 0>{});
+    };
+
+    pass(std::integral_constant<int, 0>{});
+    float l_tot = l_run + __shfl_xor(l_run, 32);
+    {
+        // a sum that is inf / NaN (some 2^S overflowed) or 0 (all of them flushed) cannot be normalised: exact recomputation for
+        // the whole workgroup (the tile loop is workgroup-synchronous)
+        const bool bad = wave_active && qrow < ntok && !(l_tot > 0.f && l_tot < INFINITY);
+        if (__any(bad) && lane == 0) *redo_flag = 1;
+        __syncthreads();                   // also: everyone is done reading the last tile
+        if (__builtin_amdgcn_readfirstlane(*redo_flag) != 0) {             // workgroup-uniform (and uniform for the compiler)
+            m_ref = -INFINITY;
+            pass(std::integral_constant<int, 1>{});
+            m_ref = fmaxf(m_ref, __shfl_xor(m_ref, 32));
+            if (!(m_ref > -INFINITY)) m_ref = 0.f;      // (only for rows that have no key at all: cannot happen, ntok >= 1)
+            __syncthreads();
+            pass(std::integral_constant<int, 2>{});
+            l_tot = l_run + __shfl_xor(l_run, 32);
+        }
+    }
+
+    // ---- normalise and write ctx[b*ntok + q][head*64 + d] (whole-row stores through a wave-private LDS patch) ----
+    const float inv = 1.0f / l_tot;
+    const int b = pair / p.heads, head = pair - b * p.heads;
+    const int dm = p.heads * 64;
+    {
+        char* patch = smem + (ntiles & 1) * STAGE_BYTES + wave * 4096;
+        const int q0 = qt * QB + wave * QW;
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 hi, lo;
+                    split_bf16x2(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv, hi.x, lo.x);
+                    split_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv, hi.y, lo.y);
+                    *reinterpret_cast<uint2*>(patch + lr * 128 + (((db * 4 + g) ^ (lr & 7)) << 4) + lh * 8) = pl == 0 ? hi : lo;
+                }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 8 + (lane >> 3);
+                const uint4 v = *reinterpret_cast<const uint4*>(patch + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                if (q0 + row < ntok)
+                    *reinterpret_cast<uint4*>(p.ctx + pl * p.ctx_plane + ((long)b * ntok + q0 + row) * dm + head * 64 + (lane & 7) * 8) = v;
+            }
+            asm volatile("" ::: "memory");
+        }
+        if (qrow < ntok && p.lse != nullptr && lh == 0) p.lse[(long)pair * ntok + qrow] = m_ref + __builtin_amdgcn_logf(l_tot);
+    }
+}
+
+template <int PLANES, int WPS>
+static int launch_z(const AttnParams& p, hipStream_t s) {
+    using namespace az;
+    const int nq = (p.ntok + QB - 1) / QB;
+    const int npairs = p.B * p.heads;
+    const int grid = ((npairs + 7) / 8) * 8 * nq;
+    const size_t lds = (size_t)2 * PLANES * 2 * KV_TILE + 16;
+    hipLaunchKernelGGL((attn_fwd_z_kernel<PLANES, WPS>), dim3(grid), dim3(NW * 64), lds, s, p);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_attention_z(const AttnParams& p, hipStream_t s) {
+    if (p.planes == 1) return launch_z<1, 4>(p, s);
+    return launch_z<2, 3>(p, s);
+}
+
+}  // namespace dseg

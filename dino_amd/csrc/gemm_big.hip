@@ -401,7 +401,11 @@ static int launch_big_cfg(const GemmParams& p, hipStream_t s) {
 template <int EPI>
 static int launch_big_one(const GemmParams& p, hipStream_t s) {
     if (p.planes == 2) return launch_big_cfg<EPI, big::Cfg128x384x2>(p, s);
+#ifdef BIG_12WAVES      // experiment: three waves per SIMD, 192 x 384 tile (3 x 4 waves of 64 x 96)
+    return launch_big_cfg<EPI, big::Cfg<3, 4, 2, 3, 3, 1>>(p, s);
+#else
     return launch_big_cfg<EPI, big::Cfg256x384>(p, s);
+#endif
 }
 
 bool gemm_big_supported(const GemmParams& p) {

@@ -75,8 +75,9 @@ struct Options {
     int attn_dbg = 0;        // same for AttnParams::dbg
     int streams = 1;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 16;
-    int attn_variant = 3;    // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
-                             // tile work; bit 2 (bf16 mode): the software-pipelined kernel (attention_pipe.hip)
+    int attn_variant = 11;   // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
+                             // tile work; bit 2 (bf16 mode): the software-pipelined kernel (attention_pipe.hip); bit 3 (bf16 mode):
+                             // the zero-reference kernel, four waves per SIMD (attention_z.hip)
 };
 Options& options();
 
@@ -89,6 +90,7 @@ struct AttnParams {
     int dbg;                           // timing-only ablations: bit0 skip max/exp, bit1 skip steady-state loads, bit2 skip PV
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
+int launch_attention_z(const AttnParams& p, hipStream_t s);    // zero-reference softmax, <= 128 registers: 4 waves per SIMD (attention_z.hip)
 int launch_attention_pipe(const AttnParams& p, hipStream_t s); // bf16 only: software-pipelined across tiles (attention_pipe.hip)
 
 // fp32 [rows, cols] -> bf16 planes [planes][rows_pad][cols_pad], zero padded

@@ -159,7 +159,7 @@ def bench_lngemm():
                 print(f"{name} planes={planes} {nm:8s}: {t * 1e3:7.1f} us  {fl / (t * 1e-3) / 1e12:7.1f} TFLOP/s", flush=True)
 
 
-ATTN_VARIANTS = [int(v) for v in os.environ.get("ATTN_VARIANTS", "3").split(",")]
+ATTN_VARIANTS = [int(v) for v in os.environ.get("ATTN_VARIANTS", "11").split(",")]
 
 
 def bench_attn():

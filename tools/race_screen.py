@@ -102,7 +102,7 @@ for (Bq, ntok, planes) in [(32, 3601, 1), (8, 3601, 2), (3, 197, 1), (1, 65, 2),
             bad += err > tol
 
 import test_ops_gpu as T
-for variant in (3, 7):
+for variant in (3, 7, 11):
   capi.check(lib.dinoseg_set_option(b"attn_variant", variant))
   for (B, H, ntok, planes) in [(32, 6, 3601, 1), (2, 6, 3601, 2), (4, 2, 197, 1), (3, 3, 64, 1), (1, 1, 129, 2), (8, 6, 14401, 1)]:
       npad = (ntok + 63) // 64 * 64
@@ -117,6 +117,6 @@ for variant in (3, 7):
           capi.check(lib.dinoseg_op_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), B * H * npad * 64, ctx.data_ptr(),
                                               B * ntok * H * 64, lse.data_ptr(), B, H, ntok, npad, planes, S()))
       screen(f"attention variant {variant} B={B} H={H} N={ntok} planes={planes}", run, lambda: [ctx, lse])
-capi.check(lib.dinoseg_set_option(b"attn_variant", 3))
+capi.check(lib.dinoseg_set_option(b"attn_variant", 11))
 print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad})")
 sys.exit(1 if bad else 0)
