@@ -79,7 +79,7 @@ __global__ __launch_bounds__(az::NW * 64, WPS) void attn_fwd_z_kernel(AttnParams
         const int row = ((wave + i * NW) & 7) * 8 + (lane >> 3);
         soff[i] = (uint32_t)((row * 64 + attn::swz(row, lane & 7) * 8) * 2);
     }
-    auto stage = [&](int st, int key0) {
+    auto stage = [&](int st, int key0) __attribute__((always_inline)) {
         char* sbase = smem + st * STAGE_BYTES;
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(az::NW * 64, WPS) void attn_fwd_z_kernel(AttnParams
     float l_run, m_ref = 0.f;
 
     // MODE 0: 2^S against the reference 0 (the fast pass).  MODE 1: row maxima only.  MODE 2: 2^(S - m_ref), exact.
-    auto tile = [&](auto mode_tag, int t, auto slot_tag) {
+    auto tile = [&](auto mode_tag, int t, auto slot_tag) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr int SLOT = decltype(slot_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t landed (this wave's pieces)
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(az::NW * 64, WPS) void attn_fwd_z_kernel(AttnParams
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of tile t are complete
     };
-    auto pass = [&](auto mode_tag) {
+    auto pass = [&](auto mode_tag) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
         if (MODE != 1) {
 #pragma unroll
@@ -300,7 +300,7 @@ static int launch_z(const AttnParams& p, hipStream_t s) {
 
 int launch_attention_z(const AttnParams& p, hipStream_t s) {
     if (p.planes == 1) return launch_z<1, 4>(p, s);
-    return launch_z<2, 3>(p, s);
+    return launch_z<2, 3>(p, s);      // hi + lo planes: 168 registers, three waves per SIMD (the reference-based kernel: 213, two)
 }
 
 }  // namespace dseg

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""gpurun_out/ev_r02/ (tools/evidence_r02.sh on the GPU box) -> profiles/r02_bench_lines.jsonl + profiles/r02_<config>_kernel_stats.csv"""
+import csv
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "ev_r02")
+DST = os.path.join(ROOT, "profiles")
+lines = []
+for name in ("headline", "parity", "960", "vitb", "finetune_bf16", "finetune_bf16x3", "L3", "two_stream"):
+    p = os.path.join(SRC, f"bench_{name}.json")
+    if os.path.exists(p):
+        txt = [l for l in open(p).read().strip().splitlines() if l.startswith("{")]
+        if txt:
+            d = json.loads(txt[-1])
+            d["evidence_config"] = name
+            lines.append(json.dumps(d))
+open(os.path.join(DST, "r02_bench_lines.jsonl"), "w").write("\n".join(lines) + "\n")
+for name in ("960", "vitb", "finetune", "parity"):
+    p = os.path.join(SRC, f"trace_{name}", "b_kernel_stats.csv")
+    if not os.path.exists(p):
+        continue
+    rows = list(csv.DictReader(open(p)))
+    keep = [r for r in rows if "dseg::" in r["Name"]] + [r for r in rows if "dseg::" not in r["Name"]][:3]
+    with open(os.path.join(DST, f"r02_{name}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+        for r in keep:
+            w.writerow([r["Name"].replace("void ", "").split("(")[0] if "dseg::" in r["Name"] else r["Name"][:80], r["Calls"],
+                        r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
+print(len(lines), "bench lines")

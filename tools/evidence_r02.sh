@@ -12,12 +12,13 @@ python3 bench.py --config vitb --steps 8 --warmup 2 --no-cpu-baseline --no-parit
 python3 bench.py --config finetune --steps 10 --warmup 3 > $OUT/bench_finetune_bf16.json 2>/dev/null
 python3 bench.py --config finetune --precision bf16x3 --steps 6 --warmup 2 > $OUT/bench_finetune_bf16x3.json 2>/dev/null
 python3 bench.py --blocks 3 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode > $OUT/bench_L3.json 2>/dev/null
+python3 bench.py --streams 2 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode > $OUT/bench_two_stream.json 2>/dev/null
 for f in $OUT/bench_*.json; do echo "== $f"; tail -1 $f | cut -c1-260; done
 export TMPDIR=/tmp
 cd /tmp
 for cfg in "960:--config 960 --steps 3 --warmup 1" "vitb:--config vitb --steps 4 --warmup 1" "finetune:--config finetune --steps 4 --warmup 2" "parity:--config parity --steps 3 --warmup 1"; do
   name=${cfg%%:*}; args=${cfg#*:}
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -o b -- python3 $ROOT/bench.py $args --no-cpu-baseline --no-parity-mode > $OUT/trace_$name.log 2>&1 || tail -3 $OUT/trace_$name.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -o b -- python3 $ROOT/bench.py $args --no-cpu-baseline --no-parity-mode --no-two-stream > $OUT/trace_$name.log 2>&1 || tail -3 $OUT/trace_$name.log
   find $OUT/trace_$name -name "*kernel_trace.csv" -delete
 done
 du -sh $OUT

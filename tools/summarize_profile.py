@@ -69,7 +69,8 @@ def main():
         for line in open(log):
             if line.startswith("{") and '"metric"' in line:
                 bench_line = json.loads(line)
-    att = next((k for k in hbm if "attn_fwd_kernel" in k), None)
+    # the bf16 (one plane) forward attention kernel of the timed loop: attention_z.hip since round 2, attention.hip before
+    att = next((k for k in hbm if "attn_fwd_z_kernel<1" in k), None) or next((k for k in hbm if "attn_fwd_kernel<1" in k), None)
     if att and bench_line:
         cfg = bench_line["config"]
         json.dump({"tag": tag, "kernel": att, "hbm_bytes_per_launch": hbm[att], "batch": cfg["batch_per_gpu"],
@@ -88,7 +89,9 @@ def main():
 
     with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
         f.write(f"# rocprofv3 summary `{tag}`\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 "
-                f"--no-cpu-baseline` (tools/profile_bench.sh), MI355X, one GPU.\n\n")
+                f"--no-cpu-baseline --no-two-stream` (tools/profile_bench.sh), MI355X, one GPU.  (`--no-two-stream`: the two-stream "
+                f"sub-record of the default line launches the same kernels on half batches; it is left out here so that the per-kernel "
+                f"averages below are those of the timed loop and of the roofline leg.)\n\n")
         if bench_line:
             f.write("Bench line under the profiler (profiled clocks run ~2-3 % lower than un-profiled):\n\n```\n"
                     + json.dumps(bench_line) + "\n```\n\n")
