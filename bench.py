@@ -225,11 +225,19 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         a.gpus = world
+    # rehearsal of the N > 1 code path on a one-GPU box: DINOSEG_BENCH_REHEARSAL=1 puts every rank on device 0 and uses gloo
+    # (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank over RCCL
+    rehearsal = os.environ.get("DINOSEG_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from dino_amd import capi
     for kv in a.option:
