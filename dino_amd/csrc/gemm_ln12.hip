@@ -365,6 +365,9 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
                 row_off[i] = (uint32_t)gm * (uint32_t)p.ldo;
             }
         }
+#ifdef LN12_SKEW      // experiment: wave group g (= wave / 4, one wave per SIMD each) starts the panel's tiles g * LN12_SKEW * 64 cycles late
+        for (int i = 0; i < wave / 4; ++i) __builtin_amdgcn_s_sleep(LN12_SKEW);
+#endif
         // fill the fragment pipeline: this panel's first two units were waited for already (kernel start / the last half-steps of
         // the previous panel)
         issue_reads(std::integral_constant<int, 0>{}, 0, 0, cs_slot);
