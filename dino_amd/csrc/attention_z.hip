@@ -22,18 +22,22 @@
 namespace dseg {
 
 namespace az {
-constexpr int QW = 32, KB = 64, NW = 4, QB = NW * QW;
+constexpr int QW = 32, KB = 64;
 constexpr int KV_TILE = attn::KV_TILE_BYTES;
 }  // namespace az
 
-template <int PLANES, int WPS>     // WPS = resident waves per SIMD the register budget is cut for
-__global__ __launch_bounds__(az::NW * 64, WPS) void attn_fwd_z_kernel(AttnParams p) {
+// NW waves per workgroup (32 query rows each); WPS = resident waves per SIMD the register budget is cut for.  The hi+lo
+// instantiation (experiment, attn_variant bit 4) uses ONE 12-wave workgroup per CU around its 64 KiB K/V ring = three waves per
+// SIMD (two 6-wave workgroups do not work: the dispatcher deals a workgroup's waves 2,2,1,1 over the SIMDs, twice).
+template <int PLANES, int WPS, int NW>
+__global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_z_kernel(AttnParams p) {
     using namespace az;
+    constexpr int QB = NW * QW;
     using attn::sigma23;
     using attn::tr_frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = PLANES * 2 * KV_TILE;   // per plane: K slab + V slab
-    static_assert(NW * 4096 <= STAGE_BYTES, "the O-store epilogue gives every wave a 4 KiB patch of one ring slot");
+    static_assert(NW * 4096 <= 2 * STAGE_BYTES, "the O-store epilogue gives every wave a 4 KiB patch of the ring");
     int* const redo_flag = reinterpret_cast<int*>(smem + 2 * STAGE_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(az::NW * 64, WPS) void attn_fwd_z_kernel(AttnParams
         for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[pl][s]));
 
     // K/V tile loader (scalar base + constant lane offset; see attention.hip)
-    constexpr int NPIECE = 16 / NW;
+    constexpr int NPIECE = (16 + NW - 1) / NW;
     uint32_t soff[NPIECE];
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(az::NW * 64, WPS) void attn_fwd_z_kernel(AttnParams
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) {
                 const int piece = wave + i * NW;              // 0..7: K rows, 8..15: V rows
+                if (16 % NW != 0 && piece >= 16) continue;    // (12 waves: 16 pieces do not divide evenly; wave-uniform)
                 // (readfirstlane: all of this is wave-uniform, but the compiler's divergence analysis loses that in the two-plane
                 //  instantiation and would hand the asm vector registers)
                 const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
@@ -251,6 +256,7 @@ __global__ __launch_bounds__(az::NW * 64, WPS) void attn_fwd_z_kernel(AttnParams
             __syncthreads();
             pass(std::integral_constant<int, 2>{});
             l_tot = l_run + __shfl_xor(l_run, 32);
+            __syncthreads();               // the O patches below reuse the ring: everyone is done reading the last tile
         }
     }
 
@@ -259,7 +265,8 @@ __global__ __launch_bounds__(az::NW * 64, WPS) void attn_fwd_z_kernel(AttnParams
     const int b = pair / p.heads, head = pair - b * p.heads;
     const int dm = p.heads * 64;
     {
-        char* patch = smem + (ntiles & 1) * STAGE_BYTES + wave * 4096;
+        // (every wave has passed the workgroup barrier behind the last tile: the whole ring is free)
+        char* patch = smem + wave * 4096;
         const int q0 = qt * QB + wave * QW;
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl) {
@@ -286,21 +293,22 @@ __global__ __launch_bounds__(az::NW * 64, WPS) void attn_fwd_z_kernel(AttnParams
     }
 }
 
-template <int PLANES, int WPS>
+template <int PLANES, int WPS, int NW>
 static int launch_z(const AttnParams& p, hipStream_t s) {
     using namespace az;
+    constexpr int QB = NW * QW;
     const int nq = (p.ntok + QB - 1) / QB;
     const int npairs = p.B * p.heads;
     const int grid = ((npairs + 7) / 8) * 8 * nq;
     const size_t lds = (size_t)2 * PLANES * 2 * KV_TILE + 16;
-    hipLaunchKernelGGL((attn_fwd_z_kernel<PLANES, WPS>), dim3(grid), dim3(NW * 64), lds, s, p);
+    hipLaunchKernelGGL((attn_fwd_z_kernel<PLANES, WPS, NW>), dim3(grid), dim3(NW * 64), lds, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_attention_z(const AttnParams& p, hipStream_t s) {
-    if (p.planes == 1) return launch_z<1, 4>(p, s);
-    return launch_z<2, 3>(p, s);      // hi + lo planes: 168 registers, three waves per SIMD (the reference-based kernel: 213, two)
+    if (p.planes == 1) return launch_z<1, 4, 4>(p, s);
+    return launch_z<2, 3, 12>(p, s);      // hi + lo planes: 168 registers, three waves per SIMD (the reference-based kernel: 213, two)
 }
 
 }  // namespace dseg
