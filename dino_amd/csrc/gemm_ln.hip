@@ -1,5 +1,9 @@
 // LayerNorm-fused, A-stationary MFMA GEMM for the two LN-fed layers of a block (K = embed_dim):
 //     qkv = LN1(x) Wqkv^T + b  (vision_transformer.py:123 -> :75,82)      fc1: gelu(LN2(x) W1^T + b)  (:135 -> :60-61)
+// This file: the design, the generic kernel template, the packed-W layout and the dispatch; it RUNS the hi+lo (bf16x3)
+// configuration (64 x 128 tile, 4 waves: small batches of the parity mode and the bf16x3 training forward).  The bf16
+// configuration is the 12-wave kernel of gemm_ln12.hip (its header says what the measurements on this one led to); the 8-wave
+// 128 x 256 bf16 instantiation of this template (Cfg384x1) is kept for reference builds only.
 //
 // Why: the separate LayerNorm kernel wrote bf16 A (88 MB per launch at B=32) that the 256x384 persistent GEMM then fetched
 // 3-4x from the fabric (one pass per column tile: its 32 workgroups per XCD keep 6 MB of A panels in flight against a 4 MB
