@@ -383,3 +383,28 @@ def test_two_stream_split_equals_one_stream(cuda, precision, B):
         assert torch.equal(small, small1)
     finally:
         dino_amd.set_option("streams", 1)
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-3), ("bf16", 0.35)])
+def test_linear_dispatch_paths_agree(cuda, precision, tol):
+    """The LN-fed linears have three routes (option 'gemm_ln': 0 = LayerNorm kernel + GEMM, 2 = fused kernel wherever it is
+    supported, 1 = by measurement: fused in bf16, LayerNorm + the hi+lo persistent GEMM in bf16x3 at >= 512 tiles) and the other
+    linears two ('gemm_big' 0 / 1).  B = 8 @480 is large enough for every route to be taken; all of them are the same arithmetic
+    up to fp32 summation order (bf16 mode: up to a bf16 rounding point of an activation moving)."""
+    import dino_amd
+    m, _, _ = build(2, precision)
+    m.set_resolution(480)
+    frames = torch.from_numpy(synthetic_frames(8, 480, seed=91)).cuda()
+    outs = {}
+    try:
+        for ln, big in ((1, 1), (0, 1), (2, 1), (1, 0)):
+            dino_amd.set_option("gemm_ln", ln)
+            dino_amd.set_option("gemm_big", big)
+            outs[(ln, big)] = m.forward_frames(frames)[0].clone()
+    finally:
+        dino_amd.set_option("gemm_ln", 1)
+        dino_amd.set_option("gemm_big", 1)
+    ref = outs[(1, 1)]
+    assert torch.isfinite(ref).all()
+    for k, v in outs.items():
+        assert float((v - ref).abs().max()) <= tol, k
