@@ -184,10 +184,11 @@ def test_attention_rescale_branch(cuda, planes, spike):
 
 
 @pytest.mark.parametrize("planes", [1, 2])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 7, 11])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 7, 11, 27])
 def test_attention_kernel_variants(cuda, planes, variant):
     """dinoseg_set_option('attn_variant'): bit 0 = overflow check on the row sums instead of a per-tile row maximum, bit 1 =
-    idle waves of the last q-tile skip the tile work.  Without a rescale after the first tile both bits do the same
+    idle waves of the last q-tile skip the tile work, bit 2 = software-pipelined kernel (bf16), bit 3 = zero-reference kernel
+    (bf16, the default), bit 4 = zero-reference hi+lo kernel (12 waves; measured, not the default).  Without a rescale after the first tile both bits do the same
     arithmetic in the same order as the base kernel."""
     lib = capi.lib()
     try:
@@ -202,7 +203,8 @@ def test_attention_kernel_variants(cuda, planes, variant):
         capi.check(lib.dinoseg_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT))
     tol = 1.2e-2 if planes == 1 else 1e-4
     lse_tol = 6e-3 if planes == 1 else 1e-4
-    if planes == 2 or not (variant & 12):     # (the pipelined / zero-reference kernels (bf16 only) round differently)
+    # (the pipelined / zero-reference kernels (bits 2, 3: bf16 only; bit 4: the hi+lo zero-reference kernel) round differently)
+    if not (variant & 12) if planes == 1 else not (variant & 16):
         assert torch.equal(got, base) and torch.equal(lse, lse0)
     assert float((got - ref).abs().max()) <= tol and float((lse - ref_lse).abs().max()) <= lse_tol
     assert float((got2 - ref2).abs().max()) <= (2e-2 if planes == 1 else tol) and float((got3 - ref3).abs().max()) <= tol
