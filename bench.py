@@ -307,6 +307,7 @@ def main():
 
     traffic = None
     clock = None
+    measured_peak = None
     tpath = os.path.join(ROOT, "profiles", "attention_traffic.json")
     if os.path.exists(tpath):
         # HBM bytes per attention launch from the committed rocprofv3 PMC passes of this same command
@@ -316,6 +317,7 @@ def main():
                 and a.arch == "vit_small":
             traffic = None if split else tj["hbm_bytes_per_launch"]
             clock = tj.get("clock_ghz_under_load")
+        measured_peak = (tj.get("measured_mfma_peak_tflops") or {}).get("random_operands") if a.precision == "bf16" else None
 
     if rank == 0:
         out = {
@@ -341,6 +343,10 @@ def main():
                          "clock_ghz_under_load": clock,
                          "peak_at_measured_clock": None if clock is None else round(peak * clock / 2.4, 1),
                          "frac_at_measured_clock": None if (clock is None or achieved is None) else round(achieved / (peak * clock / 2.4), 4),
+                         # what a register-only MFMA loop sustains on this chip with non-trivial operand bits (tools/mfma_peak.py):
+                         # the power-limited ceiling of ANY bf16 MFMA kernel here, 79 % of the nominal peak
+                         "measured_mfma_peak": measured_peak,
+                         "frac_of_measured_mfma_peak": None if (measured_peak is None or achieved is None) else round(achieved / measured_peak, 4),
                          "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/attention_traffic.json)",
                          "algorithmic_bytes_per_launch": 4 * a.batch * cfg.num_heads * ((a.res // 8) ** 2 + 1) * 64 * 2

@@ -686,6 +686,11 @@ extern "C" int dinoseg_op_confusion(const int32_t* pred, const int64_t* gt, int6
     return launch_confusion(pred, gt, n, n_classes, cm, reinterpret_cast<hipStream_t>(stream));
 }
 
+extern "C" int dinoseg_op_mfma_peak(int32_t waves_per_simd, int32_t iters, uint32_t seed, int32_t chains, float* scratch,
+                                    double* flops_out, void* stream) {
+    return launch_mfma_peak(waves_per_simd, iters, seed, chains, scratch, flops_out, reinterpret_cast<hipStream_t>(stream));
+}
+
 // ------------------------------------------------------------------------------------------------ options
 namespace dseg {
 Options& options() {

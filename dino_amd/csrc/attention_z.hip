@@ -2,9 +2,9 @@
 //
 // Same tiling, LDS image, operand orientation and loaders as attention.hip (read its header first); what changes is the softmax
 // bookkeeping, to get from 165 to <= 128 registers per wave -- one more resident workgroup per CU.  Why that matters: a wave
-// issues at most one MFMA per ~64 cycles and spends most of a tile waiting (LDS fragments, the tile barrier, v_exp results);
-// with three waves per SIMD the matrix pipe is busy 53 % and the vector port 60 % -- the kernel is latency-bound, and the one
-// thing that has raised its throughput every time is more resident waves.
+// spends most of a tile waiting (LDS fragments, the tile barrier, v_exp results); with three waves per SIMD the matrix pipe
+// is busy 53 % and the vector port 60 % -- the kernel is latency-bound, and the one thing that has raised its throughput
+// every time is more resident waves.
 //   * no running reference: probabilities are 2^S against the FIXED reference 0, S = q.k * scale * log2(e).  fp32 (and bf16, same
 //     exponent range) hold 2^S for |S| < 126, i.e. raw logits up to +-87 * 8 / 1.44 -- far outside anything a trained ViT
 //     produces -- so the score accumulators start from the inline constant 0 (no 16-register -m_run operand), there is no

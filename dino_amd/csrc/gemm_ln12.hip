@@ -3,11 +3,11 @@
 //
 // Same design as gemm_ln.hip (K-resident bf16 image of the normalised 128-row panel in LDS, only W streams, private per-wave
 // LDS-DMA rings, no workgroup barrier in the k-loop, register-only epilogue, bias through an MFMA) with one more wave per SIMD.
-// Why: a wave of this chip issues at most one MFMA per ~64 cycles while a 32x32x16 MFMA keeps the pipe busy for 32
-// (measured: one wave per SIMD runs a pure MFMA stream at 48 % of the pipe rate, two waves at 100 % only while neither
-// does anything else -- every non-MFMA instruction of the two-wave kernel added to its run time: MFMAs + loop skeleton
-// 74 us = 48 us of pipe time + 28 us of skeleton, fragment reads, stream waits, prologue and epilogue on top).  With three
-// waves per SIMD two can feed the pipe while the third reads fragments, issues its LDS-DMA or waits.
+// Why: in the 8-wave kernel the non-MFMA work of a half-step (fragment reads, ring bookkeeping -- ~27 scalar and ~10 vector
+// instructions per four MFMAs -- stream waits, prologue, epilogue) was not hidden behind matrix work: every piece added to
+// the run time (MFMAs + loop skeleton 74 us = 48 us of pipe time + 28 us of skeleton).  tools/mfma_peak.py shows a pure MFMA
+// stream needs only one wave, but 32 scalar instructions per four MFMAs hold the pipe at ~75 % whatever the occupancy (one
+// scalar unit per CU): a third wave per SIMD gives the scheduler more to interleave (core loop 103 -> 84 us).
 // What changes to make 12 waves fit:
 //   * 168 registers per wave: accumulators 64 (128 rows x 32 columns), TWO fragment sets (reads one half-step ahead of their
 //     MFMAs: the other waves cover the LDS latency), immediate epilogue;

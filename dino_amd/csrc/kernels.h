@@ -90,6 +90,7 @@ struct AttnParams {
     int dbg;                           // timing-only ablations: bit0 skip max/exp, bit1 skip steady-state loads, bit2 skip PV
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
+int launch_mfma_peak(int waves_per_simd, int iters, uint32_t seed, int chains, float* out, double* flops, hipStream_t s);   // mfma_peak.hip (measurement)
 int launch_attention_z(const AttnParams& p, hipStream_t s);    // zero-reference softmax, <= 128 registers: 4 waves per SIMD (attention_z.hip)
 int launch_attention_pipe(const AttnParams& p, hipStream_t s); // bf16 only: software-pipelined across tiles (attention_pipe.hip)
 

@@ -1,0 +1,78 @@
+// Measurement kernel, not part of the path: what dense bf16 MFMA rate does this chip sustain, as a function of the resident
+// waves per SIMD and of the operand bits?  (SURVEY.md section 8d asks for a measured peak next to the vendor's 2.5 PFLOP/s;
+// DESIGN.md section 4 leans on two facts this kernel shows directly: one wave issues at most one 32x32x16 MFMA per ~64 cycles,
+// and the clock drops with switching activity.)  Registers only: no LDS, no memory traffic in the loop.
+#include "common.h"
+#include "kernels.h"
+
+namespace dseg {
+
+// FV / FS: independent VALU (v_add_f32) / SALU (s_add_u32) instructions after every group of four MFMAs -- how much of a wave's
+// non-MFMA work do the other resident waves' MFMAs hide?
+template <int NACC, int FV, int FS>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, uint32_t seed, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    // operands: seed == 0 -> all-zero bits (no switching activity); else pseudo-random bf16 in [-2, 2)
+    uint4 au, bu;
+    uint32_t h = seed * 2654435761u + (uint32_t)(blockIdx.x * 256 + threadIdx.x) * 40503u;
+    auto next = [&]() {
+        h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+        const uint32_t lo = 0x3F80u | (h & 0x807Fu), hi = 0x3F80u | ((h >> 16) & 0x807Fu);      // +-[1, 2)
+        return seed ? (lo | (hi << 16)) : 0u;
+    };
+    au = {next(), next(), next(), next()};
+    bu = {next(), next(), next(), next()};
+    const bf16x8 a = __builtin_bit_cast(bf16x8, au), b = __builtin_bit_cast(bf16x8, bu);
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float fv = (float)lane;
+    uint32_t fs = seed;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16 / NACC; ++u) {
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = mfma32(a, b, acc[i]);     // 16 MFMAs per trip, NACC independent chains
+            if ((u * NACC) % 4 == 4 - NACC || NACC == 4) {                     // after every fourth MFMA
+#pragma unroll
+                for (int k = 0; k < FV; ++k) asm volatile("v_add_f32 %0, %0, %0" : "+v"(fv));
+#pragma unroll
+                for (int k = 0; k < FS; ++k) asm volatile("s_add_u32 %0, %0, 1" : "+s"(fs) : : "scc");
+            }
+        }
+    }
+    float s = fv * 1e-30f + (float)(fs & 1);
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][lane & 15];
+    if (s == 12345.678f) out[0] = s;      // keeps the loop alive
+}
+
+// grid = CUs x waves_per_simd workgroups of 4 waves (one per SIMD); returns the launch through *flops = MFMA FLOPs issued
+// chains: 1, 2, 4 independent accumulator chains; or 100 + n: four chains and n VALU fillers per four MFMAs (n = 8, 16, 32);
+// or 200 + n: n SALU fillers
+int launch_mfma_peak(int waves_per_simd, int iters, uint32_t seed, int chains, float* out, double* flops, hipStream_t s) {
+    const int ncu = device_cu_count();
+    if (ncu <= 0 || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1) return -1;
+    const int grid = ncu * waves_per_simd;
+#define DSEG_PK(N, V, S) hipLaunchKernelGGL((mfma_peak_kernel<N, V, S>), dim3(grid), dim3(256), 0, s, iters, seed, out)
+    switch (chains) {
+        case 1: DSEG_PK(1, 0, 0); break;
+        case 2: DSEG_PK(2, 0, 0); break;
+        case 4: DSEG_PK(4, 0, 0); break;
+        case 108: DSEG_PK(4, 8, 0); break;
+        case 116: DSEG_PK(4, 16, 0); break;
+        case 132: DSEG_PK(4, 32, 0); break;
+        case 208: DSEG_PK(4, 0, 8); break;
+        case 216: DSEG_PK(4, 0, 16); break;
+        case 232: DSEG_PK(4, 0, 32); break;
+        default: dinoseg_set_error("mfma_peak: chains = %d", chains); return -1;
+    }
+#undef DSEG_PK
+    DSEG_CHECK_HIP(hipGetLastError());
+    if (flops) *flops = (double)grid * 4 * iters * 16 * (2.0 * 32 * 32 * 16);
+    return 0;
+}
+
+}  // namespace dseg

@@ -109,6 +109,11 @@ int dinoseg_op_resize_u8(const uint8_t* src, int32_t sh, int32_t sw, uint8_t* ds
 
 /* Confusion matrix for the validation metrics (validation_epoch_end, pl_torch_modules.py:310-332):
  * cm[gt][pred] += 1 over n patches; cm int64 [n_classes, n_classes] on device (zero it first). */
+/* Measurement only (no reference counterpart): a register-only v_mfma_f32_32x32x16_bf16 loop on waves_per_simd resident waves per
+ * SIMD of every CU, `chains` (1, 2, 4) independent accumulator chains per wave, operands all-zero (seed 0) or pseudo-random;
+ * *flops_out = FLOPs the launch issues.  tools/mfma_peak.py turns it into the measured dense-bf16 peak SURVEY.md 8d asks for. */
+int dinoseg_op_mfma_peak(int32_t waves_per_simd, int32_t iters, uint32_t seed, int32_t chains, float* scratch, double* flops_out,
+                         void* stream);
 int dinoseg_op_confusion(const int32_t* pred, const int64_t* gt, int64_t n, int32_t n_classes, int64_t* cm, void* stream);
 
 /* ---- fine-tune step (replaces DINOSeg.training_step + autograd + optimizer.step, pl_torch_modules.py:258-268) ---- */

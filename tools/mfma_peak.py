@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Measured dense-bf16 MFMA rate of this chip (a measured peak next to the vendor's 2.5 PFLOP/s).
+
+A register-only v_mfma_f32_32x32x16_bf16 loop (csrc/mfma_peak.hip) on 1..8 resident waves per SIMD, with 1 / 4 independent
+accumulator chains per wave, on all-zero and on pseudo-random operands.   python tools/mfma_peak.py  (GPU box)
+Under rocprofv3 --pmc GRBM_GUI_ACTIVE (tools/pmc_ops.sh-style) the same launches give the clock each case runs at."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from dino_amd import capi  # noqa: E402
+
+lib = capi.lib()
+scratch = torch.zeros(16, device="cuda")
+flops = C.c_double(0.0)
+ITERS = int(os.environ.get("MFMA_ITERS", "20000"))
+
+
+def run(wps, seed, chains):
+    def f():
+        capi.check(lib.dinoseg_op_mfma_peak(wps, ITERS, seed, chains, scratch.data_ptr(), C.addressof(flops), capi.stream_ptr()))
+    for _ in range(2):
+        f()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(3):
+        f()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 3
+    return flops.value / (ms * 1e-3) / 1e12, ms
+
+
+print(f"{'waves/SIMD':>10} {'mode':>22} {'operands':>9} {'TFLOP/s':>9} {'of 2500':>8} {'ms':>8}")
+ONLY = os.environ.get("MFMA_MODES")
+MODES = [(4, "4 chains"), (1, "1 chain")] + [(100 + n, f"+{n} VALU / 4 MFMA") for n in (8, 16, 32)] + \
+        [(200 + n, f"+{n} SALU / 4 MFMA") for n in (8, 16, 32)]
+if ONLY:
+    MODES = [m for m in MODES if str(m[0]) in ONLY.split(",")]
+for chains, label in MODES:
+    for wps in (1, 2, 3, 4, 8):
+        for seed, name in ((0, "zero"), (7, "random")) if chains < 100 else ((0, "zero"),):
+            tf, ms = run(wps, seed, chains)
+            print(f"{wps:>10} {label:>22} {name:>9} {tf:9.1f} {tf / 2500:8.3f} {ms:8.2f}", flush=True)
