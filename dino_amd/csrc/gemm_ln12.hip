@@ -82,26 +82,30 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
     const int M = p.M, N = p.N;
     const int nbn = (N + BN - 1) / BN, npanels = (M + BM - 1) / BM;
     const int my_panels = ((int)blockIdx.x < npanels) ? (npanels - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    const int total_hs = my_panels * nbn * NH;
-    if (total_hs == 0) return;
+    if (my_panels == 0) return;
     const bool wave_cols_valid_last = (nbn - 1) * BN + wave * 32 < N;     // does this wave own real columns in the last tile?
 
     // ---- W stream: a linear walk over nbn * NH contiguous half-step stages, restarted for every panel; one 1-KiB LDS-DMA per
-    // wave and half-step
-    int is_hs = 0, is_slot = 0;
-    long is_off = (long)wave * UNIT + lane * 16;
-    const long w_panel_bytes = (long)nbn * NH * HSTAGE;
-    const long is_off_end = w_panel_bytes + (long)wave * UNIT + lane * 16;
-    auto issue_next = [&]() {
-        glds16(reinterpret_cast<const char*>(p.W) + is_off, sWw + is_slot * UNIT);
-        ++is_hs;
+    // wave and half-step.  Bookkeeping is kept to a few SCALAR instructions per half-step (the CU has one scalar unit for its
+    // four SIMDs: tools/mfma_peak.py -- 32 scalar instructions per four MFMAs hold the matrix pipe at ~75 %, and the first
+    // version of this loop carried ~27 scalar + ~10 vector ones): the stream position is one 32-bit scalar byte offset (a packed
+    // W is < 4 GiB) next to a constant per-lane offset, ring positions are byte offsets with one wrap each, the refill is
+    // unconditional (the stream wraps inside W, so the RING units issued past this workgroup's last half-step read valid
+    // memory into a ring nobody reads any more; they are drained before the kernel ends).
+    const uint32_t w_panel_bytes = (uint32_t)(nbn * NH * HSTAGE);
+    const uint32_t lane16 = (uint32_t)lane * 16;
+    uint32_t is_off = (uint32_t)wave * UNIT;                    // scalar: this wave's unit of the half-step stage being issued
+    const uint32_t is_off_end = w_panel_bytes + (uint32_t)wave * UNIT;
+    uint32_t ring_off = 0;                                      // scalar: byte offset (in the wave's ring) of the unit being multiplied
+    auto issue_next = [&](uint32_t slot_off) {
+        glds16(reinterpret_cast<const char*>(p.W) + (size_t)(is_off + lane16), sWw + slot_off);
         is_off += HSTAGE;
-        if (is_off == is_off_end) is_off -= w_panel_bytes;
-        is_slot = is_slot + 1 == RING ? 0 : is_slot + 1;
+        is_off = is_off == is_off_end ? is_off - w_panel_bytes : is_off;
     };
+    static_assert(NH >= RING, "the ring prologue assumes a panel has at least RING half-steps");
 #pragma unroll
     for (int s = 0; s < RING; ++s)
-        if (s < total_hs && !(dbg & 2)) issue_next();
+        if (!(dbg & 2)) issue_next(s * UNIT);
 
     f32x16 acc[MI];
     uint32_t row_off[MI];       // element offset of this lane's output row in each row block of the current panel
@@ -189,15 +193,14 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
     const uint32_t lds_w = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)sWw;
     const uint32_t la0 = lds_a + off64(lr, lh), la1 = lds_a + off64(lr, 2 + lh);        // the two halves of a 32-k slab
     const uint32_t lw = lds_w + lr * 32 + ((lh ^ ((lr >> 3) & 1)) << 4);
-    int cs_slot = 0;                        // ring slot of the unit being multiplied
     constexpr int TILE_STORES = MI * 2;     // 16-byte stores of one tile's epilogue (without aux_out: with it the waits are merely stricter)
     int stores_young = 0;                   // half-steps for which the last epilogue's stores are younger than the awaited unit
-    auto issue_reads = [&](auto set_tag, int kt, int kk, int slot) {
+    auto issue_reads = [&](auto set_tag, uint32_t a_off, int kk, uint32_t slot_off) {
         constexpr int S = decltype(set_tag)::value;
         Half& f = hs[S];
         if ((DBG || ALN_ABL) && (dbg & 32)) return;
-        const uint32_t aw = lw + slot * UNIT;
-        const uint32_t ap = (kk ? la1 : la0) + kt * A_SLAB;
+        const uint32_t aw = lw + slot_off;
+        const uint32_t ap = (kk ? la1 : la0) + a_off;
         asm volatile("ds_read_b128 %0, %1" : "=v"(f.w) : "v"(aw));
         asm volatile("ds_read_b128 %0, %1" : "=v"(f.a[0]) : "v"(ap));
         asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f.a[1]) : "v"(ap));
@@ -212,10 +215,11 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
 #pragma unroll
         for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(f.a[i]));
     };
-    // one half-step (kt, kk) = ring unit cs_slot, fragments in set KK.  `last` = last half-step of the panel: no reads ahead
-    // (the next panel's fill issues them from the new image).  gfx9 retires loads, stores and LDS-DMA through one in-order
-    // vmcnt: after the refill the three youngest units may stay in flight; the unit read at the NEXT half-step is older.
-    auto half_step = [&](auto valid_tag, auto kk_tag, int kt, bool last) {
+    // one half-step (slab byte offset a_off, half kk) = the ring unit at ring_off, fragments in set KK.  The reads one half-step
+    // ahead are issued unconditionally: at a panel's last half-step they fetch stale image rows into set 0, which the next
+    // panel's fill overwrites (LDS requests of one wave complete in order).  gfx9 retires loads, stores and LDS-DMA through one
+    // in-order vmcnt: after the refill the three youngest units may stay in flight; the unit read at the NEXT half-step is older.
+    auto half_step = [&](auto valid_tag, auto kk_tag, uint32_t a_off_next) {
         constexpr bool VALID = decltype(valid_tag)::value;
         constexpr int KK = decltype(kk_tag)::value;
         using Cur = std::integral_constant<int, KK>;
@@ -225,15 +229,12 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
         const bool mm = VALID && !((DBG || ALN_ABL) && (dbg & 8));
         if (mm) acc[0] = mfma32(f.w, f.a[0], acc[0]);
         __builtin_amdgcn_sched_barrier(0);
-        if (!last) issue_reads(Nxt{}, KK ? (kt + 1 == NK ? 0 : kt + 1) : kt, KK ^ 1, cs_slot + 1 == RING ? 0 : cs_slot + 1);
+        const uint32_t ring_next = ring_off + UNIT == RING * UNIT ? 0 : ring_off + UNIT;
+        issue_reads(Nxt{}, a_off_next, KK ^ 1, ring_next);
         __builtin_amdgcn_sched_barrier(0);
         if (mm) acc[1] = mfma32(f.w, f.a[1], acc[1]);
         __builtin_amdgcn_sched_barrier(0);
-        bool refill = false;
-        if (!(dbg & 2)) {
-            refill = is_hs < total_hs;      // this unit's fragments are in registers: its slot takes unit + RING
-            if (refill) issue_next();
-        }
+        if (!(dbg & 2)) issue_next(ring_off);      // this unit's fragments are in registers: its slot takes unit + RING
         __builtin_amdgcn_sched_barrier(0);
         if (mm) acc[2] = mfma32(f.w, f.a[2], acc[2]);
         if (mm) acc[3] = mfma32(f.w, f.a[3], acc[3]);
@@ -242,23 +243,21 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
             // the epilogue's 8 stores sit between units in the queue: for the three half-steps after a drain they are YOUNGER than
             // the awaited unit and may stay in flight too (without them in the count every tile began by waiting for its
             // predecessor's stores to be acknowledged, all twelve waves at once)
-            if (!refill) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last RING half-steps of the kernel
-            else if (stores_young > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 2 + TILE_STORES) : "memory");
+            if (stores_young > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 2 + TILE_STORES) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 2) : "memory");
             stores_young = stores_young > 0 ? stores_young - 1 : 0;
-        } else {
-            ++is_hs;
         }
         asm volatile("" ::: "memory");
-        cs_slot = cs_slot + 1 == RING ? 0 : cs_slot + 1;
+        ring_off = ring_next;
     };
     auto run_tile = [&](auto valid_tag, int bn) {
-        const bool last_tile = bn + 1 == nbn;
+        load_bias(bn + 1 < nbn ? bn + 1 : 0, bias_nxt);      // of the NEXT tile (wraps to the next panel's first)
+        uint32_t a_off = 0;
 #pragma unroll 1
         for (int kt = 0; kt < NK; ++kt) {
-            half_step(valid_tag, std::integral_constant<int, 0>{}, kt, false);
-            if (kt == 0) load_bias(bn + 1 < nbn ? bn + 1 : 0, bias_nxt);      // of the NEXT tile (wraps to the next panel's first)
-            half_step(valid_tag, std::integral_constant<int, 1>{}, kt, last_tile && kt + 1 == NK);
+            half_step(valid_tag, std::integral_constant<int, 0>{}, a_off);                       // reads ahead: (kt, 1)
+            a_off = a_off + A_SLAB == NK * A_SLAB ? 0 : a_off + A_SLAB;
+            half_step(valid_tag, std::integral_constant<int, 1>{}, a_off);                       // reads ahead: (kt + 1, 0)
         }
     };
 
@@ -370,7 +369,7 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
 #endif
         // fill the fragment pipeline: this panel's first two units were waited for already (kernel start / the last half-steps of
         // the previous panel)
-        issue_reads(std::integral_constant<int, 0>{}, 0, 0, cs_slot);
+        issue_reads(std::integral_constant<int, 0>{}, 0, 0, ring_off);
         for (int bn = 0; bn < nbn; ++bn) {
             const bool cols_valid = bn + 1 < nbn || wave_cols_valid_last;      // wave-uniform
             init_acc(bias_cur);
@@ -388,6 +387,7 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
             bias_cur = bias_nxt;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the RING units issued past the end (and the last stores)
 }
 
 template <int EPI>
