@@ -36,12 +36,14 @@ constexpr int PASSES = BM / 4, PPW = (PASSES + NW - 1) / NW;     // LayerNorm: 4
 __global__ __launch_bounds__(256) void pack_slabs12_kernel(const float* __restrict__ src, int N, int K, bf16_t* __restrict__ dst,
                                                            long total) {
     const int nh = K / 16;
+    const long nstages = (long)((N + ln12::BN - 1) / ln12::BN) * nh;      // + RING more: the first RING stages again (see the kernel)
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         long t = idx;
         const int e = (int)(t & 7); t >>= 3;
         const int phys = (int)(t & 1); t >>= 1;
         const int r = (int)(t & 31); t >>= 5;
         const int rb = (int)(t % ln12::NW); t /= ln12::NW;
+        if (t >= nstages) t -= nstages;
         const int h = (int)(t % nh);
         const int tile = (int)(t / nh);
         const int n = tile * ln12::BN + rb * 32 + r, k = h * 16 + ((phys ^ ((r >> 3) & 1)) << 3) + e;
@@ -50,7 +52,12 @@ __global__ __launch_bounds__(256) void pack_slabs12_kernel(const float* __restri
     }
 }
 
-long gemm_ln12_slab_elems(int N, int K) { return (long)((N + ln12::BN - 1) / ln12::BN) * ln12::BN * K; }
+// (the walk over the nbn * NH half-step stages of a panel is followed by a copy of its first RING stages: the stream runs RING
+//  units ahead of the multiplication, so it crosses into the next panel's first stages before the panel ends -- with the copy
+//  it does so linearly and the wrap-around is one subtraction per panel instead of a compare + select per half-step)
+long gemm_ln12_slab_elems(int N, int K) {
+    return (long)((N + ln12::BN - 1) / ln12::BN) * ln12::BN * K + (long)ln12::RING * ln12::HSTAGE / 2;
+}
 
 int launch_pack_slabs12(const float* src, int N, int K, bf16_t* dst, hipStream_t s) {
     const long total = gemm_ln12_slab_elems(N, K);
@@ -95,12 +102,10 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
     const uint32_t w_panel_bytes = (uint32_t)(nbn * NH * HSTAGE);
     const uint32_t lane16 = (uint32_t)lane * 16;
     uint32_t is_off = (uint32_t)wave * UNIT;                    // scalar: this wave's unit of the half-step stage being issued
-    const uint32_t is_off_end = w_panel_bytes + (uint32_t)wave * UNIT;
     uint32_t ring_off = 0;                                      // scalar: byte offset (in the wave's ring) of the unit being multiplied
     auto issue_next = [&](uint32_t slot_off) {
         glds16(reinterpret_cast<const char*>(p.W) + (size_t)(is_off + lane16), sWw + slot_off);
-        is_off += HSTAGE;
-        is_off = is_off == is_off_end ? is_off - w_panel_bytes : is_off;
+        is_off += HSTAGE;       // wraps once per panel (below): the packed copy repeats its first RING stages at the end
     };
     static_assert(NH >= RING, "the ring prologue assumes a panel has at least RING half-steps");
 #pragma unroll
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
     const uint32_t la0 = lds_a + off64(lr, lh), la1 = lds_a + off64(lr, 2 + lh);        // the two halves of a 32-k slab
     const uint32_t lw = lds_w + lr * 32 + ((lh ^ ((lr >> 3) & 1)) << 4);
     constexpr int TILE_STORES = MI * 2;     // 16-byte stores of one tile's epilogue (without aux_out: with it the waits are merely stricter)
-    int stores_young = 0;                   // half-steps for which the last epilogue's stores are younger than the awaited unit
+    bool prev_stored = false;               // did this wave's previous tile end with stores (wave-uniform)?
     auto issue_reads = [&](auto set_tag, uint32_t a_off, int kk, uint32_t slot_off) {
         constexpr int S = decltype(set_tag)::value;
         Half& f = hs[S];
@@ -219,9 +224,13 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
     // ahead are issued unconditionally: at a panel's last half-step they fetch stale image rows into set 0, which the next
     // panel's fill overwrites (LDS requests of one wave complete in order).  gfx9 retires loads, stores and LDS-DMA through one
     // in-order vmcnt: after the refill the three youngest units may stay in flight; the unit read at the NEXT half-step is older.
-    auto half_step = [&](auto valid_tag, auto kk_tag, uint32_t a_off_next) {
+    // LAX (the first RING - 2 half-steps of a tile): the previous tile's epilogue stores sit between units in the queue and are
+    // YOUNGER than the awaited unit -- they may stay in flight too (without them in the count every tile began by waiting for its
+    // predecessor's stores to be acknowledged, all twelve waves at once)
+    auto half_step = [&](auto valid_tag, auto kk_tag, auto lax_tag, uint32_t a_off_next) {
         constexpr bool VALID = decltype(valid_tag)::value;
         constexpr int KK = decltype(kk_tag)::value;
+        constexpr bool LAX = decltype(lax_tag)::value;
         using Cur = std::integral_constant<int, KK>;
         using Nxt = std::integral_constant<int, KK ^ 1>;
         const Half& f = hs[KK];
@@ -240,24 +249,30 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
         if (mm) acc[3] = mfma32(f.w, f.a[3], acc[3]);
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 2)) {
-            // the epilogue's 8 stores sit between units in the queue: for the three half-steps after a drain they are YOUNGER than
-            // the awaited unit and may stay in flight too (without them in the count every tile began by waiting for its
-            // predecessor's stores to be acknowledged, all twelve waves at once)
-            if (stores_young > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 2 + TILE_STORES) : "memory");
+            if (LAX && prev_stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 2 + TILE_STORES) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 2) : "memory");
-            stores_young = stores_young > 0 ? stores_young - 1 : 0;
         }
         asm volatile("" ::: "memory");
         ring_off = ring_next;
     };
     auto run_tile = [&](auto valid_tag, int bn) {
         load_bias(bn + 1 < nbn ? bn + 1 : 0, bias_nxt);      // of the NEXT tile (wraps to the next panel's first)
-        uint32_t a_off = 0;
+        using K0 = std::integral_constant<int, 0>;
+        using K1 = std::integral_constant<int, 1>;
+        static_assert(RING - 2 == 3 && NK % 2 == 0, "three lax half-steps, the k-loop unrolled by two");
+        // k-steps 0 and 1 (the first three half-steps lax), then pairs of k-steps; the reads run one half-step ahead
+        half_step(valid_tag, K0{}, std::true_type{}, 0);
+        half_step(valid_tag, K1{}, std::true_type{}, A_SLAB);
+        half_step(valid_tag, K0{}, std::true_type{}, A_SLAB);
+        half_step(valid_tag, K1{}, std::false_type{}, 2 * A_SLAB);
+        uint32_t a_off = 2 * A_SLAB;
 #pragma unroll 1
-        for (int kt = 0; kt < NK; ++kt) {
-            half_step(valid_tag, std::integral_constant<int, 0>{}, a_off);                       // reads ahead: (kt, 1)
-            a_off = a_off + A_SLAB == NK * A_SLAB ? 0 : a_off + A_SLAB;
-            half_step(valid_tag, std::integral_constant<int, 1>{}, a_off);                       // reads ahead: (kt + 1, 0)
+        for (int kt = 2; kt < NK; kt += 2) {
+            half_step(valid_tag, K0{}, std::false_type{}, a_off);
+            half_step(valid_tag, K1{}, std::false_type{}, a_off + A_SLAB);
+            half_step(valid_tag, K0{}, std::false_type{}, a_off + A_SLAB);
+            a_off = a_off + 2 * A_SLAB == NK * A_SLAB ? 0 : a_off + 2 * A_SLAB;
+            half_step(valid_tag, K1{}, std::false_type{}, a_off);
         }
     };
 
@@ -382,10 +397,11 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
                 drain_block(std::integral_constant<int, 1>{}, n0);
                 drain_block(std::integral_constant<int, 2>{}, n0);
                 drain_block(std::integral_constant<int, 3>{}, n0);
-                if (n0 < N && !(dbg & 1)) stores_young = RING - 2;
             }
+            prev_stored = cols_valid && bn * BN + wave * 32 < N && !(dbg & 1);
             bias_cur = bias_nxt;
         }
+        is_off -= w_panel_bytes;       // the stream has walked nbn * NH stages (it is RING stages into the repeated head)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the RING units issued past the end (and the last stores)
 }
