@@ -83,7 +83,7 @@ def main():
     if old_traffic:
         tj = json.load(open(os.path.join(dst, "attention_traffic.json")))
         for key, val in old_traffic.items():
-            if key.startswith("clock_"):
+            if key.startswith("clock_") or key.startswith("measured_"):
                 tj[key] = val
         json.dump(tj, open(os.path.join(dst, "attention_traffic.json"), "w"), indent=1)
 
