@@ -453,3 +453,29 @@ def test_outlier_channels_and_sharp_heads(cuda, precision):
         assert not bool((flips & (margin > 4e-3)).any())       # only genuine ties may flip
     else:
         assert err <= 0.6 and float(flips.float().mean()) <= 0.05
+
+
+def test_two_stream_forward_is_graph_capturable(cuda):
+    """include/dinoseg.h promises that the split forward stays capturable: the internal stream joins the capture through the fork
+    event and leaves it through the join event.  Capture on a side stream, replay, compare with the eager single-stream result."""
+    import dino_amd
+    m, _, _ = build(2, "bf16")
+    m.set_resolution(112)
+    frames = torch.from_numpy(synthetic_frames(16, 112, seed=5)).cuda()
+    ref = m.forward_frames(frames)[0].clone()
+    dino_amd.set_option("streams", 2)
+    try:
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            m.forward_frames(frames)            # warm-up outside the capture: workspaces, the internal stream and its events exist
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                out, _ = m.forward_frames(frames)
+        torch.cuda.synchronize()
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    finally:
+        dino_amd.set_option("streams", 1)
