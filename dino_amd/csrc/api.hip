@@ -23,7 +23,7 @@ extern "C" void dinoseg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* dinoseg_last_error(void) { return g_err; }
-extern "C" int dinoseg_version(void) { return 200; }
+extern "C" int dinoseg_version(void) { return 210; }      // 2.1: "streams" option, dinoseg_op_mfma_peak, hi+lo persistent GEMM
 
 int device_cu_count() {
     static std::atomic<int> cache[64];
