@@ -9,7 +9,8 @@ namespace dseg {
 
 // FV / FS: independent VALU (v_add_f32) / SALU (s_add_u32) instructions after every group of four MFMAs -- how much of a wave's
 // non-MFMA work do the other resident waves' MFMAs hide?
-template <int NACC, int FV, int FS>
+// FN / FW: s_nop 0 / s_waitcnt lgkmcnt(0) (nothing outstanding) fillers -- sequencer-internal instructions.
+template <int NACC, int FV, int FS, int FN = 0, int FW = 0>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, uint32_t seed, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     // operands: seed == 0 -> all-zero bits (no switching activity); else pseudo-random bf16 in [-2, 2)
@@ -40,6 +41,10 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, uint32_t seed
                 for (int k = 0; k < FV; ++k) asm volatile("v_add_f32 %0, %0, %0" : "+v"(fv));
 #pragma unroll
                 for (int k = 0; k < FS; ++k) asm volatile("s_add_u32 %0, %0, 1" : "+s"(fs) : : "scc");
+#pragma unroll
+                for (int k = 0; k < FN; ++k) asm volatile("s_nop 0");
+#pragma unroll
+                for (int k = 0; k < FW; ++k) asm volatile("s_waitcnt lgkmcnt(0)");
             }
         }
     }
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, uint32_t seed
 
 // grid = CUs x waves_per_simd workgroups of 4 waves (one per SIMD); returns the launch through *flops = MFMA FLOPs issued
 // chains: 1, 2, 4 independent accumulator chains; or 100 + n: four chains and n VALU fillers per four MFMAs (n = 8, 16, 32);
-// or 200 + n: n SALU fillers
+// or 200 + n: n SALU fillers; 300 + n (16, 32): s_nop 0; 400 + n (16, 32): s_waitcnt lgkmcnt(0)
 int launch_mfma_peak(int waves_per_simd, int iters, uint32_t seed, int chains, float* out, double* flops, hipStream_t s) {
     const int ncu = device_cu_count();
     if (ncu <= 0 || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1) return -1;
@@ -67,6 +72,10 @@ int launch_mfma_peak(int waves_per_simd, int iters, uint32_t seed, int chains, f
         case 208: DSEG_PK(4, 0, 8); break;
         case 216: DSEG_PK(4, 0, 16); break;
         case 232: DSEG_PK(4, 0, 32); break;
+        case 316: hipLaunchKernelGGL((mfma_peak_kernel<4, 0, 0, 16, 0>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
+        case 332: hipLaunchKernelGGL((mfma_peak_kernel<4, 0, 0, 32, 0>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
+        case 416: hipLaunchKernelGGL((mfma_peak_kernel<4, 0, 0, 0, 16>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
+        case 432: hipLaunchKernelGGL((mfma_peak_kernel<4, 0, 0, 0, 32>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
         default: dinoseg_set_error("mfma_peak: chains = %d", chains); return -1;
     }
 #undef DSEG_PK

@@ -37,7 +37,8 @@ def run(wps, seed, chains):
 print(f"{'waves/SIMD':>10} {'mode':>22} {'operands':>9} {'TFLOP/s':>9} {'of 2500':>8} {'ms':>8}")
 ONLY = os.environ.get("MFMA_MODES")
 MODES = [(4, "4 chains"), (1, "1 chain")] + [(100 + n, f"+{n} VALU / 4 MFMA") for n in (8, 16, 32)] + \
-        [(200 + n, f"+{n} SALU / 4 MFMA") for n in (8, 16, 32)]
+        [(200 + n, f"+{n} SALU / 4 MFMA") for n in (8, 16, 32)] + [(300 + n, f"+{n} s_nop / 4 MFMA") for n in (16, 32)] + \
+        [(400 + n, f"+{n} s_waitcnt / 4 MFMA") for n in (16, 32)]
 if ONLY:
     MODES = [m for m in MODES if str(m[0]) in ONLY.split(",")]
 for chains, label in MODES:
