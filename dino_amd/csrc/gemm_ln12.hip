@@ -175,7 +175,8 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
                 const auto sx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
                 const uint4 o = {sx[0], sy[0], sx[1], sy[1]};
-                *reinterpret_cast<uint4*>(dst + qq * 16 + lh * 8) = o;
+                if ((DBG || ALN_ABL) && (dbg & 64)) asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));      // ablation: stores issued from the k-loop instead
+                else *reinterpret_cast<uint4*>(dst + qq * 16 + lh * 8) = o;
             }
         };
         if (EPI == EPI_GELU && p.aux_out != nullptr) store_block(v, p.aux_out + row_off[i] + n0);
@@ -270,6 +271,17 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
         for (int kt = 2; kt < NK; kt += 2) {
             half_step(valid_tag, K0{}, std::false_type{}, a_off);
             half_step(valid_tag, K1{}, std::false_type{}, a_off + A_SLAB);
+            if ((DBG || ALN_ABL) && (dbg & 64) && EPI == EPI_GELU && bn > 0) {
+                // timing experiment (wrong results): the PREVIOUS tile's 8 stores spread over this tile's k-loop, two per pair of
+                // k-steps, the way a deferred epilogue would issue them -- is the epilogue's cost the burst or the bytes?
+                const int blk = (kt - 2) >> 1;
+                if (blk < MI) {
+                    const uint4 junk = {0u, 0u, 0u, 0u};
+                    bf16_t* dst = p.out_bf16 + row_off[blk & (MI - 1)] + ((bn - 1) * BN + wave * 32);
+                    *reinterpret_cast<uint4*>(dst + lh * 8) = junk;
+                    *reinterpret_cast<uint4*>(dst + 16 + lh * 8) = junk;
+                }
+            }
             half_step(valid_tag, K0{}, std::false_type{}, a_off + A_SLAB);
             a_off = a_off + 2 * A_SLAB == NK * A_SLAB ? 0 : a_off + 2 * A_SLAB;
             half_step(valid_tag, K1{}, std::false_type{}, a_off);
