@@ -23,7 +23,7 @@ extern "C" void dinoseg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* dinoseg_last_error(void) { return g_err; }
-extern "C" int dinoseg_version(void) { return 210; }      // 2.1: "streams" option, dinoseg_op_mfma_peak, hi+lo persistent GEMM
+extern "C" int dinoseg_version(void) { return 300; }      // 2.1: "streams" option, dinoseg_op_mfma_peak, hi+lo persistent GEMM
 
 int device_cu_count() {
     static std::atomic<int> cache[64];
@@ -179,6 +179,7 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
                 h->tws_B = h->tws_r = h->tr_B = -1;
                 h->packed.clear();
                 h->packed_slab.clear();
+                h->packed_mlp.clear();
                 h->bound.clear();
                 h->grads.clear();
             }
@@ -243,6 +244,9 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
         if (sp.n_pad != sp.N) total += align_up((size_t)sp.n_pad * sizeof(float), 256);
         if (ln_fed(sp)) total += align_up((size_t)gemm_ln_slab_elems(sp.N, sp.K, sp.planes) * sizeof(bf16_t), 256);
     }
+    const int Dm = h->cfg.embed_dim, Fh = h->cfg.embed_dim * h->cfg.mlp_ratio;
+    const bool mlp_fusable = mlp_fused_supported(Dm, Fh, h->planes);
+    if (mlp_fusable) total += (size_t)h->cfg.n_blocks * align_up((size_t)mlp_fused_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
     if (total > h->wbuf_bytes) {
         if (h->wbuf) DSEG_CHECK_HIP(hipFree(h->wbuf));
         h->wbuf = nullptr;
@@ -273,6 +277,15 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
             h->packed_slab[sp.wname] = slab;
         }
     }
+    h->packed_mlp.clear();
+    if (mlp_fusable)
+        for (int i = 0; i < h->cfg.n_blocks; ++i) {
+            const std::string b = "dino.blocks." + std::to_string(i) + ".";
+            bf16_t* dst = reinterpret_cast<bf16_t*>(h->wbuf + off);
+            off += align_up((size_t)mlp_fused_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
+            DSEG_TRY(launch_pack_mlp(W(h, b + "mlp.fc1.weight"), W(h, b + "mlp.fc2.weight"), Dm, Fh, dst, s));
+            h->packed_mlp[b] = dst;
+        }
     h->weights_ready = true;
     h->pos_r = -1;   // pos_embed may have changed (fine-tune)
     return 0;
@@ -532,6 +545,16 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.out_f32 = X; g.ldo_f32 = D;
             DSEG_PROF(DINOSEG_PROF_PROJ, DSEG_TRY(launch_gemm(g, s)));
         }
+        const bool fuse_mlp = h->packed_mlp.count(b) && (options().mlp_fused == 2 ||
+                                                         (options().mlp_fused == 1 && L.M >= options().mlp_fused_min_rows));
+        if (fuse_mlp) {
+            // LN2 + fc1 + GELU + fc2 + residual in one launch: the hidden activation never reaches HBM (mlp_fused.hip)
+            MlpFusedParams g = {};
+            g.X = X; g.ldx = D; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
+            g.Wp = h->packed_mlp.at(b); g.b1 = W(h, b + "mlp.fc1.bias"); g.b2 = W(h, b + "mlp.fc2.bias");
+            g.M = L.M;
+            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_mlp_fused(g, s)));
+        } else {
         if (fuse_ln && h->packed_slab.count(b + "mlp.fc1.weight") && L.hb_plane < (1L << 31)) {
             LnGemmParams g = {};
             g.X = X; g.ldx = D; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
@@ -562,6 +585,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.bias = W(h, b + "mlp.fc2.bias");
             g.out_f32 = X; g.ldo_f32 = D;
             DSEG_PROF(DINOSEG_PROF_FC2, DSEG_TRY(launch_gemm(g, s)));
+        }
         }
         if (tap_block == i + 1 && tap_out) DSEG_CHECK_HIP(hipMemcpyAsync(tap_out, X, xbytes, hipMemcpyDeviceToDevice, s));
         if (mreq && mreq->feat_out && mreq->feat_blocks == i + 1 && i + 1 < c.n_blocks)      // forward(x, intermediate=k)
@@ -713,6 +737,14 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().streams = value;
         return 0;
     }
+    if (strcmp(key, "mlp_fused") == 0) {
+        dseg::options().mlp_fused = value;
+        return 0;
+    }
+    if (strcmp(key, "mlp_fused_min_rows") == 0) {
+        dseg::options().mlp_fused_min_rows = value;
+        return 0;
+    }
     if (strcmp(key, "split_min") == 0) {
         dseg::options().split_min = value < 2 ? 2 : value;
         return 0;
@@ -804,6 +836,28 @@ extern "C" int dinoseg_op_qkv_gemm(const void* A, int64_t a_plane, const void* W
     g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
     g.qkv_plane = qkv_plane; g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = D; g.qscale = qscale;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t dinoseg_op_mlp_fused_pack_elems(int32_t D, int32_t F) { return mlp_fused_pack_elems(D, F); }
+
+extern "C" int dinoseg_op_pack_mlp(const float* W1, const float* W2, int32_t D, int32_t F, void* dst, void* stream) {
+    if (!W1 || !W2 || !dst) {
+        dinoseg_set_error("dinoseg_op_pack_mlp: null pointer");
+        return -1;
+    }
+    return launch_pack_mlp(W1, W2, D, F, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_mlp_fused(float* X, const float* gamma, const float* beta, float eps, const void* Wp, const float* b1,
+                                    const float* b2, int32_t M, int32_t D, int32_t F, void* stream) {
+    if (!X || !gamma || !beta || !Wp || !b1 || !b2 || !mlp_fused_supported(D, F, 1)) {
+        dinoseg_set_error("dinoseg_op_mlp_fused: null pointer or unsupported shape D=%d F=%d", D, F);
+        return -1;
+    }
+    MlpFusedParams g = {};
+    g.X = X; g.ldx = D; g.gamma = gamma; g.beta = beta; g.eps = eps;
+    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
+    return launch_mlp_fused(g, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t dinoseg_op_ln_gemm_slab_elems(int32_t N, int32_t K, int32_t planes) {

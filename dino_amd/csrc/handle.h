@@ -40,6 +40,7 @@ struct dinoseg_handle {
     size_t wbuf_bytes = 0;
     std::map<std::string, PackedLinear> packed;
     std::map<std::string, bf16_t*> packed_slab;     // slab-major copies of the LN-fed weights (gemm_ln.hip), when supported
+    std::map<std::string, bf16_t*> packed_mlp;      // per block ("dino.blocks.i."): fc1 + fc2 in MFMA fragment order (mlp_fused.hip)
     bool weights_ready = false;
     // pos-embed cache
     float* pos_cache = nullptr;

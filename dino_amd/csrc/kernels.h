@@ -67,12 +67,27 @@ long gemm_ln_slab_elems(int N, int K, int planes);      // bf16 elements of the 
 int launch_pack_slabs(const float* src, int N, int K, int planes, bf16_t* dst, hipStream_t s);
 int launch_gemm_ln(const LnGemmParams& p, int K, int planes, hipStream_t s);
 
+// Fused MLP of one transformer block, bf16 mode, D = 384 (mlp_fused.hip): X += fc2(gelu(fc1(LayerNorm(X))))   in place
+struct MlpFusedParams {
+    float* X; int ldx;                          // residual stream [M, 384] fp32
+    const float* gamma; const float* beta; float eps;
+    const bf16_t* Wp;                           // both weights in MFMA fragment order (launch_pack_mlp)
+    const float* b1; const float* b2;           // [1536], [384]
+    int M;
+};
+bool mlp_fused_supported(int D, int F, int planes);
+long mlp_fused_pack_elems(int D, int F);        // bf16 elements of the packed copy (0: unsupported shape)
+int launch_pack_mlp(const float* W1, const float* W2, int D, int F, bf16_t* dst, hipStream_t s);
+int launch_mlp_fused(const MlpFusedParams& p, hipStream_t s);
+
 // tuning knobs (dinoseg_set_option): see api.hip
 struct Options {
     int gemm_ln = 1;         // qkv / fc1 through the LayerNorm-fused kernel (gemm_ln.hip): 0 never, 2 wherever it applies, 1 = by measurement (api.hip)
     int gemm_big = 1;        // use gemm_big.hip where it applies
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
     int attn_dbg = 0;        // same for AttnParams::dbg
+    int mlp_fused = 1;       // the MLP half of a block as one launch (mlp_fused.hip): 0 never, 1 for >= mlp_fused_min_rows rows, 2 wherever supported
+    int mlp_fused_min_rows = 24000;
     int streams = 1;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 16;
     int attn_variant = 11;   // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the

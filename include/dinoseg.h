@@ -181,6 +181,8 @@ int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
  *   "gemm_big"   1 [default] = the persistent 256x384 (bf16) / 128x384 (bf16x3) GEMM where it applies, 0 = always the 128x128
  *                kernel, 2 = wherever its shape rules allow;
  *   "gemm_ln"    1 [default] = qkv / fc1 through the LayerNorm-fused kernels where measured faster, 0 never, 2 wherever supported;
+ *   "mlp_fused"  1 [default] = the MLP half of a block (LayerNorm2, fc1, GELU, fc2, residual) as ONE launch where it applies (bf16
+ *                mode, embed_dim 384, batches of >= 8 frames at 480x480), 0 never, 2 wherever the shape allows;
  *   "attn_variant", "gemm_dbg", "attn_dbg": kernel A/B and timing-ablation switches (tools/bench_ops.py). */
 int dinoseg_set_option(const char* key, int32_t value);
 
@@ -219,6 +221,16 @@ int dinoseg_op_ln_gemm(const float* X, const float* gamma, const float* beta, fl
                        const float* bias, int32_t M, int32_t N, int32_t K, int32_t planes, int32_t epi, void* out_bf16,
                        int64_t out_plane, void* q, void* k, void* v, int64_t qkv_plane, int32_t ntok, int32_t npad,
                        int32_t heads, float qscale, void* a_out, void* aux_out, void* stream);
+
+/* The whole MLP half of a block in one launch (bf16 mode, embed_dim 384, hidden 1536):  X += fc2(gelu(fc1(LayerNorm(X)))),
+ * X fp32 [M, 384] updated in place.  Replaces Block.forward's `x = x + self.mlp(self.norm2(x))` (vision_transformer.py:135 ->
+ * :59-65): LayerNorm2, fc1, exact GELU (fitted form of the bf16 mode), fc2, residual add; the hidden activation stays on chip.
+ * Wp = both weights re-packed in MFMA fragment order by dinoseg_op_pack_mlp (dinoseg_op_mlp_fused_pack_elems(D, F) bf16
+ * elements; 0 = unsupported shape). */
+int64_t dinoseg_op_mlp_fused_pack_elems(int32_t D, int32_t F);
+int dinoseg_op_pack_mlp(const float* W1, const float* W2, int32_t D, int32_t F, void* dst, void* stream);
+int dinoseg_op_mlp_fused(float* X, const float* gamma, const float* beta, float eps, const void* Wp, const float* b1,
+                         const float* b2, int32_t M, int32_t D, int32_t F, void* stream);
 
 /* fused softmax(q k^T) v (vision_transformer.py:85,101,104); q must be pre-scaled by 64^-0.5 * log2(e).
  * q, k, v: [planes][B,heads,npad,64] (rows >= ntok zero); ctx: bf16 planes [planes][B*ntok][heads*64];

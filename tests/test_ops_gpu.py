@@ -432,3 +432,44 @@ def test_ln_gemm_qkv_layout(cuda, planes, B, ntok):
     assert float((gk[:, :, :ntok] - ref[1]).abs().max()) <= tol
     assert float((gv[:, :, :ntok] - ref[2]).abs().max()) <= tol
     assert torch.all(gq[:, :, ntok:] == 0) and torch.all(gk[:, :, ntok:] == 0) and torch.all(gv[:, :, ntok:] == 0)
+
+
+def pack_mlp(W1: torch.Tensor, W2: torch.Tensor) -> torch.Tensor:
+    F_, D_ = W1.shape
+    n = capi.lib().dinoseg_op_mlp_fused_pack_elems(D_, F_)
+    assert n == 2 * D_ * F_
+    out = torch.empty((n,), dtype=torch.int16, device=W1.device)
+    capi.check(capi.lib().dinoseg_op_pack_mlp(W1.contiguous().data_ptr(), W2.contiguous().data_ptr(), D_, F_, out.data_ptr(), S()))
+    return out
+
+
+@pytest.mark.parametrize("M_", [128, 77, 128 * 5 + 33, 128 * 300 + 19])
+def test_mlp_fused(cuda, M_):
+    """LN2 + fc1 + GELU + fc2 + residual in one launch (mlp_fused.hip), bf16 operands: against fp64 on the operands the kernel
+    sees (bf16 LayerNorm output, bf16 weights, bf16 GELU output).  M = 38 419: more items than CUs (persistent walk, the weight
+    ring running on across items), ragged last item; M = 77: one partial item."""
+    D_, F_ = 384, 1536
+    X = seeded((M_, D_), 31) * 1.7 + 0.4 + torch.arange(D_, device="cuda", dtype=torch.float32)[None, :] * 1e-3
+    gam, bet = 1 + 0.2 * seeded((D_,), 32), 0.1 * seeded((D_,), 33)
+    W1 = seeded((F_, D_), 34) * 0.06 + torch.arange(F_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    b1 = seeded((F_,), 35) * 0.5
+    W2 = seeded((D_, F_), 36) * 0.04 + torch.arange(D_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    b2 = seeded((D_,), 37)
+    Wp = pack_mlp(W1, W2)
+    got = X.clone()
+    capi.check(capi.lib().dinoseg_op_mlp_fused(got.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(),
+                                               b2.data_ptr(), M_, D_, F_, S()))
+    torch.cuda.synchronize()
+    A = quant_like(_ln_ref(X, gam, bet).cuda(), 1).double()
+    z = A @ quant_like(W1, 1).double().t() + b1.double()
+    Hq = quant_like(O.gelu_erf(z.float().cpu()).cuda(), 1).double()
+    delta = (Hq @ quant_like(W2, 1).double().t() + b2.double())
+    want = (X.double() + delta).float()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    scale = float(delta.abs().max())
+    # what is left: fp32 summation order, the fitted GELU (2.6e-5), and bf16 rounding points of LN / GELU outputs that the
+    # kernel's own fp32 arithmetic moves by one ulp (each moves one of 1536 products by 2^-8 of itself)
+    assert err <= 2.0 ** -9 * scale + 1e-3, (err, scale)
+    # and the update is not a near-miss of something else: it carries the whole MLP term
+    assert float((got - X).abs().max()) > 0.5 * scale

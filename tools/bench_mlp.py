@@ -1,0 +1,41 @@
+"""GPU box: time the fused MLP operator (mlp_fused.hip) alone: python tools/bench_mlp.py [rows] [iters]
+(DINOSEG_LIB selects the build: tools/ab_ops.sh-style A/B runs of ablation variants)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dino_amd import capi  # noqa: E402
+from tests.gpu_util import seeded  # noqa: E402
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 32 * 3601
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+D, F = 384, 1536
+X = seeded((M, D), 1) * 1.5
+gam, bet = 1 + 0.2 * seeded((D,), 2), 0.1 * seeded((D,), 3)
+W1, b1 = seeded((F, D), 4) * 0.06, seeded((F,), 5) * 0.5
+W2, b2 = seeded((D, F), 6) * 0.002, seeded((D,), 7) * 0.01
+n = capi.lib().dinoseg_op_mlp_fused_pack_elems(D, F)
+Wp = torch.empty((n,), dtype=torch.int16, device="cuda")
+S = capi.stream_ptr
+capi.check(capi.lib().dinoseg_op_pack_mlp(W1.data_ptr(), W2.data_ptr(), D, F, Wp.data_ptr(), S()))
+
+
+def run():
+    capi.check(capi.lib().dinoseg_op_mlp_fused(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(),
+                                               b2.data_ptr(), M, D, F, S()))
+
+
+for _ in range(5):
+    run()
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(iters):
+    run()
+b.record()
+torch.cuda.synchronize()
+us = a.elapsed_time(b) / iters * 1e3
+fl = 2 * 2 * M * D * F
+print(f"mlp_fused M={M}: {us:.1f} us  {fl / us / 1e6:.0f} TFLOP/s  lib={os.path.basename(os.environ.get('DINOSEG_LIB', 'in-tree'))}")
