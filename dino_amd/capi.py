@@ -52,7 +52,6 @@ SIGNATURES = {
     "dinoseg_forward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _fp, _i32, _fp, _vp]),
     "dinoseg_workspace_bytes": (_i64, [_vp, _i32, _i32]),
     "dinoseg_last_selfattention": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _vp]),
-    "dinoseg_op_mfma_peak": (C.c_int, [_i32, _i32, C.c_uint32, _i32, _fp, _fp, _vp]),
     "dinoseg_op_confusion": (C.c_int, [_fp, _fp, _i64, _i32, _fp, _vp]),
     "dinoseg_forward_mask": (C.c_int, [_vp, _vp, _i32, _i32, _fp, _i32, _fp, _fp, _vp]),
     "dinoseg_features": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _fp, _vp]),

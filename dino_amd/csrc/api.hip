@@ -23,7 +23,7 @@ extern "C" void dinoseg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* dinoseg_last_error(void) { return g_err; }
-extern "C" int dinoseg_version(void) { return 300; }      // 2.1: "streams" option, dinoseg_op_mfma_peak, hi+lo persistent GEMM
+extern "C" int dinoseg_version(void) { return 300; }      // 3.0: fused MLP kernel, two streams by default; the measurement kernel moved to libdinoseg_tools.so
 
 int device_cu_count() {
     static std::atomic<int> cache[64];
@@ -708,11 +708,6 @@ extern "C" int dinoseg_op_resize_u8(const uint8_t* src, int32_t sh, int32_t sw, 
 
 extern "C" int dinoseg_op_confusion(const int32_t* pred, const int64_t* gt, int64_t n, int32_t n_classes, int64_t* cm, void* stream) {
     return launch_confusion(pred, gt, n, n_classes, cm, reinterpret_cast<hipStream_t>(stream));
-}
-
-extern "C" int dinoseg_op_mfma_peak(int32_t waves_per_simd, int32_t iters, uint32_t seed, int32_t chains, float* scratch,
-                                    double* flops_out, void* stream) {
-    return launch_mfma_peak(waves_per_simd, iters, seed, chains, scratch, flops_out, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------------------ options

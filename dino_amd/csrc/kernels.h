@@ -88,7 +88,7 @@ struct Options {
     int attn_dbg = 0;        // same for AttnParams::dbg
     int mlp_fused = 1;       // the MLP half of a block as one launch (mlp_fused.hip): 0 never, 1 for >= mlp_fused_min_rows rows, 2 wherever supported
     int mlp_fused_min_rows = 24000;
-    int streams = 1;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
+    int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 16;
     int attn_variant = 11;   // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
                              // tile work; bit 2 (bf16 mode): the software-pipelined kernel (attention_pipe.hip); bit 3 (bf16 mode):
@@ -105,7 +105,6 @@ struct AttnParams {
     int dbg;                           // timing-only ablations: bit0 skip max/exp, bit1 skip steady-state loads, bit2 skip PV
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
-int launch_mfma_peak(int waves_per_simd, int iters, uint32_t seed, int chains, float* out, double* flops, hipStream_t s);   // mfma_peak.hip (measurement)
 int launch_attention_z(const AttnParams& p, hipStream_t s);    // zero-reference softmax, <= 128 registers: 4 waves per SIMD (attention_z.hip)
 int launch_attention_pipe(const AttnParams& p, hipStream_t s); // bf16 only: software-pipelined across tiles (attention_pipe.hip)
 

@@ -128,6 +128,9 @@ class DataParallelFineTuner:
         self.collective = collective
         self.overlap = overlap
         self.group = group
+        # the model's step binds the parameters' .grad to flat buckets of ITS current bucket size: fix that size before the first
+        # step, or the first reduce would build (and reduce) a second, unbound set of buckets
+        model.grad_buckets(bucket_bytes)
         self.torch_opt = None if fused_optimizer else model.configure_optimizers()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -144,12 +147,26 @@ class DataParallelFineTuner:
         w1.wait()        # orders the all-gather behind the reduce-scatter on the current (communication) stream
         return [dist.all_gather_into_tensor(flat, mine, group=self.group, async_op=True)]
 
+    def check_bound(self, buckets) -> None:
+        """The buckets about to be reduced must be the memory the step wrote its gradients into (every parameter's .grad is a
+        view into them): reducing a freshly built, unbound set would silently average zeros."""
+        named = dict(self.model.named_parameters()) if hasattr(self.model, "named_parameters") else {}
+        for b in buckets:
+            lo = b["flat"].data_ptr()
+            hi = lo + b["flat"].numel() * b["flat"].element_size()
+            for name in b["names"]:
+                p = named.get(name)
+                if p is not None and p.requires_grad and (p.grad is None or not lo <= p.grad.data_ptr() < hi):
+                    raise RuntimeError(f"the .grad of '{name}' does not live in the bucket about to be reduced: the step and the "
+                                       f"reduction disagree about the bucket layout (bucket_bytes)")
+
     def reduce_gradients(self) -> None:
         """Sum the gradient buckets over the ranks (the mean's 1/world is applied by the optimiser step)."""
         self.last_collectives = 0
         if self.world == 1:
             return
         buckets = self.model.grad_buckets(self.bucket_bytes)
+        self.check_bound(buckets)
         on_gpu = buckets and buckets[0]["flat"].is_cuda
         works = []
         if on_gpu and self.overlap:

@@ -109,11 +109,6 @@ int dinoseg_op_resize_u8(const uint8_t* src, int32_t sh, int32_t sw, uint8_t* ds
 
 /* Confusion matrix for the validation metrics (validation_epoch_end, pl_torch_modules.py:310-332):
  * cm[gt][pred] += 1 over n patches; cm int64 [n_classes, n_classes] on device (zero it first). */
-/* Measurement only (no reference counterpart): a register-only v_mfma_f32_32x32x16_bf16 loop on waves_per_simd resident waves per
- * SIMD of every CU, `chains` (1, 2, 4) independent accumulator chains per wave, operands all-zero (seed 0) or pseudo-random;
- * *flops_out = FLOPs the launch issues.  tools/mfma_peak.py turns it into the measured dense-bf16 peak SURVEY.md 8d asks for. */
-int dinoseg_op_mfma_peak(int32_t waves_per_simd, int32_t iters, uint32_t seed, int32_t chains, float* scratch, double* flops_out,
-                         void* stream);
 int dinoseg_op_confusion(const int32_t* pred, const int64_t* gt, int64_t n, int32_t n_classes, int64_t* cm, void* stream);
 
 /* ---- fine-tune step (replaces DINOSeg.training_step + autograd + optimizer.step, pl_torch_modules.py:258-268) ---- */
@@ -175,9 +170,10 @@ int dinoseg_profile(dinoseg_handle* h, int32_t level);
 int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
 
 /* Process-wide switches.  Keys:
- *   "streams"    1 [default] / 2: dinoseg_forward runs a batch of >= "split_min" (default 16) frames as two half-batches, the
- *                first on the caller's stream, the second on an internal stream forked from / joined to it by events (the
- *                call stays stream-ordered and capturable; outputs identical; +5 % frames/s at B = 32 on MI355X);
+ *   "streams"    2 [default] / 1: with 2, dinoseg_forward runs a batch of >= "split_min" (default 16) frames as two half-batches,
+ *                the first on the caller's stream, the second on an internal stream forked from / joined to it by events (the
+ *                call stays stream-ordered and capturable; outputs identical; +6 to +9 % frames/s at B = 32 on MI355X: one
+ *                half's attention fills the CUs the other half's GEMM tails and memory phases leave idle); 1 = one stream;
  *   "gemm_big"   1 [default] = the persistent 256x384 (bf16) / 128x384 (bf16x3) GEMM where it applies, 0 = always the 128x128
  *                kernel, 2 = wherever its shape rules allow;
  *   "gemm_ln"    1 [default] = qkv / fc1 through the LayerNorm-fused kernels where measured faster, 0 never, 2 wherever supported;

@@ -369,6 +369,7 @@ def test_two_stream_split_equals_one_stream(cuda, precision, B):
     m, _, _ = build(2, precision)
     m.set_resolution(112)
     frames = torch.from_numpy(synthetic_frames(B, 112, seed=77)).cuda()
+    dino_amd.set_option("streams", 1)                          # the reference: the whole batch on the caller's stream
     lp1, am1 = m.forward_frames(frames)
     lp1, am1 = lp1.clone(), am1.clone()
     small1 = m.forward_frames(frames[:3])[0].clone()
@@ -382,7 +383,7 @@ def test_two_stream_split_equals_one_stream(cuda, precision, B):
         small, _ = m.forward_frames(frames[:3])                # below split_min: the ordinary path
         assert torch.equal(small, small1)
     finally:
-        dino_amd.set_option("streams", 1)
+        dino_amd.set_option("streams", 2)                      # the library default
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-3), ("bf16", 0.35)])
@@ -462,6 +463,7 @@ def test_two_stream_forward_is_graph_capturable(cuda):
     m, _, _ = build(2, "bf16")
     m.set_resolution(112)
     frames = torch.from_numpy(synthetic_frames(16, 112, seed=5)).cuda()
+    dino_amd.set_option("streams", 1)
     ref = m.forward_frames(frames)[0].clone()
     dino_amd.set_option("streams", 2)
     try:
@@ -478,4 +480,4 @@ def test_two_stream_forward_is_graph_capturable(cuda):
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
     finally:
-        dino_amd.set_option("streams", 1)
+        dino_amd.set_option("streams", 2)

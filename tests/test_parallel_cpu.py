@@ -166,3 +166,59 @@ def test_flat_buckets_are_views_in_backward_order():
             assert lo <= v.data_ptr() < hi and v.data_ptr() % 256 == lo % 256 and v.is_contiguous()
     assert DINOSeg.grad_stage("clf.layer_1.weight", 3) == 0 and DINOSeg.grad_stage("dino.blocks.2.mlp.fc1.bias", 3) == 1
     assert DINOSeg.grad_stage("dino.blocks.0.norm1.weight", 3) == 3 and DINOSeg.grad_stage("dino.pos_embed", 3) == 4
+
+
+def test_bench_self_launch_dry_run():
+    """`python bench.py --gpus 2` with no launcher starts its own two ranks (a torch.distributed.run child, before anything touches
+    a GPU), rank 0 prints the one JSON line, every rank is seen by the all-reduce of ones.  --dry-run: no model, gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    for extra in ([], ["--config", "finetune"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"] + extra, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["dry_run"] is True
+    # a failing rank makes the launcher exit non-zero
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--no-such-flag"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+
+
+def test_finetuner_fixes_the_bucket_size_before_the_first_step():
+    """with a non-default bucket_bytes the tuner must make the model build (and bind) buckets of THAT size before the
+    first step, and refuse to reduce buckets the step did not write into."""
+    import torch
+    from dino_amd.parallel import DataParallelFineTuner, make_flat_buckets
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.zeros(1000))
+            self.b = torch.nn.Parameter(torch.zeros(3000))
+            self.asked = []
+            self._bk = None
+
+        def grad_buckets(self, bucket_bytes=8 << 20):
+            self.asked.append(bucket_bytes)
+            if self._bk is None or self._bk[0] != bucket_bytes:
+                self._bk = (bucket_bytes, make_flat_buckets(list(self.named_parameters()), None, bucket_bytes))
+            return self._bk[1]["buckets"]
+
+        def bind(self):
+            for n, p in self.named_parameters():
+                p.grad = self._bk[1]["views"][n]
+
+    m = Model()
+    t = DataParallelFineTuner(m, fused_optimizer=True, bucket_bytes=8 << 10)
+    assert m.asked == [8 << 10] and len(m.grad_buckets(8 << 10)) == 2
+    m.bind()
+    t.check_bound(m.grad_buckets(8 << 10))
+    stale = make_flat_buckets(list(m.named_parameters()), None, 8 << 20)["buckets"]      # a second, unbound set
+    with pytest.raises(RuntimeError):
+        t.check_bound(stale)

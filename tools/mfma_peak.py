@@ -12,7 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from dino_amd import capi  # noqa: E402
 
-lib = capi.lib()
+lib = C.CDLL(os.path.join(os.path.dirname(capi.LIB_PATH), "libdinoseg_tools.so"))      # make -C dino_amd/csrc tools
+lib.dinoseg_tools_mfma_peak.restype = C.c_int
+lib.dinoseg_tools_mfma_peak.argtypes = [C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
 scratch = torch.zeros(16, device="cuda")
 flops = C.c_double(0.0)
 ITERS = int(os.environ.get("MFMA_ITERS", "20000"))
@@ -20,7 +22,8 @@ ITERS = int(os.environ.get("MFMA_ITERS", "20000"))
 
 def run(wps, seed, chains):
     def f():
-        capi.check(lib.dinoseg_op_mfma_peak(wps, ITERS, seed, chains, scratch.data_ptr(), C.addressof(flops), capi.stream_ptr()))
+        rc = lib.dinoseg_tools_mfma_peak(wps, ITERS, seed, chains, scratch.data_ptr(), C.addressof(flops), capi.stream_ptr())
+        assert rc == 0, rc
     for _ in range(2):
         f()
     torch.cuda.synchronize()
@@ -38,11 +41,12 @@ print(f"{'waves/SIMD':>10} {'mode':>22} {'operands':>9} {'TFLOP/s':>9} {'of 2500
 ONLY = os.environ.get("MFMA_MODES")
 MODES = [(4, "4 chains"), (1, "1 chain")] + [(100 + n, f"+{n} VALU / 4 MFMA") for n in (8, 16, 32)] + \
         [(200 + n, f"+{n} SALU / 4 MFMA") for n in (8, 16, 32)] + [(300 + n, f"+{n} s_nop / 4 MFMA") for n in (16, 32)] + \
-        [(400 + n, f"+{n} s_waitcnt / 4 MFMA") for n in (16, 32)]
+        [(400 + n, f"+{n} s_waitcnt / 4 MFMA") for n in (16, 32)] + \
+        [(500, "32x32x16 regs (ctl)"), (504, "16x16x32 regs"), (604, "32x32x16 LDS-fed"), (704, "16x16x32 LDS-fed")]
 if ONLY:
     MODES = [m for m in MODES if str(m[0]) in ONLY.split(",")]
 for chains, label in MODES:
     for wps in (1, 2, 3, 4, 8):
-        for seed, name in ((0, "zero"), (7, "random")) if chains < 100 else ((0, "zero"),):
+        for seed, name in ((0, "zero"), (7, "random")) if (chains < 100 or chains >= 500) else ((0, "zero"),):
             tf, ms = run(wps, seed, chains)
             print(f"{wps:>10} {label:>22} {name:>9} {tf:9.1f} {tf / 2500:8.3f} {ms:8.2f}", flush=True)
