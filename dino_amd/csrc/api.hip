@@ -174,6 +174,17 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
                 if (h->pos_cache) (void)hipFree(h->pos_cache);
                 release_workspaces(h);
                 (void)dinoseg_train_release(h);
+                // events belong to the device they were created on: the gradient-stage and profiler events too
+                for (auto& e : h->stage_ev) (void)hipEventDestroy(e);
+                h->stage_ev.clear();
+                h->stage_done = 0;
+                for (auto& r : h->prof_recs) {
+                    (void)hipEventDestroy(r.a);
+                    (void)hipEventDestroy(r.b);
+                }
+                h->prof_recs.clear();
+                for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
+                h->prof_pool.clear();
                 h->wbuf = nullptr; h->pos_cache = nullptr;
                 h->wbuf_bytes = h->pos_cap = 0;
                 h->tws_B = h->tws_r = h->tr_B = -1;

@@ -423,6 +423,7 @@ static int launch_bwd(const AttnBwdParams& p, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
         DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<PLANES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
+        once.mark();
     }
     const long rows = (long)p.B * p.heads * p.npad;
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p.dO, p.O, p.dO_plane, PLANES,

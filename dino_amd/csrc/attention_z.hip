@@ -9,7 +9,7 @@
 //     exponent range) hold 2^S for |S| < 126, i.e. raw logits up to +-87 * 8 / 1.44 -- far outside anything a trained ViT
 //     produces -- so the score accumulators start from the inline constant 0 (no 16-register -m_run operand), there is no
 //     per-tile overflow check, no rescale path in the loop;
-//   * a row whose sum overflowed (inf / NaN) or vanished (every 2^S flushed to 0) is detected ONCE, after the last tile; the
+//   * a row whose sum left the band [2^-60, 2^60] (overflow of a 2^S or of the O accumulators, or underflow) is detected ONCE, after the last tile; the
 //     workgroup then recomputes exactly: one pass for the row maxima (scores only), one pass with S - max subtracted on the
 //     VALU (32 extra v_sub per tile, only on this path).  Hit only by adversarial inputs (tests force it);
 //   * the K fragments of a tile are read in two windows of four (16 registers instead of 32).
@@ -243,9 +243,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_z_kernel(AttnParams p) 
     pass(std::integral_constant<int, 0>{});
     float l_tot = l_run + __shfl_xor(l_run, 32);
     {
-        // a sum that is inf / NaN (some 2^S overflowed) or 0 (all of them flushed) cannot be normalised: exact recomputation for
-        // the whole workgroup (the tile loop is workgroup-synchronous)
-        const bool bad = wave_active && qrow < ntok && !(l_tot > 0.f && l_tot < INFINITY);
+        // Exact recomputation for the whole workgroup (the tile loop is workgroup-synchronous) unless every row sum lies in a safe band
+        // [2^-60, 2^60]: outside it a 2^S may have overflowed (also in the O accumulators: sum of P V reaches 2^128 before l does
+        // when |V| > 1; a P in [2^127.99, 2^128) rounds to bf16 inf) or the row's large terms may sit in the flushed range of
+        // v_exp (row maximum below ~-100: l stays > 0 but has lost entries).  The band costs the fast path nothing.
+        const bool bad = wave_active && qrow < ntok && !(l_tot >= 0x1p-60f && l_tot <= 0x1p60f);
         if (__any(bad) && lane == 0) *redo_flag = 1;
         __syncthreads();                   // also: everyone is done reading the last tile
         if (__builtin_amdgcn_readfirstlane(*redo_flag) != 0) {             // workgroup-uniform (and uniform for the compiler)

@@ -124,11 +124,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 struct PerDeviceOnce {
     std::atomic<bool> done[64];
     PerDeviceOnce() { for (auto& d : done) d.store(false); }
-    // true exactly once per device (callers then do the per-device setup); devices beyond the table always set up again
+    // true until the per-device setup has been marked done (callers do the setup, then call mark()): two host threads may both do
+    // it -- hipFuncSetAttribute is idempotent -- but none launches before its own setup call has returned.  Devices beyond the
+    // table always set up again.
     bool first() {
         int d = 0;
         if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
-        return !done[d].exchange(true);
+        return !done[d].load(std::memory_order_acquire);
+    }
+    void mark() {
+        int d = 0;
+        if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) done[d].store(true, std::memory_order_release);
     }
 };
 extern "C" void dinoseg_set_error(const char* fmt, ...);

@@ -256,9 +256,11 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     const int grid = ((nbm + 7) / 8) * 8 * nbn;
     const size_t lds = (size_t)PLANES * 2 * 2 * TILE_BYTES;
     static PerDeviceOnce once;
-    if (once.first())
+    if (once.first()) {
         DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<PLANES, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.mark();
+    }
     hipLaunchKernelGGL((gemm_nt_kernel<PLANES, EPI>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3(256), lds, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;

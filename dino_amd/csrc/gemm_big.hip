@@ -381,9 +381,11 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
 template <int EPI, class C>
 static int launch_big_cfg(const GemmParams& p, hipStream_t s) {
     static PerDeviceOnce once;
-    if (once.first())
+    if (once.first()) {
         DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<EPI, C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        once.mark();
+    }
     const int ncu = device_cu_count();
     if (ncu <= 0) return -2;
     const int nbn = p.N / C::BN, nbm = (p.M + C::BM - 1) / C::BM;

@@ -535,6 +535,7 @@ static int launch_ln_cfg(const LnGemmParams& p, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_kernel<EPI, C, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        once.mark();
     }
     const int ncu = device_cu_count();
     if (ncu <= 0) return -2;

@@ -426,6 +426,7 @@ static int launch_ln12(const LnGemmParams& p, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ln12::LDS_BYTES));
         DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln12_kernel<EPI, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ln12::LDS_BYTES));
+        once.mark();
     }
     const int ncu = device_cu_count();
     if (ncu <= 0) return -2;

@@ -189,9 +189,11 @@ int launch_gemm_tn(const TnParams& p, hipStream_t s) {
         hipLaunchKernelGGL(gemm_tn_kernel<1>, dim3(tiles, p.ksplit), dim3(256), lds, s, p);
     } else {
         static PerDeviceOnce once;
-        if (once.first())
-            DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<2>),
+        if (once.first()) {
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<2>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.mark();
+    }
         hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(tiles, p.ksplit), dim3(256), lds, s, p);
     }
     DSEG_CHECK_HIP(hipGetLastError());

@@ -63,6 +63,8 @@ struct dinoseg_handle {
     size_t tws_bytes = 0;
     int tws_B = -1, tws_r = -1;
     int tr_B = -1, tr_r = -1;              // batch / resolution of the saved forward dinoseg_backward will differentiate
+    int* bad_label_flag = nullptr;         // sticky "a label outside [0, C) other than -100 was seen" (device int, owned by the handle:
+                                           // it must survive the training workspace being re-laid out for another batch shape)
     // gradient-stage events of the last backward (dinoseg_stream_wait_grad_stage): stage 0 = head, 1 + k = final norm and block
     // n_blocks-1-k, n_blocks + 1 = embeddings; stage_done = number of stages the last backward recorded
     std::vector<hipEvent_t> stage_ev;

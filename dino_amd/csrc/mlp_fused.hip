@@ -488,9 +488,11 @@ bool mlp_fused_supported(int Dm, int Fh, int planes) { return Dm == mf::D && Fh 
 
 int launch_mlp_fused(const MlpFusedParams& p, hipStream_t s) {
     static PerDeviceOnce once;
-    if (once.first())
+    if (once.first()) {
         DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            mf::LDS_BYTES));
+        once.mark();
+    }
     if (p.M <= 0 || p.ldx < mf::D || (p.ldx & 3)) {
         dinoseg_set_error("mlp_fused: bad shape M=%d ldx=%d", p.M, p.ldx);
         return -1;

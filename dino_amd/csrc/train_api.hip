@@ -95,7 +95,7 @@ TrainLayout make_train_layout(const dinoseg_handle* h, int B, int r) {
     L.NDEL = take((size_t)B * c.num_heads * L.npad * 4);
     L.DPOS = take((size_t)L.ntok * D * 4);
     L.SINK = take((size_t)4 * 1024 * 4);
-    L.ACC = take(256);        // nll_loss accumulators {sum of -logp[y], valid rows} + sticky bad-label flag (int at +128)
+    L.ACC = take(256);        // nll_loss accumulators {sum of -logp[y], valid rows} (the sticky bad-label flag lives in the handle)
     L.SPLITK = take((size_t)SPLITK_TILES * 128 * 128 * 4);     // split-K partial tiles of the weight gradients
     L.total = off;
     return L;
@@ -137,6 +137,8 @@ struct TW {
 int dinoseg_train_release(dinoseg_handle* h) {
     if (h->tws) (void)hipFree(h->tws);
     if (h->twbuf) (void)hipFree(h->twbuf);
+    if (h->bad_label_flag) (void)hipFree(h->bad_label_flag);
+    h->bad_label_flag = nullptr;
     h->tws = nullptr;
     h->twbuf = nullptr;
     h->tws_bytes = h->twbuf_bytes = 0;
@@ -236,6 +238,10 @@ static int train_forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, 
     const TrainLayout L = make_train_layout(h, B, r);
 
     // ---- workspace
+    if (!h->bad_label_flag) {       // (its own allocation: a change of batch shape re-lays the workspace, the latched flag must survive it)
+        DSEG_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&h->bad_label_flag), 256));
+        DSEG_CHECK_HIP(hipMemsetAsync(h->bad_label_flag, 0, 256, s));
+    }
     if (L.total > h->tws_bytes) {
         if (h->tws) {
             DSEG_CHECK_HIP(hipStreamSynchronize(s));
@@ -554,7 +560,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
     };
 
     // ---- loss and d logits (pl_torch_modules.py:264-265)
-    DSEG_TRY(launch_nll_loss_grad(LOGP, labels, dlogp, L.Mp, C, F32(L.ACC), reinterpret_cast<int*>(ws + L.ACC + 128), loss_out, DZ,
+    DSEG_TRY(launch_nll_loss_grad(LOGP, labels, dlogp, L.Mp, C, F32(L.ACC), h->bad_label_flag, loss_out, DZ,
                                   L.dz_plane, 64, s));
     const long tpl = L.t_plane;
     float* dX = F32(L.dX);
@@ -708,14 +714,13 @@ extern "C" int dinoseg_train_status(dinoseg_handle* h, int32_t* bad_labels, void
         return -1;
     }
     *bad_labels = 0;
-    if (!h->tws || h->tws_B < 0) return 0;
+    if (!h->bad_label_flag) return 0;
     DeviceGuard guard(h);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const TrainLayout L = make_train_layout(h, h->tws_B, h->tws_r);
     int flag = 0;
-    DSEG_CHECK_HIP(hipMemcpyAsync(&flag, h->tws + L.ACC + 128, sizeof(int), hipMemcpyDeviceToHost, s));
+    DSEG_CHECK_HIP(hipMemcpyAsync(&flag, h->bad_label_flag, sizeof(int), hipMemcpyDeviceToHost, s));
     DSEG_CHECK_HIP(hipStreamSynchronize(s));
-    if (flag) DSEG_CHECK_HIP(hipMemsetAsync(h->tws + L.ACC + 128, 0, sizeof(int), s));
+    if (flag) DSEG_CHECK_HIP(hipMemsetAsync(h->bad_label_flag, 0, sizeof(int), s));
     *bad_labels = flag;
     return 0;
 }

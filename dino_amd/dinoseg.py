@@ -150,9 +150,13 @@ class _ViTParams(nn.Module):
 
     def forward(self, x: torch.Tensor, all: bool = True, intermediate=False) -> torch.Tensor:
         """VisionTransformer.forward (vision_transformer.py:237-248): fp32 [B,3,r,r] -> final-norm tokens [B, N, D]
-        (``all=False``: the CLS row [B, D]); ``intermediate=k`` stops after block k."""
-        t = self._owner().features(x, n_blocks=int(intermediate) if intermediate else 0)
-        return t if all else t[:, 0]
+        (``all=False``: the CLS row [B, D]); ``intermediate=k`` returns ``norm(x)`` of ALL tokens after block k, whatever ``all``
+        says (:241-242) -- unless k is past the last block, where the loop never exits early and ``all`` applies (:243-248)."""
+        owner = self._owner()
+        k = int(intermediate) if intermediate else 0
+        early = 0 < k <= owner.n_blocks
+        t = owner.features(x, n_blocks=k if early else 0)
+        return t if (all or early) else t[:, 0]
 
     def get_last_selfattention(self, x, cls_mask=None):
         """vision_transformer.py:273-280; reference call site visualize_attention.py:46."""

@@ -155,6 +155,23 @@ def g4():
          argmax=lp.argmax(1).numpy().astype(np.uint8), margin=margins(lp))
 
 
+# ----------------------------------------------------------------------------- G13 ViT-S/8 L=12 @960 (BASELINE configs[2] depth)
+def g13():
+    """The headline depth at 960x960 (14 401 tokens: the reference materialises a 6 x 14401^2 fp32 attention matrix per block,
+    ~5 GB; twelve blocks run one after the other).  256 sampled rows of log-probabilities + the whole argmax map."""
+    r, L = 960, 12
+    frames = synthetic_frames(1, r, seed=4)
+    cfg = ViTConfig(n_blocks=L)
+    sd = procedural_state_dict(cfg)
+    vit, head = ref_vit(cfg, sd), TorchHead(cfg, sd)
+    with torch.no_grad():
+        lp = ref_logp(vit, head, preprocess_np(frames))
+    rows = np.random.default_rng(45).choice(lp.shape[0], 256, replace=False).astype(np.int64)
+    rows.sort()
+    save("g4_vits8_L12_r960", frame_seed=np.int64(4), rows=rows, logp_rows=lp[rows].numpy(),
+         argmax=lp.argmax(1).numpy().astype(np.uint8), margin=margins(lp))
+
+
 # ----------------------------------------------------------------------------- G5 predict() maps
 def g5():
     out = {}
@@ -429,7 +446,7 @@ def g12():
     save("g12_finetune_r480_ignore", **{k.replace("/", "|"): v for k, v in out.items()})
 
 
-ALL = {"G12": g12, "G11": g11, "G10": g10, "G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
+ALL = {"G13": g13, "G12": g12, "G11": g11, "G10": g10, "G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -64,32 +64,61 @@ def test_g3_vits8_480_parity_mode(cuda, golden_dir, L):
     assert flips == 0
 
 
+@pytest.mark.parametrize("mlp_fused", [0, 2])
 @pytest.mark.parametrize("L", [1, 12])
-def test_g3_vits8_480_bf16_mode_is_bounded(cuda, golden_dir, L):
-    """Benchmark mode: plain bf16 operands.  Not the parity mode -- bounded and reported, not 1e-3."""
+def test_g3_vits8_480_bf16_mode_is_bounded(cuda, golden_dir, L, mlp_fused):
+    """Benchmark mode: plain bf16 operands.  Not the parity mode -- bounded and reported, not 1e-3.  The bounds are 1.5x what is
+    measured (max |dlogp| 0.125-0.135, 15-24 flips of 3600 = 0.4-0.7 %, on both routes of the MLP: separate kernels and the fused
+    kernel, which a single frame only takes when forced): a 2x numerical regression of the mode fails here."""
+    import dino_amd
     g = load(golden_dir, f"g3_vits8_L{L}_r480")
     m, _, _ = build(L, "bf16")
     frames = torch.from_numpy(synthetic_frames(1, 480, seed=int(g["frame_seed"]))).cuda()
-    lp, am = m.forward_frames(frames)
+    dino_amd.set_option("mlp_fused", mlp_fused)
+    try:
+        lp, am = m.forward_frames(frames)
+    finally:
+        dino_amd.set_option("mlp_fused", 1)
     err = float((lp.cpu() - torch.from_numpy(g["logp"])).abs().max())
     differ = am.cpu().numpy() != g["argmax"].astype(np.int32)
-    print(f"L={L} bf16 mode: max|dlogp|={err:.3e} flips={int(differ.sum())}/3600")
-    assert err <= 0.35
-    assert differ.mean() <= 0.03
+    print(f"L={L} bf16 mode (mlp_fused={mlp_fused}): max|dlogp|={err:.3e} flips={int(differ.sum())}/3600")
+    assert err <= 0.2
+    assert differ.mean() <= 0.01
     assert np.all(g["margin"][differ] <= 2 * err)      # only near-ties move
 
 
-def test_g4_vits8_960(cuda, golden_dir):
-    g = load(golden_dir, "g4_vits8_L3_r960")
-    m, _, _ = build(3, "bf16x3")
+@pytest.mark.parametrize("L", [3, 12])
+def test_g4_vits8_960(cuda, golden_dir, L):
+    """BASELINE configs[2]'s resolution (14 401 tokens), at the shipped depth 3 and at the headline depth 12 (fixture G13): parity
+    mode against the reference's log-probabilities (256 sampled rows) and its whole argmax map."""
+    g = load(golden_dir, f"g4_vits8_L{L}_r960")
+    m, _, _ = build(L, "bf16x3")
     m.set_resolution(960)
     frames = torch.from_numpy(synthetic_frames(1, 960, seed=int(g["frame_seed"]))).cuda()
     lp, am = m.forward_frames(frames)
     rows = torch.from_numpy(g["rows"])
     err = float((lp.cpu()[rows] - torch.from_numpy(g["logp_rows"])).abs().max())
     flips = int((am.cpu().numpy() != g["argmax"].astype(np.int32)).sum())
-    print(f"960: max|dlogp|={err:.3e} flips={flips}/14400")
+    print(f"960 L={L}: max|dlogp|={err:.3e} flips={flips}/14400")
     assert err <= TOL and flips == 0
+
+
+def test_g4_vits8_960_L12_bf16_mode_is_bounded(cuda, golden_dir):
+    """The benchmark mode at 960x960, 12 blocks, as a batch of 8 (the shape `bench.py --config 960` times: fused MLP, persistent
+    GEMMs): bounded against the reference fixture like its 480x480 sibling, every copy of the frame identical."""
+    g = load(golden_dir, "g4_vits8_L12_r960")
+    m, _, _ = build(12, "bf16")
+    m.set_resolution(960)
+    frame = torch.from_numpy(synthetic_frames(1, 960, seed=int(g["frame_seed"]))).cuda()
+    lp, am = m.forward_frames(frame.expand(8, *frame.shape[1:]).contiguous())
+    lp, am = lp.reshape(8, 14400, -1), am.reshape(8, 14400)
+    assert bool((lp == lp[:1]).all()) and bool((am == am[:1]).all())
+    rows = torch.from_numpy(g["rows"])
+    err = float((lp[7].cpu()[rows] - torch.from_numpy(g["logp_rows"])).abs().max())
+    differ = am[7].cpu().numpy() != g["argmax"].astype(np.int32)
+    print(f"960 L=12 bf16 B=8: max|dlogp|={err:.3e} flips={int(differ.sum())}/14400")
+    assert err <= 0.2 and differ.mean() <= 0.01
+    assert np.all(g["margin"][differ] <= 0.5)
 
 
 def test_g5_predict_maps(cuda, golden_dir):
@@ -306,8 +335,12 @@ def test_dino_backbone_is_callable(cuda, golden_dir):
         t = O.block(t, W, 0, TINY.num_heads, 1e-6)
         want = O.layer_norm(t, W["dino.norm.weight"], W["dino.norm.bias"], 1e-6)
     assert float((m.dino(x, intermediate=1).cpu() - want).abs().max()) <= 5e-4
-    with pytest.raises(ValueError):
-        m.dino(x, intermediate=5)
+    # the early exit returns norm(x) of ALL tokens whatever `all` says (:241-242) ...
+    early = m.dino(x, all=False, intermediate=1)
+    assert tuple(early.shape) == (2, 65, 128) and float((early.cpu() - want).abs().max()) <= 5e-4
+    # ... and an `intermediate` past the last block never exits early: the full depth, and `all` applies (:243-248)
+    assert torch.equal(m.dino(x, intermediate=5), tok)
+    assert torch.equal(m.dino(x, all=False, intermediate=5), tok[:, 0])
 
 
 def test_model_copies_and_pickles_without_the_native_handle(cuda, tmp_path):
@@ -335,7 +368,7 @@ def test_model_copies_and_pickles_without_the_native_handle(cuda, tmp_path):
     assert not torch.equal(m.forward_frames(frames)[0], lp)
 
 
-@pytest.mark.parametrize("precision,tol,flip_frac", [("bf16x3", 1e-3, 0.0), ("bf16", 0.35, 0.03)])
+@pytest.mark.parametrize("precision,tol,flip_frac", [("bf16x3", 1e-3, 0.0), ("bf16", 0.15, 0.01)])
 def test_g4_960_batch8_frames_are_independent(cuda, precision, tol, flip_frac):
     """@960 (14 401 tokens) at the BASELINE batch of 8: every frame of the batch gets what it gets alone (frames are independent:
     pl_torch_modules.py:253 flattens them) up to the GEMM dispatch -- batch 1 and batch 8 take different tile shapes = different
@@ -411,29 +444,32 @@ def test_linear_dispatch_paths_agree(cuda, precision, tol):
         assert float((v - ref).abs().max()) <= tol, k
 
 
-def _outlier_state(sd, cfg):
+def _outlier_state(sd, cfg, chan=40.0, head=5.0):
     """Procedural weights with the two features of trained DINO checkpoints that uniform synthetic weights lack: a few residual
-    channels two orders of magnitude above the rest ("massive activations": three output channels of block 0's fc2 scaled x40)
-    and one sharp attention head (its q and k rows of block 1 scaled x5: logits x25, past 2^126 in the log2 domain for some rows)."""
+    channels two orders of magnitude above the rest ("massive activations": three output channels of block 0's fc2 scaled x chan)
+    and one sharp attention head (its q and k rows of block 1 scaled x head: logits x head^2, past 2^126 in the log2 domain for
+    some rows)."""
     sd = {k: v.copy() for k, v in sd.items()}
     D, dh = cfg.embed_dim, 64
     for c in (7, 129, 300):
-        sd["dino.blocks.0.mlp.fc2.weight"][c] *= 40.0
-        sd["dino.blocks.0.mlp.fc2.bias"][c] *= 40.0
+        sd["dino.blocks.0.mlp.fc2.weight"][c] *= chan
+        sd["dino.blocks.0.mlp.fc2.bias"][c] *= chan
     w, b = sd["dino.blocks.1.attn.qkv.weight"], sd["dino.blocks.1.attn.qkv.bias"]
     for base in (0, D):                       # q rows and k rows of head 2
-        w[base + 2 * dh: base + 3 * dh] *= 5.0
-        b[base + 2 * dh: base + 3 * dh] *= 5.0
+        w[base + 2 * dh: base + 3 * dh] *= head
+        b[base + 2 * dh: base + 3 * dh] *= head
     return sd
 
 
+@pytest.mark.parametrize("chan,head", [(40.0, 5.0), (100.0, 8.0)])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
-def test_outlier_channels_and_sharp_heads(cuda, precision):
-    """Against the CPU oracle (fp32, same op order as the reference) on weights with outlier channels and a sharp head: the parity
-    mode holds its bar where the probabilities are not degenerate, the bf16 mode stays finite and close; the sharp head drives
-    scores past the zero-reference attention kernel's fast range, so its exact recomputation runs inside a real forward."""
+def test_outlier_channels_and_sharp_heads(cuda, precision, chan, head):
+    """Against the CPU oracle (fp32, same op order as the reference) on weights with outlier channels and a sharp head, at two
+    severities (x40 channels / x5 head; x100 / x8): the parity mode holds the north-star bar (1e-3, argmax identical outside
+    genuine ties), the bf16 mode stays finite and close; the sharp head drives scores past the zero-reference attention kernel's
+    fast range, so its exact recomputation runs inside a real forward."""
     cfg = ViTConfig(n_blocks=3)
-    sd = _outlier_state(procedural_state_dict(cfg), cfg)
+    sd = _outlier_state(procedural_state_dict(cfg), cfg, chan, head)
     m = DINOSeg(head=cfg.head, n_blocks=cfg.n_blocks, n_classes=cfg.n_classes, precision=precision, arch=cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     m.to("cuda:0")
@@ -448,12 +484,23 @@ def test_outlier_channels_and_sharp_heads(cuda, precision):
     flips = am != ref.argmax(1)
     top2 = ref.topk(2, dim=1).values
     margin = top2[:, 0] - top2[:, 1]
-    print(f"outliers {precision}: max|dlogp| {err:.3e}, flips {int(flips.sum())} / {flips.numel()}")
+    # the input's own conditioning: the same graph evaluated in fp64 against the fp32 oracle (= the reference's arithmetic).  On the
+    # plain procedural weights the two differ by 2.8e-5; with these outliers by 1.0e-4 (x40 / x5) and 1.3e-4 (x100 / x8): fp32
+    # rounding (6e-8) comes out amplified ~2000x, and oracle/precision_ablation.py's forward with these weights shows no operand
+    # slot whose exact evaluation lowers the split mode's error -- near-tied keys of the sharp head trade places.
+    with torch.no_grad():
+        ref64 = O.dinoseg_forward(O.preprocess(frames).double(), {k: v.double() for k, v in O.to_torch(sd).items()}, cfg.num_heads)
+    gap = float((ref.double() - ref64).abs().max())
+    print(f"outliers x{chan:g} / x{head:g} {precision}: max|dlogp| {err:.3e}, flips {int(flips.sum())} / {flips.numel()}, "
+          f"fp32-vs-fp64 oracle {gap:.2e}")
     if precision == "bf16x3":
-        assert err <= 2e-3
-        assert not bool((flips & (margin > 4e-3)).any())       # only genuine ties may flip
+        # the north-star bar at the severity round 2 tested (measured 9.9e-4); at x100 / x8 widened by four times the reference's
+        # own fp32 noise on this input (bar 1.52e-3, measured 1.36e-3)
+        assert err <= (1e-3 if chan <= 40.0 else 1e-3 + 4 * gap)
+        assert not bool((flips & (margin > 2e-3)).any())       # only genuine ties may flip
     else:
-        assert err <= 0.6 and float(flips.float().mean()) <= 0.05
+        # measured 0.47 / 2 flips and 1.64 / 3 flips of 392: bounds at 1.5x
+        assert err <= (0.7 if chan <= 40.0 else 2.5) and float(flips.float().mean()) <= 0.02
 
 
 def test_two_stream_forward_is_graph_capturable(cuda):

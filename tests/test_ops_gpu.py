@@ -122,12 +122,17 @@ def _attention_case(B, H, ntok, planes, seed, spike=False):
     if spike:   # force the online-softmax rescale late in the sweep: one key dominates one query row
         # (True: log2-domain score ~104, still a finite 2^S; "over": ~208, 2^S overflows fp32 -> the zero-reference kernel's
         #  exact recomputation; "under": every score of row 7 below -126, every 2^S flushes to 0 -> same path)
-        K[:, :, ntok - 3] = Q[:, :, 5] * (8.0 if spike == "over" else 4.0)
-        if spike == "under":
+        #  "bigv": score ~122 with |V| ~ 1000: the row sum stays finite (2^122) while sum(P V) passes 2^128 -> only the safe band
+        #  on the row sum [2^-60, 2^60] sends the row to the exact path; "lowmax": row 7's scores around -117 +- 7: the sum stays
+        #  > 0 but its entries below -126 are flushed by v_exp -> same band)
+        K[:, :, ntok - 3] = Q[:, :, 5] * {"over": 8.0, "bigv": 4.7}.get(spike, 4.0)
+        if spike == "bigv":
+            V = V * 1000.0
+        if spike in ("under", "lowmax"):
             u = torch.zeros(64)
             u[3] = 1.0
-            Q[:, :, 7] = 30.0 * u
-            K = K - 30.0 * u
+            Q[:, :, 7] = (30.0 if spike == "under" else 25.0) * u
+            K = K - (30.0 if spike == "under" else 24.5) * u
     qs = Q * (0.125 * LOG2E)
 
     def planes_of(x, shape_pad):
@@ -169,7 +174,7 @@ def test_attention(cuda, planes, B, H, ntok):
 
 
 @pytest.mark.parametrize("planes", [1, 2])
-@pytest.mark.parametrize("spike", [True, "over", "under"])
+@pytest.mark.parametrize("spike", [True, "over", "under", "bigv", "lowmax"])
 def test_attention_rescale_branch(cuda, planes, spike):
     """One key dominating a row late in the sweep (the reference-moving path of the online-softmax kernels), scores whose 2^S
     overflows fp32 and a row whose 2^S all flush to zero (the exact two-pass recomputation of the zero-reference kernel).
@@ -177,9 +182,11 @@ def test_attention_rescale_branch(cuda, planes, spike):
     kernel whose reference is the row maximum has it exactly 1."""
     got, ref, lse, ref_lse = _attention_case(1, 1, 300, planes, seed=77, spike=spike)
     assert torch.isfinite(got).all() and torch.isfinite(lse).all()
-    # ("under" multiplies operands of magnitude 30: the dropped lo*lo term of the hi+lo products is 2^-18 of scores of ~900)
-    tol2 = 5e-3 if spike == "under" else 1e-4
-    assert float((got - ref).abs().max()) <= (2e-2 if planes == 1 else tol2)
+    # ("under" / "lowmax" multiply operands of magnitude 25-30: the dropped lo*lo term of the hi+lo products is 2^-18 of scores of
+    #  ~600-900; "bigv" scales the outputs by 1000)
+    tol2 = 5e-3 if spike in ("under", "lowmax") else 1e-4
+    vs = 1000.0 if spike == "bigv" else 1.0
+    assert float((got - ref).abs().max()) <= (2e-2 if planes == 1 else tol2) * vs
     assert float((lse - ref_lse).abs().max()) <= (6e-3 if planes == 1 else 50 * tol2)
 
 

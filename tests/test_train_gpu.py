@@ -323,3 +323,25 @@ def test_unsupported_optimizer_raises_and_per_parameter_steps(cuda):
     big = g.abs() > 0.1 * g.abs().mean()
     assert float((d[big].abs() - 1e-3).abs().max()) <= 2e-5      # |update| = lr at step 1; the shared-step bug gave ~0.55 lr
     assert m2._adam_state["clf.layer_1.weight"]["step"] == 2 and m2._adam_state["dino.blocks.0.mlp.fc1.weight"]["step"] == 1
+
+
+def test_bad_label_flag_survives_a_change_of_batch_shape(cuda):
+    """F.nll_loss raises for a label outside [0, C) that is not -100; here the row is skipped on device and the flag is latched
+    until check_labels() (fit() calls it once per epoch).  A short last batch re-lays the training workspace: the latched flag
+    must survive that (it lives in its own allocation)."""
+    cfg = TINY
+    sd = procedural_state_dict(cfg)
+    m = DINOSeg(head=cfg.head, n_blocks=cfg.n_blocks, n_classes=cfg.n_classes, precision="bf16x3", arch=cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m.to("cuda:0")
+    m.unfreeze_bb()
+    n = (64 // 8) ** 2
+    x2 = torch.from_numpy(synthetic_frames(2, 64, seed=3)).cuda()
+    y2 = torch.from_numpy(synthetic_labels(2, n, cfg.n_classes, seed=4)).cuda()
+    y2[1, 5] = cfg.n_classes + 3                      # out of range
+    m.fused_training_step((x2, y2))
+    y1 = torch.from_numpy(synthetic_labels(1, n, cfg.n_classes, seed=5)).cuda()
+    m.fused_training_step((x2[:1], y1))               # clean, other batch shape
+    with pytest.raises(IndexError):
+        m.check_labels()
+    m.check_labels()                                  # reported once, then cleared
