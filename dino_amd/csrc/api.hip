@@ -564,7 +564,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.X = X; g.ldx = D; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
             g.Wp = h->packed_mlp.at(b); g.b1 = W(h, b + "mlp.fc1.bias"); g.b2 = W(h, b + "mlp.fc2.bias");
             g.M = L.M;
-            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_mlp_fused(g, s)));
+            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(options().mlp_variant == 1 ? launch_mlp_fused(g, s) : launch_mlp_fused2(g, s)));
         } else {
         if (fuse_ln && h->packed_slab.count(b + "mlp.fc1.weight") && L.hb_plane < (1L << 31)) {
             LnGemmParams g = {};
@@ -747,6 +747,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().mlp_fused = value;
         return 0;
     }
+    if (strcmp(key, "mlp_variant") == 0) {
+        dseg::options().mlp_variant = value;
+        return 0;
+    }
     if (strcmp(key, "mlp_fused_min_rows") == 0) {
         dseg::options().mlp_fused_min_rows = value;
         return 0;
@@ -863,7 +867,8 @@ extern "C" int dinoseg_op_mlp_fused(float* X, const float* gamma, const float* b
     MlpFusedParams g = {};
     g.X = X; g.ldx = D; g.gamma = gamma; g.beta = beta; g.eps = eps;
     g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
-    return launch_mlp_fused(g, reinterpret_cast<hipStream_t>(stream));
+    return options().mlp_variant == 1 ? launch_mlp_fused(g, reinterpret_cast<hipStream_t>(stream))
+                                      : launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t dinoseg_op_ln_gemm_slab_elems(int32_t N, int32_t K, int32_t planes) {

@@ -74,11 +74,13 @@ struct MlpFusedParams {
     const bf16_t* Wp;                           // both weights in MFMA fragment order (launch_pack_mlp)
     const float* b1; const float* b2;           // [1536], [384]
     int M;
+    int* queue;                                 // set by launch_mlp_fused: work counter of the persistent walk (zeroed per launch)
 };
 bool mlp_fused_supported(int D, int F, int planes);
 long mlp_fused_pack_elems(int D, int F);        // bf16 elements of the packed copy (0: unsupported shape)
 int launch_pack_mlp(const float* W1, const float* W2, int D, int F, bf16_t* dst, hipStream_t s);
-int launch_mlp_fused(const MlpFusedParams& p, hipStream_t s);
+int launch_mlp_fused(const MlpFusedParams& p, hipStream_t s);      // one wave per SIMD (mlp_fused.hip)
+int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s);     // role-split wave pairs, two waves per SIMD (mlp_fused2.hip)
 
 // tuning knobs (dinoseg_set_option): see api.hip
 struct Options {
@@ -88,6 +90,7 @@ struct Options {
     int attn_dbg = 0;        // same for AttnParams::dbg
     int mlp_fused = 1;       // the MLP half of a block as one launch (mlp_fused.hip): 0 never, 1 for >= mlp_fused_min_rows rows, 2 wherever supported
     int mlp_fused_min_rows = 24000;
+    int mlp_variant = 2;     // 1: mlp_fused.hip (one wave per SIMD), 2: mlp_fused2.hip (role-split wave pairs)
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 16;
     int attn_variant = 11;   // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the

@@ -28,8 +28,7 @@
 // 48 tiles and runs on across the items of the persistent walk.
 #include <type_traits>
 
-#include "attn_common.h"
-#include "kernels.h"
+#include "mlp_common.h"
 
 namespace dseg {
 
@@ -43,7 +42,8 @@ constexpr int W1_OFF = 0, W2_OFF = RING * W_TILE;
 constexpr int B1_OFF = 2 * RING * W_TILE;          // b1 [F] fp32
 constexpr int B2_OFF = B1_OFF + F * 4;             // b2, gamma, beta [D] fp32 each
 constexpr int G_OFF = B2_OFF + D * 4, BE_OFF = G_OFF + D * 4;
-constexpr int LDS_BYTES = BE_OFF + D * 4;
+constexpr int Q_OFF = BE_OFF + D * 4;              // next item of the persistent walk (one int, broadcast to the workgroup)
+constexpr int LDS_BYTES = Q_OFF + 16;
 static_assert(NDB * 2 == NKS && LDS_BYTES <= 160 * 1024, "fragment counts / LDS budget");
 constexpr int PIECES = W_TILE / 1024 / 2;          // LDS-DMA pieces per wave and tile: waves 0,1 carry W1, waves 2,3 carry W2
 static_assert(PIECES == 12, "three groups of four pieces");
@@ -85,49 +85,6 @@ int launch_pack_mlp(const float* W1, const float* W2, int Dm, int Fh, bf16_t* ds
     hipLaunchKernelGGL(pack_mlp_kernel, dim3(2048), dim3(256), 0, s, W1, W2, dst, total);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
-}
-
-// four 1-KiB LDS-DMA pieces: global sbase + voff + {0, 1, 2, 3} KiB -> LDS lds_dst + {0, 1, 2, 3} KiB (+ 16 * lane).  The
-// instruction's immediate offset applies to the global AND the LDS address, so M0 is set once.
-__device__ __forceinline__ void mf_dma4(uint32_t voff, uint64_t sbase, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_dst)
-        : "memory");
-}
-
-template <int... I, class Fn>
-__device__ __forceinline__ void mf_for(std::integer_sequence<int, I...>, Fn&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-// one 1-KiB LDS-DMA piece (the instruction's immediate offset applies to the global AND the LDS address)
-template <int OFF>
-__device__ __forceinline__ void mf_dma1(uint32_t voff, uint64_t sbase, uint32_t lds_dst) {
-    // (M0 is not saved: nothing else in the tile loop uses it -- no LDS-DMA builtin, no movrel, no GWS -- and every statement that
-    //  needs it sets it)
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
-                 :
-                 : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(OFF)
-                 : "memory");
-}
-// fragment read / counted wait (the compiler must neither count nor move these: it would drain the read-ahead)
-template <int OFF>
-__device__ __forceinline__ void mf_rd(bf16x8& dst, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void mf_wait() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);      // (an MFMA is not a memory operation: only this keeps it behind the wait)
 }
 
 __global__ __launch_bounds__(mf::THREADS, 1) void mlp_fused_kernel(MlpFusedParams p) {
@@ -251,7 +208,10 @@ __global__ __launch_bounds__(mf::THREADS, 1) void mlp_fused_kernel(MlpFusedParam
     const float* const sG = reinterpret_cast<const float*>(smem + G_OFF);
     const float* const sBe = reinterpret_cast<const float*>(smem + BE_OFF);
 
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    // Persistent walk over the 128-row items.  With a work counter (p.queue, zeroed per launch) the next item is drawn when the
+    // current one is finished -- every item costs the same, but workgroups drift apart (HBM phases, other kernels on the chip)
+    // and the counter keeps the tail short; without one the items are dealt round-robin.
+    for (int item = blockIdx.x; item < nitems;) {
         // ================= prologue: this lane's half of row (item*128 + wave*32 + lr): x[16 s + 8 lh + 0..7], s = 0..23, straight
         // into the accumulators (o[db][8 s2 + j] <-> s = 2 db + s2): they start from the residual
         const int row = item * BM + wave * 32 + lr;
@@ -480,6 +440,15 @@ __global__ __launch_bounds__(mf::THREADS, 1) void mlp_fused_kernel(MlpFusedParam
 #pragma unroll
             for (int db = 0; db < NDB; ++db) asm volatile("" ::"v"(o[db]));
         }
+        if (p.queue != nullptr) {
+            int* const nxt = reinterpret_cast<int*>(smem + Q_OFF);
+            if (tid == 0) *nxt = atomicAdd(p.queue, 1) + (int)gridDim.x;
+            __syncthreads();
+            item = __builtin_amdgcn_readfirstlane(*nxt);
+            __syncthreads();
+        } else {
+            item += gridDim.x;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring units issued past the last item's end
 }
@@ -501,7 +470,26 @@ int launch_mlp_fused(const MlpFusedParams& p, hipStream_t s) {
     if (ncu <= 0) return -2;
     const int nitems = (p.M + mf::BM - 1) / mf::BM;
     const int grid = nitems < ncu ? nitems : ncu;
-    hipLaunchKernelGGL(mlp_fused_kernel, dim3(grid), dim3(mf::THREADS), mf::LDS_BYTES, s, p);
+    MlpFusedParams q = p;
+    q.queue = nullptr;
+    if (nitems > grid) {
+        // the work counter: one int per device, zeroed ahead of every launch (a memset node when captured).  Launches on two
+        // streams of one device may overlap (the two-stream forward): eight counters per device, taken in turn
+        static int* qbuf[64] = {};
+        static std::atomic<unsigned> turn{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (!qbuf[dev]) {
+                int* b = nullptr;
+                if (hipMalloc(reinterpret_cast<void**>(&b), 8 * 64) == hipSuccess) qbuf[dev] = b;
+            }
+            if (qbuf[dev]) {
+                q.queue = qbuf[dev] + (turn.fetch_add(1) & 7) * 16;
+                DSEG_CHECK_HIP(hipMemsetAsync(q.queue, 0, 16, s));
+            }
+        }
+    }
+    hipLaunchKernelGGL(mlp_fused_kernel, dim3(grid), dim3(mf::THREADS), mf::LDS_BYTES, s, q);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,515 @@
+// Fused transformer MLP, bf16 mode, ViT-S width -- role-split wave pairs (two waves per SIMD).
+//     x += fc2(gelu(fc1(LayerNorm2(x))))      (vision_transformer.py:135 -> :59-65)
+//
+// Same arithmetic, same packed weights and the same per-tile dataflow as mlp_fused.hip (read its header first).  What that kernel
+// showed (profiles/r03_mlp_ablation.md): with ONE wave per SIMD everything the wave issues besides its MFMAs -- 12 LDS-DMA
+// pieces, 48 fragment reads, ~170 vector instructions of GELU per tile -- is serial with them (in-order issue: 55 cycles per MFMA
+// gap instead of 32; the bare MFMA stream alone runs at the pipe's rate).  Here the work of a 32-row block is split between TWO
+// waves that share a SIMD, so one wave's memory / vector issue overlaps the other's matrix work:
+//   wave A ("fc1")  holds xn = LayerNorm2(x) of the 32 rows (96 registers).  Tile step s: S(s+1)^T = W1_{s+1} . xn^T + b1
+//                   (24 MFMAs, fragments from the W1 ring) while the GELU of S(s) runs on the vector unit; P(s) = bf16(gelu(S(s)))
+//                   goes to a 2-KiB LDS buffer in B-operand fragment order (two ds_write_b128 per lane).
+//   wave B ("fc2")  holds the out^T[384][32] accumulators (192 registers), initialised with x + b2.  Tile step s: o^T += W2^T_{s-1} .
+//                   P(s-1)^T (24 MFMAs, fragments from the W2 ring, P from the LDS buffer its partner filled one step earlier) and
+//                   issues the workgroup's weight stream: 12 LDS-DMA pieces per step (W2(s), then W1(s+3)).
+// A workgroup is four such pairs = 8 waves = 128 rows; one barrier per tile step (49 per item: wave B runs one step behind).  Wave A
+// does the next item's LayerNorm prologue while wave B finishes the last tile and stores the rows: the item boundary overlaps too.
+// LDS: W1 ring 3 x 24 KiB, W2 ring 2 x 24 KiB (read one step after it was issued, its pieces go first in the step), P 4 pairs x 2
+// x 2 KiB, constants 10.5 KiB = 147 KiB.
+#include <stdio.h>
+
+#include <vector>
+
+#include "mlp_common.h"
+
+namespace dseg {
+
+namespace mf2 {
+using namespace mfc;
+constexpr int NP = 4, BM = NP * 32, THREADS = 2 * NP * 64;      // pairs per workgroup; rows; threads
+constexpr int W1_OFF = 0, W2_OFF = 3 * W_TILE;
+constexpr int P_OFF = W2_OFF + 2 * W_TILE;          // [pair][slot][fragment][64 lanes][16 B]
+constexpr int B1_OFF = P_OFF + NP * 2 * 2048;       // b1 [F] fp32
+constexpr int B2_OFF = B1_OFF + F * 4;              // b2, gamma, beta [D] fp32 each
+constexpr int G_OFF = B2_OFF + D * 4, BE_OFF = G_OFF + D * 4;
+constexpr int LDS_BYTES = BE_OFF + D * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+#ifndef MF2_RA
+#define MF2_RA 4
+#endif
+constexpr int RA = MF2_RA, NFR = RA + 1;            // fragment read-ahead (gaps); fragment registers
+}  // namespace mf2
+
+#ifndef MF2_ABL
+#define MF2_ABL 0      // timing ablations (wrong results): 1 no GELU, 2 no W DMA, 4 no fc1 MFMAs, 8 no fc2 MFMAs, 16 no fragment reads,
+                       // 32 no row loads / stores
+#endif
+
+#ifndef MF2_STAMP
+#define MF2_STAMP 0      // diagnostic build only: lane 0 of waves 0 (A) and 4 (B) stamps s_memrealtime / s_memtime into p.queue
+#endif
+#define MF2_ST(role, item_k, idx)                                                                                         \
+    do {                                                                                                                  \
+        if (MF2_STAMP && (tid & 63) == 0 && (item_k) < 4) {                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(p.queue) +                                      \
+                                    ((((long)blockIdx.x * 2 + (role)) * 4 + (item_k)) * 16 + (idx)) * 2;                  \
+            d[0] = __builtin_amdgcn_s_memrealtime();                                                                      \
+            d[1] = __builtin_amdgcn_s_memtime();                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+        }                                                                                                                 \
+    } while (0)
+
+__global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedParams p) {
+    using namespace mf2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave & 3;
+    const bool is_b = wave >= 4;                  // wave-uniform role
+    const int M = p.M;
+    const int nitems = (M + BM - 1) / BM;
+    if ((int)blockIdx.x >= nitems) return;
+
+    // ---- constants into LDS: b1, b2, gamma, beta
+    {
+        float* const sB1w = reinterpret_cast<float*>(smem + B1_OFF);
+        for (int i = tid; i < F / 4; i += THREADS) reinterpret_cast<f32x4*>(sB1w)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
+        for (int i = tid; i < 3 * D / 4; i += THREADS) {
+            const int which = i / (D / 4), j = i - which * (D / 4);
+            const float* src = which == 0 ? p.b2 : (which == 1 ? p.gamma : p.beta);
+            reinterpret_cast<f32x4*>(smem + B2_OFF + which * D * 4)[j] = reinterpret_cast<const f32x4*>(src)[j];
+        }
+    }
+#ifndef MF2_STAGGER
+#define MF2_STAGGER 0      // experiment: odd workgroups start MF2_STAGGER x 8128 cycles late (desynchronises the HBM bursts of item boundaries)
+#endif
+    if (MF2_STAGGER > 0 && (blockIdx.x & 1))
+        for (int i = 0; i < MF2_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const float* const sB1 = reinterpret_cast<const float*>(smem + B1_OFF);
+    const float* const sB2 = reinterpret_cast<const float*>(smem + B2_OFF);
+    const float* const sG = reinterpret_cast<const float*>(smem + G_OFF);
+    const float* const sBe = reinterpret_cast<const float*>(smem + BE_OFF);
+    auto uniform64 = [](uint64_t v) __attribute__((always_inline)) -> uint64_t {
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) |
+               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
+    };
+    const uint64_t wp = reinterpret_cast<uint64_t>(p.Wp);
+
+    if (is_b) {
+        // ================================================================================================= wave B: fc2 + weight stream
+        // this wave's share of a tile's stream: fragments 6 pair .. 6 pair + 5 of each matrix
+        const uint32_t frag0 = (uint32_t)pair * 6 * 1024;
+        {
+            // ring prologue = what the last steps of a previous item would have issued: W1(0), W1(1), W1(2)
+            const uint32_t lane16 = (uint32_t)(tid & 63) * 16;
+            if (!(MF2_ABL & 2))
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const uint64_t sb = uniform64(wp + (uint32_t)t * TILE_BYTES + frag0);
+                    const uint32_t ld = __builtin_amdgcn_readfirstlane(lds_base + W1_OFF + t * W_TILE + frag0);
+                    mf_dma4(lane16, sb, ld);
+                    mf_dma1<0>(lane16, sb + 4096, ld + 4096);
+                    mf_dma1<1024>(lane16, sb + 4096, ld + 4096);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();      // constants staged; W1(0..2) visible
+
+        f32x16 o[NDB];
+        int item_k = 0;
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++item_k) {
+            if (wave == 4) MF2_ST(1, item_k, 0);
+            // per-lane constants from an opaque lane id, once per item (values that live across the item loop get spilled, and a
+            // scratch reload inside the step loop drains the weight ring: see mlp_fused.hip)
+            uint32_t zero = 0;
+            asm volatile("" : "+v"(zero));
+            const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+            const uint32_t lane16_i = lane_i * 16, lr_i = lane_i & 31, lh_i = lane_i >> 5;
+            const uint32_t frag_rd_i = lds_base + lane16_i;
+            const uint32_t p_rd_i = lds_base + P_OFF + (uint32_t)pair * 4096 + lane16_i;
+            const int row = item * BM + pair * 32 + (int)lr_i;
+            const int row_c = row < M ? row : M - 1;
+            float* const xrow = p.X + (long)row_c * D + lh_i * 8;
+            // the residual rows of an item, straight into the accumulators (+ the fc2 bias): issued BEFORE the item's first
+            // barrier -- for the first item at the kernel's start, for the others right behind the previous item's stores -- so
+            // that they run beside wave A's LayerNorm prologue instead of after it
+            auto load_rows = [&](const float* xr) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < NKS; ++k) {
+                    f32x4 a = {1.f, 2.f, 3.f, (float)k}, b = a;
+                    if (!(MF2_ABL & 32)) {
+                        a = *reinterpret_cast<const f32x4*>(xr + k * 16);
+                        b = *reinterpret_cast<const f32x4*>(xr + k * 16 + 4);
+                    }
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(sB2 + k * 16 + lh_i * 8);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(sB2 + k * 16 + lh_i * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[k >> 1][(k & 1) * 8 + e] = a[e] + c0[e];
+                        o[k >> 1][(k & 1) * 8 + 4 + e] = b[e] + c1[e];
+                    }
+                }
+            };
+            if (item == (int)blockIdx.x) load_rows(xrow);
+            if (wave == 4) MF2_ST(1, item_k, 1);
+
+            // the stream pieces of step s: W2(s) (s <= 47) first, then W1 of virtual tile s + 3 (48: none; 49.. = the next item's 0..)
+            auto step_b = [&](int s, auto kind_tag) __attribute__((always_inline)) {
+                constexpr int KIND = decltype(kind_tag)::value;      // 0: step 0 (row loads, no fc2); 1: steps 1..48
+                __builtin_amdgcn_s_barrier();
+                const int v1 = s + 3;
+                const bool has_w2 = s <= NT - 1, has_w1 = v1 != NT;
+                const int t1 = v1 < NT ? v1 : v1 - (NT + 1);
+                uint64_t gsb[4];
+                uint32_t gld[4];
+                {
+                    const uint32_t so2 = (uint32_t)s * TILE_BYTES + W_TILE + frag0, so1 = (uint32_t)t1 * TILE_BYTES + frag0;
+                    const uint32_t d2 = lds_base + W2_OFF + (uint32_t)(s & 1) * W_TILE + frag0;
+                    const uint32_t d1 = lds_base + W1_OFF + (uint32_t)(t1 % 3) * W_TILE + frag0;
+                    gsb[0] = uniform64(wp + so2);
+                    gsb[1] = uniform64(wp + so2 + 4096);
+                    gsb[2] = uniform64(wp + so1);
+                    gsb[3] = uniform64(wp + so1 + 4096);
+                    gld[0] = __builtin_amdgcn_readfirstlane(d2);
+                    gld[1] = __builtin_amdgcn_readfirstlane(d2 + 4096);
+                    gld[2] = __builtin_amdgcn_readfirstlane(d1);
+                    gld[3] = __builtin_amdgcn_readfirstlane(d1 + 4096);
+                }
+                auto piece = [&](auto j_tag) __attribute__((always_inline)) {
+                    constexpr int J = decltype(j_tag)::value;      // 0..5: W2, 6..11: W1
+                    if (MF2_ABL & 2) return;
+                    if (J < 6 ? !has_w2 : !has_w1) return;
+                    constexpr int Q = J % 6, G4 = (J / 6) * 2 + (Q >= 4 ? 1 : 0), OFF = (Q & 3) * 1024;
+                    mf_dma1<OFF>(lane16_i, gsb[G4], gld[G4]);
+                };
+                if constexpr (KIND == 0) {
+                    mf_for(std::make_integer_sequence<int, 12>{}, piece);
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // W2(0) (and the row loads / stores issued before it)
+                } else {
+                    const uint32_t a2 = frag_rd_i + W2_OFF + (uint32_t)((s - 1) & 1) * W_TILE;
+                    const uint32_t ap = p_rd_i + (uint32_t)((s - 1) & 1) * 2048;
+                    bf16x8 p0, p1, fr[NFR];
+                    mf_rd<0>(p0, ap);
+                    mf_rd<1024>(p1, ap);
+                    // fragment of gap G: all k-step-0 products (they take p0), then the k-step-1 products
+                    auto issue_read = [&](auto g_tag) __attribute__((always_inline)) {
+                        constexpr int G = decltype(g_tag)::value;
+                        if (MF2_ABL & 16) return;
+                        if constexpr (G < 12) mf_rd<(2 * G) * 1024>(fr[G % NFR], a2);
+                        else mf_rd<(2 * (G - 12) + 1) * 1024>(fr[G % NFR], a2);
+                    };
+                    mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
+                    mf_for(std::make_integer_sequence<int, 24>{}, [&](auto g_tag) __attribute__((always_inline)) {
+                        constexpr int G = decltype(g_tag)::value;
+                        if constexpr (G + RA < 24) issue_read(std::integral_constant<int, G + RA>{});
+                        if (MF2_ABL & 16) fr[G % NFR] = p0;
+                        else mf_wait<(23 - G < RA ? 23 - G : RA)>();
+                        if (!(MF2_ABL & 8)) o[G % 12] = mfma32(fr[G % NFR], G < 12 ? p0 : p1, o[G % 12]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr ((G & 1) == 0) piece(std::integral_constant<int, G / 2>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    // what the next step reads must have landed: W2(s) (this wave's pieces; the barrier publishes them) and W1 of
+                    // the step before; the six W1 pieces issued last may stay in flight
+                    if (s >= 1 && s <= NT - 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            };
+            step_b(0, std::integral_constant<int, 0>{});
+            if (wave == 4) MF2_ST(1, item_k, 2);
+#pragma unroll 1
+            for (int s = 1; s <= NT; ++s) {
+                step_b(s, std::integral_constant<int, 1>{});
+                if (wave == 4 && s == 1) MF2_ST(1, item_k, 3);
+                if (wave == 4 && s == 24) MF2_ST(1, item_k, 4);
+                if (wave == 4 && s == 47) MF2_ST(1, item_k, 5);
+            }
+            if (wave == 4) MF2_ST(1, item_k, 6);
+
+            // ---- epilogue: o = x + b2 + fc2(...) back to the residual stream
+            if (MF2_ABL & 32) {
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) asm volatile("" ::"v"(o[db]));
+            } else if (row < M) {
+#pragma unroll
+                for (int k = 0; k < NKS; ++k) {
+                    f32x4 a, b;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] = o[k >> 1][(k & 1) * 8 + e];
+                        b[e] = o[k >> 1][(k & 1) * 8 + 4 + e];
+                    }
+                    *reinterpret_cast<f32x4*>(xrow + k * 16) = a;
+                    *reinterpret_cast<f32x4*>(xrow + k * 16 + 4) = b;
+                }
+            }
+            if (wave == 4) MF2_ST(1, item_k, 7);
+            if (item + (int)gridDim.x < nitems) {      // the next item's rows (same lane mapping, BM * gridDim rows further on)
+                const int nrow = row + BM * (int)gridDim.x;
+                load_rows(p.X + (long)(nrow < M ? nrow : M - 1) * D + lh_i * 8);
+            }
+            if (wave == 4) MF2_ST(1, item_k, 8);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring pieces issued past the last item's end
+        return;
+    }
+
+    // ===================================================================================================== wave A: LayerNorm, fc1, GELU
+    __syncthreads();      // (pairs with wave B's: constants staged, W1(0..2) visible)
+    bf16x8 xn[NKS];
+    f32x16 sa, sb;
+
+    // LayerNorm2 of this lane's half row -> xn (B-operand fragments, k = 16 s + 8 lh + j), then S(0) (compiler-scheduled)
+    auto prologue = [&](int item) __attribute__((always_inline)) {
+        int lane_p = tid & 63;
+        asm volatile("" : "+v"(lane_p));
+        const int lr = lane_p & 31, lh = lane_p >> 5;
+        const int row = item * BM + pair * 32 + lr;
+        const int row_c = row < M ? row : M - 1;
+        const float* const xrow = p.X + (long)row_c * D + lh * 8;
+        f32x4 x[2 * NKS];
+#pragma unroll
+        for (int k = 0; k < NKS; ++k) {
+            if (MF2_ABL & 32) {
+                x[2 * k] = f32x4{1.f, 2.f, (float)k, (float)lane_p};
+                x[2 * k + 1] = x[2 * k];
+            } else {
+                x[2 * k] = *reinterpret_cast<const f32x4*>(xrow + k * 16);
+                x[2 * k + 1] = *reinterpret_cast<const f32x4*>(xrow + k * 16 + 4);
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * NKS; k += 2) sum += ((x[k][0] + x[k][1]) + (x[k][2] + x[k][3])) + ((x[k + 1][0] + x[k + 1][1]) + (x[k + 1][2] + x[k + 1][3]));
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / D);
+        float qv = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * NKS; ++k) {
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dlt = x[k][e] - mean;
+                part = fmaf(dlt, dlt, part);
+            }
+            qv += part;
+        }
+        qv += __shfl_xor(qv, 32);
+        const float rstd = 1.0f / sqrtf(qv * (1.0f / D) + p.eps);
+        int kc = lh * 8;
+        asm volatile("" : "+v"(kc));
+        float mean_n = mean;
+        asm volatile("" : "+v"(mean_n));
+#pragma unroll
+        for (int k = 0; k < NKS; ++k) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int k0 = k * 16 + kc;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(sG + k0), g1 = *reinterpret_cast<const f32x4*>(sG + k0 + 4);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(sBe + k0), e1 = *reinterpret_cast<const f32x4*>(sBe + k0 + 4);
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (x[2 * k][e] - mean_n) * rstd * g0[e] + e0[e];
+                y[4 + e] = (x[2 * k + 1][e] - mean_n) * rstd * g1[e] + e1[e];
+            }
+            uint4 u;
+            u.x = pack_bf16x2(y[0], y[1]);
+            u.y = pack_bf16x2(y[2], y[3]);
+            u.z = pack_bf16x2(y[4], y[5]);
+            u.w = pack_bf16x2(y[6], y[7]);
+            xn[k] = __builtin_bit_cast(bf16x8, u);
+        }
+        // S(0): accumulators start from b1 (tile 0), fragments from W1 ring slot 0
+        f32x16 s;
+        const float* bp = sB1 + kc;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(bp), c1 = *reinterpret_cast<const f32x4*>(bp + 4);
+        const f32x4 c2 = *reinterpret_cast<const f32x4*>(bp + 16), c3 = *reinterpret_cast<const f32x4*>(bp + 20);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s[e] = c0[e];
+            s[4 + e] = c1[e];
+            s[8 + e] = c2[e];
+            s[12 + e] = c3[e];
+        }
+        const char* w = smem + W1_OFF + lane_p * 16;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) s = mfma32(lds_frag(w + ks * 1024), xn[ks], s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return s;
+    };
+
+    // ---- the GELU of S(s), spread over the 24 MFMA gaps of the step (+ a tail slot): element n (accumulator register n) starts
+    // at slot (14 n) / 15 and issues instruction i of gelu_fast (common.h) at slot start + i; odd elements pack a dword at + 10
+    float ex[16], ea[16], eb[16], ec[16];
+    uint32_t pd[8];
+    auto gelu_op = [&](auto n_tag, auto i_tag, const f32x16& s) __attribute__((always_inline)) {
+        constexpr int N = decltype(n_tag)::value, I = decltype(i_tag)::value;
+        if constexpr (I == 0) ex[N] = s[N];
+        if (MF2_ABL & 1) {
+            if constexpr (I == 10 && (N & 1)) pd[N >> 1] = pack_bf16x2(ex[N - 1], ex[N]);
+            return;
+        }
+        if constexpr (I == 1) ea[N] = __builtin_amdgcn_fmed3f(ex[N], -8.0f, 8.0f);
+        if constexpr (I == 2) eb[N] = ea[N] * ea[N];
+        if constexpr (I == 3) ec[N] = fmaf(1.01537542e-3f, eb[N], -1.06782573e-1f);
+        if constexpr (I == 4) ec[N] = fmaf(ec[N], eb[N], -2.30111381f);
+        if constexpr (I == 5) ec[N] = ec[N] * ea[N];
+        if constexpr (I == 6) ec[N] = __builtin_amdgcn_exp2f(ec[N]);
+        if constexpr (I == 7) ec[N] = 1.0f + ec[N];
+        if constexpr (I == 8) ec[N] = __builtin_amdgcn_rcpf(ec[N]);
+        if constexpr (I == 9) ex[N] = ex[N] * ec[N];
+        if constexpr (I == 10 && (N & 1)) pd[N >> 1] = pack_bf16x2(ex[N - 1], ex[N]);
+    };
+    auto valu_slot = [&](auto g_tag, const f32x16& s) __attribute__((always_inline)) {
+        constexpr int G = decltype(g_tag)::value;
+        mf_for(std::make_integer_sequence<int, 16>{}, [&](auto n_tag) __attribute__((always_inline)) {
+            constexpr int N = decltype(n_tag)::value;
+            constexpr int SG = (14 * N) / 15;
+            if constexpr (G >= SG && G - SG <= 10) gelu_op(n_tag, std::integral_constant<int, G - SG>{}, s);
+        });
+    };
+
+    if (wave == 0) MF2_ST(0, 0, 15);
+    sa = prologue(blockIdx.x);
+    int item_k = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++item_k) {
+        if (wave == 0) MF2_ST(0, item_k, 0);
+        uint32_t zero = 0;
+        asm volatile("" : "+v"(zero));
+        const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+        const uint32_t lane16_i = lane_i * 16, lh_i = lane_i >> 5;
+        const uint32_t frag_rd_i = lds_base + lane16_i;
+        char* const p_wr = smem + P_OFF + pair * 4096 + lane16_i;
+        const float* const b1_lane_p = sB1 + attn::sigma23((int)(lane_i & 31));     // + HT * tile: b1 of MFMA A row lr
+        const uint4 ones_u = {lh_i == 0 ? 0x3F803F80u : 0u, lh_i == 0 ? 0x00003F80u : 0u, 0u, 0u};     // k = 0, 1, 2 are 1.0
+
+        // tile step s: S(s+1) (unless LAST) || GELU of S(s) -> P(s) into the pair's LDS buffer s & 1
+        auto step_a = [&](f32x16& s_cur, f32x16& s_nxt, int s, auto last_tag) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            bf16x8 bias_frag;
+            if (!LAST) {      // b1 of tile s+1 as an A fragment (hi + mid + lo = the fp32 value exactly) times a ones fragment
+                const float bj = b1_lane_p[(s + 1) * HT];
+                const uint32_t hi = pack_bf16x2(bj, 0.f);
+                const float r1f = bj - bf16_lo_to_f32(hi);
+                const uint32_t mid = pack_bf16x2(r1f, 0.f);
+                const uint32_t lo = pack_bf16x2(r1f - bf16_lo_to_f32(mid), 0.f);
+                const uint4 fu = {lh_i == 0 ? ((hi & 0xFFFFu) | (mid << 16)) : 0u, lh_i == 0 ? (lo & 0xFFFFu) : 0u, 0u, 0u};
+                bias_frag = __builtin_bit_cast(bf16x8, fu);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if constexpr (!LAST) {
+                const uint32_t a1 = frag_rd_i + W1_OFF + (uint32_t)((s + 1) % 3) * W_TILE;
+                bf16x8 fr[NFR];
+                auto issue_read = [&](auto g_tag) __attribute__((always_inline)) {
+                    constexpr int G = decltype(g_tag)::value;
+                    if (MF2_ABL & 16) return;
+                    mf_rd<G * 1024>(fr[G % NFR], a1);
+                };
+                mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
+                {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    s_nxt = mfma32(bias_frag, __builtin_bit_cast(bf16x8, ones_u), z);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mf_for(std::make_integer_sequence<int, 24>{}, [&](auto g_tag) __attribute__((always_inline)) {
+                    constexpr int G = decltype(g_tag)::value;
+                    if constexpr (G + RA < 24) issue_read(std::integral_constant<int, G + RA>{});
+                    if (MF2_ABL & 16) fr[G % NFR] = xn[(G + 1) % NKS];
+                    else mf_wait<(23 - G < RA ? 23 - G : RA)>();
+                    if (!(MF2_ABL & 4)) s_nxt = mfma32(fr[G % NFR], xn[G], s_nxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    valu_slot(g_tag, s_cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                valu_slot(std::integral_constant<int, 24>{}, s_cur);
+            } else {
+                mf_for(std::make_integer_sequence<int, 25>{}, [&](auto g_tag) __attribute__((always_inline)) { valu_slot(g_tag, s_cur); });
+            }
+            const uint4 u0 = {pd[0], pd[1], pd[2], pd[3]}, u1 = {pd[4], pd[5], pd[6], pd[7]};
+            *reinterpret_cast<uint4*>(p_wr + (s & 1) * 2048) = u0;
+            *reinterpret_cast<uint4*>(p_wr + (s & 1) * 2048 + 1024) = u1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // P(s) is in LDS before the next barrier
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll 1
+        for (int s = 0; s < NT - 2; s += 2) {
+            step_a(sa, sb, s, std::false_type{});
+            if (wave == 0 && s == 0) MF2_ST(0, item_k, 1);
+            step_a(sb, sa, s + 1, std::false_type{});
+            if (wave == 0 && s == 0) MF2_ST(0, item_k, 2);
+            if (wave == 0 && s == 22) MF2_ST(0, item_k, 3);
+        }
+        if (wave == 0) MF2_ST(0, item_k, 4);
+        step_a(sa, sb, NT - 2, std::false_type{});
+        step_a(sb, sa, NT - 1, std::true_type{});
+        if (wave == 0) MF2_ST(0, item_k, 5);
+        __builtin_amdgcn_s_barrier();      // step 48: wave B's last tile; this wave already works on the next item
+        if (wave == 0) MF2_ST(0, item_k, 6);
+        if (item + (int)gridDim.x < nitems) sa = prologue(item + gridDim.x);
+        if (wave == 0) MF2_ST(0, item_k, 7);
+    }
+}
+
+int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s) {
+    static PerDeviceOnce once;
+    if (once.first()) {
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           mf2::LDS_BYTES));
+        once.mark();
+    }
+    if (p.M <= 0 || p.ldx != mf2::D) {
+        dinoseg_set_error("mlp_fused2: bad shape M=%d ldx=%d", p.M, p.ldx);
+        return -1;
+    }
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return -2;
+    const int nitems = (p.M + mf2::BM - 1) / mf2::BM;
+    const int grid = nitems < ncu ? nitems : ncu;
+    MlpFusedParams q = p;
+    q.queue = nullptr;
+#if MF2_STAMP
+    static unsigned long long* sbuf = nullptr;
+    const size_t sbytes = (size_t)grid * 2 * 4 * 16 * 2 * 8;
+    if (!sbuf) DSEG_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&sbuf), 256 * 2 * 4 * 16 * 2 * 8));
+    DSEG_CHECK_HIP(hipMemsetAsync(sbuf, 0, sbytes, s));
+    q.queue = reinterpret_cast<int*>(sbuf);
+#endif
+    hipLaunchKernelGGL(mlp_fused2_kernel, dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
+    DSEG_CHECK_HIP(hipGetLastError());
+#if MF2_STAMP
+    {
+        static int calls = 0;
+        if (++calls == 20) {      // one report, well after warm-up: per stamp the mean over workgroups of (time since the item's first stamp)
+            DSEG_CHECK_HIP(hipStreamSynchronize(s));
+            std::vector<unsigned long long> h(sbytes / 8);
+            DSEG_CHECK_HIP(hipMemcpy(h.data(), sbuf, sbytes, hipMemcpyDeviceToHost));
+            for (int role = 0; role < 2; ++role)
+                for (int k = 0; k < 4; ++k) {
+                    fprintf(stderr, "role %c item %d:", role ? 'B' : 'A', k);
+                    for (int i = 0; i < 16; ++i) {
+                        double sum = 0, sumc = 0;
+                        int n = 0;
+                        for (int b = 0; b < grid; ++b) {
+                            const unsigned long long* d = &h[((((size_t)b * 2 + role) * 4 + k) * 16) * 2];
+                            const unsigned long long* d0 = &h[((((size_t)b * 2 + 1) * 4 + 0) * 16) * 2];      // B, item 0, stamp 0
+                            if (d[2 * i] == 0 || d0[0] == 0) continue;
+                            sum += (double)(d[2 * i] - d0[0]) * 0.01;          // us (100 MHz)
+                            sumc += (double)(d[2 * i + 1] - d0[1]);            // shader cycles
+                            ++n;
+                        }
+                        if (n) fprintf(stderr, " [%d] %.1fus/%.0fkc", i, sum / n, sumc / n / 1e3);
+                    }
+                    fprintf(stderr, "\n");
+                }
+        }
+    }
+#endif
+    return 0;
+}
+
+}  // namespace dseg

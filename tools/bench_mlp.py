@@ -1,5 +1,5 @@
-"""GPU box: time the fused MLP operator (mlp_fused.hip) alone: python tools/bench_mlp.py [rows] [iters]
-(DINOSEG_LIB selects the build: tools/ab_ops.sh-style A/B runs of ablation variants)."""
+"""GPU box: time the fused MLP operator alone: python tools/bench_mlp.py [rows] [iters] [variant]
+(variant 1 = mlp_fused.hip, 2 = mlp_fused2.hip; DINOSEG_LIB selects the build for A/B runs of ablation variants)."""
 import os
 import sys
 
@@ -11,6 +11,7 @@ from tests.gpu_util import seeded  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 32 * 3601
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2]
 D, F = 384, 1536
 X = seeded((M, D), 1) * 1.5
 gam, bet = 1 + 0.2 * seeded((D,), 2), 0.1 * seeded((D,), 3)
@@ -27,15 +28,18 @@ def run():
                                                b2.data_ptr(), M, D, F, S()))
 
 
-for _ in range(5):
-    run()
-torch.cuda.synchronize()
-a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-a.record()
-for _ in range(iters):
-    run()
-b.record()
-torch.cuda.synchronize()
-us = a.elapsed_time(b) / iters * 1e3
-fl = 2 * 2 * M * D * F
-print(f"mlp_fused M={M}: {us:.1f} us  {fl / us / 1e6:.0f} TFLOP/s  lib={os.path.basename(os.environ.get('DINOSEG_LIB', 'in-tree'))}")
+for rep in range(2):
+    for v in variants:
+        capi.check(capi.lib().dinoseg_set_option(b"mlp_variant", v))
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            run()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) / iters * 1e3
+        fl = 2 * 2 * M * D * F
+        print(f"mlp_fused variant {v} M={M}: {us:.1f} us  {fl / us / 1e6:.0f} TFLOP/s  lib={os.path.basename(os.environ.get('DINOSEG_LIB', 'in-tree'))}")
