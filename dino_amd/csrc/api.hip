@@ -747,6 +747,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().mlp_fused = value;
         return 0;
     }
+    if (strcmp(key, "mlp_grid") == 0) {
+        dseg::options().mlp_grid = value;
+        return 0;
+    }
     if (strcmp(key, "mlp_variant") == 0) {
         dseg::options().mlp_variant = value;
         return 0;

@@ -475,7 +475,8 @@ int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s) {
     const int ncu = device_cu_count();
     if (ncu <= 0) return -2;
     const int nitems = (p.M + mf2::BM - 1) / mf2::BM;
-    const int grid = nitems < ncu ? nitems : ncu;
+    const int cap = options().mlp_grid > 0 && options().mlp_grid < ncu ? options().mlp_grid : ncu;
+    const int grid = nitems < cap ? nitems : cap;
     MlpFusedParams q = p;
     q.queue = nullptr;
 #if MF2_STAMP
