@@ -113,6 +113,8 @@ static void release_workspaces(dinoseg_handle* h) {
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (auto& e : h->bw_ev) (void)hipEventDestroy(e);
+    h->bw_ev.clear();
     h->ws = h->ws2 = nullptr;
     h->ws_bytes = h->ws2_bytes = 0;
     h->ws_B = h->ws_r = h->ws2_B = h->ws2_r = -1;
@@ -233,6 +235,8 @@ static std::vector<LinSpec> linear_specs(const dinoseg_handle* h) {
     return v;
 }
 
+static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s);
+
 extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     if (!h) return -1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -265,6 +269,7 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
         h->wbuf_bytes = total;
     }
     size_t off = 0;
+    std::vector<PackJob> jobs;
     for (const LinSpec& sp : specs) {
         PackedLinear pk;
         pk.w = reinterpret_cast<bf16_t*>(h->wbuf + off);
@@ -272,7 +277,7 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
         pk.n_pad = sp.n_pad;
         pk.k_pad = sp.k_pad;
         off += align_up((size_t)sp.planes * sp.n_pad * sp.k_pad * sizeof(bf16_t), 256);
-        DSEG_TRY(launch_pack_planes(W(h, sp.wname), sp.N, sp.K, pk.w, pk.plane, sp.n_pad, sp.k_pad, sp.planes, s));
+        jobs.push_back({W(h, sp.wname), pk.w, pk.plane, sp.N, sp.K, sp.n_pad, sp.k_pad, sp.planes, 0});
         if (sp.n_pad != sp.N) {
             pk.bias_pad = reinterpret_cast<float*>(h->wbuf + off);
             off += align_up((size_t)sp.n_pad * sizeof(float), 256);
@@ -288,15 +293,19 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
             h->packed_slab[sp.wname] = slab;
         }
     }
+    DSEG_TRY(launch_multi_pack(jobs.data(), (int)jobs.size(), s));
     h->packed_mlp.clear();
     if (mlp_fusable)
         for (int i = 0; i < h->cfg.n_blocks; ++i) {
             const std::string b = "dino.blocks." + std::to_string(i) + ".";
             bf16_t* dst = reinterpret_cast<bf16_t*>(h->wbuf + off);
             off += align_up((size_t)mlp_fused_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
-            DSEG_TRY(launch_pack_mlp(W(h, b + "mlp.fc1.weight"), W(h, b + "mlp.fc2.weight"), Dm, Fh, dst, s));
             h->packed_mlp[b] = dst;
         }
+    // Packed now, except while gradient buffers are bound (a fine-tune in progress refreshes after every optimiser step and its
+    // forward never runs the fused kernel): then the first inference forward that wants them packs them (ensure_mlp_packs).
+    h->packed_mlp_stale = true;
+    if (h->grads.empty()) DSEG_TRY(ensure_mlp_packs(h, s));
     h->weights_ready = true;
     h->pos_r = -1;   // pos_embed may have changed (fine-tune)
     return 0;
@@ -411,6 +420,20 @@ struct MaskRequest {            // forward_mask / get_last_selfattention(x, cls_
     float* feat_out;            // dinoseg_features: final-norm tokens [B, N, D] after feat_blocks blocks (0 = all), then stop
     int feat_blocks;
 };
+
+// the fused MLP kernel runs for this many token rows (options mlp_fused / mlp_fused_min_rows)
+static bool mlp_fuse_wanted(const dinoseg_handle* h, long rows) {
+    return !h->packed_mlp.empty() && (options().mlp_fused == 2 || (options().mlp_fused == 1 && rows >= options().mlp_fused_min_rows));
+}
+// fragment-order MLP weights (mlp_fused.hip), packed on first use after a weight refresh
+static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s) {
+    if (!h->packed_mlp_stale) return 0;
+    const int Dm = h->cfg.embed_dim, Fh = h->cfg.embed_dim * h->cfg.mlp_ratio;
+    for (auto& kv : h->packed_mlp)
+        DSEG_TRY(launch_pack_mlp(W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc2.weight"), Dm, Fh, kv.second, s));
+    h->packed_mlp_stale = false;
+    return 0;
+}
 
 static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
                         int32_t* argmax_out, int32_t tap_block, float* tap_out, float* attn_out, void* stream,
@@ -556,9 +579,9 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.out_f32 = X; g.ldo_f32 = D;
             DSEG_PROF(DINOSEG_PROF_PROJ, DSEG_TRY(launch_gemm(g, s)));
         }
-        const bool fuse_mlp = h->packed_mlp.count(b) && (options().mlp_fused == 2 ||
-                                                         (options().mlp_fused == 1 && L.M >= options().mlp_fused_min_rows));
+        const bool fuse_mlp = h->packed_mlp.count(b) && mlp_fuse_wanted(h, L.M);
         if (fuse_mlp) {
+            DSEG_TRY(ensure_mlp_packs(h, s));      // (a split forward has done this before its fork)
             // LN2 + fc1 + GELU + fc2 + residual in one launch: the hidden activation never reaches HBM (mlp_fused.hip)
             MlpFusedParams g = {};
             g.X = X; g.ldx = D; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
@@ -642,6 +665,15 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     return 0;
 }
 
+int ensure_aux_stream(dinoseg_handle* h) {
+    if (!h->aux_stream) {
+        DSEG_CHECK_HIP(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+        DSEG_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        DSEG_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    return 0;
+}
+
 // Option "streams" = 2: a batch of >= split_min frames runs as two half-batches, the first on the caller's stream, the second on
 // the handle's internal stream (forked from and joined to the caller's stream by events, so the call keeps its stream-ordered
 // semantics and stays capturable).  Frames are independent (pl_torch_modules.py:253 flattens them); kernels of different
@@ -655,16 +687,14 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DeviceGuard guard(h);
     DSEG_TRY(check_stream_device(h, s));
-    if (!h->aux_stream) {
-        DSEG_CHECK_HIP(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-        DSEG_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        DSEG_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    }
+    DSEG_TRY(ensure_aux_stream(h));
     DSEG_TRY(dinoseg_prepare_resolution(h, r, stream));      // the resampled position embedding: before the fork, both halves read it
     const int B0 = (B + 1) / 2, B1 = B - B0;
     const long n = (long)(r / 8) * (r / 8);
     const size_t frame_bytes = x_kind == DINOSEG_INPUT_U8_HWC ? (size_t)r * r * 3 : (size_t)r * r * 3 * sizeof(float);
     const void* x1 = reinterpret_cast<const char*>(x) + (size_t)B0 * frame_bytes;
+    const long ntok_ = n + 1;
+    if (mlp_fuse_wanted(h, B0 * ntok_) || mlp_fuse_wanted(h, B1 * ntok_)) DSEG_TRY(ensure_mlp_packs(h, s));   // before the fork: both halves read them
     DSEG_CHECK_HIP(hipEventRecord(h->ev_fork, s));
     DSEG_CHECK_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
     const int rc0 = forward_impl(h, x, x_kind, B0, r, logp_out, argmax_out, -1, nullptr, nullptr, stream);
@@ -749,6 +779,14 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
     }
     if (strcmp(key, "mlp_grid") == 0) {
         dseg::options().mlp_grid = value;
+        return 0;
+    }
+    if (strcmp(key, "splitk_tiles") == 0) {
+        dseg::options().splitk_tiles = value;
+        return 0;
+    }
+    if (strcmp(key, "train_streams") == 0) {
+        dseg::options().train_streams = value;
         return 0;
     }
     if (strcmp(key, "mlp_variant") == 0) {

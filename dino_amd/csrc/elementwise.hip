@@ -54,6 +54,54 @@ int launch_pack_planes_t(const float* src, int rows, int cols, bf16_t* dst, long
     return 0;
 }
 
+// Many packs in one launch: block b serves job t with boff[t] <= b < boff[t+1] (a wave-uniform scan of kernel arguments).
+constexpr int PACK_MAX = 40, PACK_CHUNK = 256 * 16;
+struct MultiPackTable {
+    PackJob job[PACK_MAX];
+    int boff[PACK_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void multi_pack_kernel(MultiPackTable T) {
+    int t = 0;
+    while (t + 1 < T.count && T.boff[t + 1] <= (int)blockIdx.x) ++t;
+    const PackJob& j = T.job[t];
+    const long total = (long)j.rows_pad * j.cols_pad;
+    const long base = (long)(blockIdx.x - T.boff[t]) * PACK_CHUNK;
+    for (long i = base + threadIdx.x; i < base + PACK_CHUNK && i < total; i += 256) {
+        int r, c;
+        if (j.transposed) {
+            c = (int)(i / j.rows_pad);
+            r = (int)(i - (long)c * j.rows_pad);
+        } else {
+            r = (int)(i / j.cols_pad);
+            c = (int)(i - (long)r * j.cols_pad);
+        }
+        const float v = (r < j.rows && c < j.cols) ? j.src[(long)r * j.cols + c] : 0.f;
+        const uint32_t hi = pack_bf16x2(v, 0.f);
+        j.dst[i] = (bf16_t)(hi & 0xFFFF);
+        if (j.planes == 2) j.dst[j.plane + i] = (bf16_t)(pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
+    }
+}
+
+int launch_multi_pack(const PackJob* jobs, int count, hipStream_t s) {
+    for (int t0 = 0; t0 < count; t0 += PACK_MAX) {
+        MultiPackTable T;
+        T.count = count - t0 < PACK_MAX ? count - t0 : PACK_MAX;
+        int blocks = 0;
+        for (int t = 0; t < T.count; ++t) {
+            T.job[t] = jobs[t0 + t];
+            T.boff[t] = blocks;
+            const long total = (long)jobs[t0 + t].rows_pad * jobs[t0 + t].cols_pad;
+            blocks += (int)((total + PACK_CHUNK - 1) / PACK_CHUNK);
+        }
+        T.boff[T.count] = blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(multi_pack_kernel, dim3(blocks), dim3(256), 0, s, T);
+        DSEG_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm (nn.LayerNorm(D, eps=1e-6): vision_transformer.py:303; uses :114,:118,:183).
 // One wavefront per row; the row lives in registers (D/128 float2 per lane); mean, then the biased variance

@@ -41,6 +41,8 @@ struct dinoseg_handle {
     std::map<std::string, PackedLinear> packed;
     std::map<std::string, bf16_t*> packed_slab;     // slab-major copies of the LN-fed weights (gemm_ln.hip), when supported
     std::map<std::string, bf16_t*> packed_mlp;      // per block ("dino.blocks.i."): fc1 + fc2 in MFMA fragment order (mlp_fused.hip)
+    bool packed_mlp_stale = false;         // the fragment-order packs are made on the first forward that uses them (the fine-tune
+                                           // step refreshes the weights every step and never runs the fused MLP kernel)
     bool weights_ready = false;
     // pos-embed cache
     float* pos_cache = nullptr;
@@ -69,6 +71,9 @@ struct dinoseg_handle {
     // n_blocks-1-k, n_blocks + 1 = embeddings; stage_done = number of stages the last backward recorded
     std::vector<hipEvent_t> stage_ev;
     int stage_done = 0;
+    // fork / join events of the weight-gradient side stream (option train_streams = 2: train_api.hip); aux_stream is shared with
+    // the split forward
+    std::vector<hipEvent_t> bw_ev;
     char* twbuf = nullptr;                 // transposed packed weights for the input-gradient GEMMs
     size_t twbuf_bytes = 0;
     int prof_level = 0;                    // 0 off, 1 attention only, 2 every class
@@ -103,6 +108,9 @@ static inline int check_stream_device(const dinoseg_handle* h, hipStream_t s) {
     }
     return 0;
 }
+
+// the handle's side stream + its fork / join events (api.hip): created on first use, destroyed with the workspaces
+int ensure_aux_stream(dinoseg_handle* h);
 
 static inline int prof_begin(dinoseg_handle* h, int cat, hipStream_t s) {
     if (h->prof_level == 0 || (h->prof_level == 1 && cat != DINOSEG_PROF_ATTN)) return -1;

@@ -94,6 +94,8 @@ struct Options {
     int mlp_variant = 2;     // 1: mlp_fused.hip (one wave per SIMD), 2: mlp_fused2.hip (role-split wave pairs)
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 16;
+    int train_streams = 2;   // 2: backward runs the weight-gradient GEMMs of the blocks on the handle's side stream (train_api.hip)
+    int splitk_tiles = 512;  // weight-gradient GEMMs: partial 128x128 tiles per launch (<= 768, the workspace holds that many)
     int attn_variant = 11;   // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
                              // tile work; bit 2 (bf16 mode): the software-pipelined kernel (attention_pipe.hip); bit 3 (bf16 mode):
                              // the zero-reference kernel, four waves per SIMD (attention_z.hip)
@@ -185,6 +187,13 @@ int launch_multi_adam(int count, float* const* p, const float* const* g, float* 
 int launch_multi_zero(int count, float* const* p, const long* n, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
                 int decoupled, int step, float gscale, hipStream_t s);
+// several pack_planes / pack_planes_t jobs in ONE launch (a weight refresh is ~30 of them, each a few microseconds of work
+// behind a launch: the fine-tune step repacks every weight after every optimiser step)
+struct PackJob {
+    const float* src; bf16_t* dst; long plane;
+    int rows, cols, rows_pad, cols_pad, planes, transposed;
+};
+int launch_multi_pack(const PackJob* jobs, int count, hipStream_t s);
 // fp32 [rows, cols] -> TRANSPOSED bf16 planes [planes][cols_pad][rows_pad] (zero padded): W^T operands for dgrad
 int launch_pack_planes_t(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,
                          int planes, hipStream_t s);

@@ -16,7 +16,11 @@
 
 namespace {
 
-constexpr int SPLITK_TILES = 768;      // partial 128x128 fp32 tiles of one weight-gradient GEMM (48 MiB)
+constexpr int SPLITK_TILES = 768;      // partial 128x128 fp32 tiles of one weight-gradient GEMM (48 MiB): what the workspace holds
+inline int splitk_budget() {
+    const int v = dseg::options().splitk_tiles;
+    return v < 1 ? 1 : v > SPLITK_TILES ? SPLITK_TILES : v;
+}
 
 struct TrainLayout {
     int n, ntok, npad, M, Mp, Mpad, Mppad, Cmax;
@@ -438,15 +442,17 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
             h->twbuf_bytes = total;
         }
         size_t off = 0;
+        std::vector<dseg::PackJob> jobs;
         for (const TLin& t : tspecs) {
             TW e;
             e.w = reinterpret_cast<bf16_t*>(h->twbuf + off);
             e.plane = (long)t.k_pad * t.n_pad;
             off += align_up((size_t)t.planes * t.k_pad * t.n_pad * 2, 256);
             // W [N][K] fp32 -> W^T planes [k_pad][n_pad]: "rows" of the source are N, transposed destination rows are K
-            DSEG_TRY(launch_pack_planes_t(W(h, t.wname), t.N, t.K, e.w, e.plane, t.n_pad, t.k_pad, t.planes, s));
+            jobs.push_back({W(h, t.wname), e.w, e.plane, t.N, t.K, t.n_pad, t.k_pad, t.planes, 1});
             tw[t.wname] = e;
         }
+        DSEG_TRY(launch_multi_pack(jobs.data(), (int)jobs.size(), s));
     }
 
     auto grad = [&](const std::string& name) -> float* {
@@ -477,14 +483,57 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
     // =============================================================== backward
     // stage events: a side stream can start reducing a gradient bucket while the rest of backward still runs
     h->stage_done = 0;
-    auto stage_mark = [&](int stage) -> int {
+    auto stage_mark_on = [&](int stage, hipStream_t on) -> int {
         while ((int)h->stage_ev.size() <= stage) {
             hipEvent_t ev;
             DSEG_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             h->stage_ev.push_back(ev);
         }
-        DSEG_CHECK_HIP(hipEventRecord(h->stage_ev[stage], s));
+        DSEG_CHECK_HIP(hipEventRecord(h->stage_ev[stage], on));
         h->stage_done = stage + 1;
+        return 0;
+    };
+    auto stage_mark = [&](int stage) -> int { return stage_mark_on(stage, s); };
+    // Side stream for the blocks' weight gradients (option train_streams = 2).  dW = dY^T . X reads what the input-gradient chain
+    // has already produced and feeds nothing but the optimiser, so it runs beside that chain on the handle's internal stream:
+    // the chain's tail rounds and memory-bound kernels (LayerNorm backward, the attention prep) leave CUs idle that the
+    // weight-gradient tiles fill.  side_begin(): the side stream waits for everything queued on s so far; side_end() returns an
+    // event the caller's stream waits on (side_wait) before it overwrites an operand the side kernels read, and before every
+    // gradient-stage event.  Fork and join are events only: the call stays stream-ordered for the caller and capturable.
+    const bool side = options().train_streams >= 2 && D % 128 == 0 && F % 128 == 0;   // (narrow layers go through T1 / T2: one stream)
+    hipStream_t ws_ = s;
+    size_t bw_i = 0;
+    auto bw_event = [&](hipEvent_t* out) -> int {
+        if (bw_i == h->bw_ev.size()) {
+            hipEvent_t ev;
+            DSEG_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            h->bw_ev.push_back(ev);
+        }
+        *out = h->bw_ev[bw_i++];
+        return 0;
+    };
+    if (side) {
+        DSEG_TRY(ensure_aux_stream(h));
+        ws_ = h->aux_stream;
+    }
+    auto side_begin = [&]() -> int {
+        if (!side) return 0;
+        hipEvent_t ev;
+        DSEG_TRY(bw_event(&ev));
+        DSEG_CHECK_HIP(hipEventRecord(ev, s));
+        DSEG_CHECK_HIP(hipStreamWaitEvent(ws_, ev, 0));
+        return 0;
+    };
+    auto side_end = [&](hipEvent_t* done) -> int {
+        *done = nullptr;
+        if (!side) return 0;
+        DSEG_TRY(bw_event(done));
+        DSEG_CHECK_HIP(hipEventRecord(*done, ws_));
+        return 0;
+    };
+    auto side_wait = [&](hipEvent_t& done) -> int {
+        if (done) DSEG_CHECK_HIP(hipStreamWaitEvent(s, done, 0));
+        done = nullptr;
         return 0;
     };
     float* sink = F32(L.SINK);
@@ -508,7 +557,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
         g.A = Tdy; g.a_plane = tplane; g.lda = m_pad; g.W = Tx; g.w_plane = tplane;
         g.M = n_rows; g.N = k_pad128; g.K = m_pad; g.planes = planes;
         const int row_tiles = (n_rows + 127) / 128, tiles = row_tiles * (k_pad128 / 128), nk = m_pad / 64;
-        int ks = SPLITK_TILES / tiles;
+        int ks = splitk_budget() / tiles;
         if (ks > nk / 2) ks = nk / 2;
         if (ks < 1) ks = 1;
         if (ks == 1) {
@@ -531,7 +580,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
     // dbias (optional): the layer's bias gradient = column sums of Y, taken inside the weight-gradient kernel; when that kernel
     // does not run (frozen weight, narrow layer) a pack pass over Y produces them
     auto wgrad_tn = [&](const bf16_t* Y, long y_plane, int ldy, const bf16_t* X, long x_plane, int ldx, int m_rows, int n_rows,
-                        int k_cols, int planes, float* dW, float* dbias = nullptr) -> int {
+                        int k_cols, int planes, float* dW, float* dbias, hipStream_t s) -> int {
         if (dbias && (!dW || k_cols % 128 != 0))
             DSEG_TRY(launch_transpose_planes(nullptr, Y, y_plane, ldy, m_rows, n_rows, nullptr, 0, pad128(n_rows), L.Mpad, nullptr, 0, 0,
                                              dbias, planes, 0, 0, s));
@@ -549,7 +598,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
         g.Y = Y; g.y_plane = y_plane; g.ldy = ldy; g.X = X; g.x_plane = x_plane; g.ldx = ldx;
         g.M = m_rows; g.N = n_rows; g.Kc = k_cols; g.planes = planes;
         const int row_tiles = (n_rows + 127) / 128, tiles = row_tiles * (k_cols / 128), nchunks = (m_rows + 63) / 64;
-        int ks = SPLITK_TILES / tiles;
+        int ks = splitk_budget() / tiles;
         if (ks > nchunks / 2) ks = nchunks / 2;
         if (ks < 1) ks = 1;
         const int per = (nchunks + ks - 1) / ks, used = (nchunks + per - 1) / per;
@@ -611,6 +660,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
                                   NB > 0 ? grad("dino.blocks." + std::to_string(NB - 1) + ".mlp.fc2.bias") : nullptr));
 
     bf16_t* dCTX = B16(L.dCTX);
+    hipEvent_t w_fc2 = nullptr, w_fc1 = nullptr, w_proj = nullptr, w_qkv = nullptr;
     for (int l = NB - 1; l >= 0; --l) {
         const std::string b = "dino.blocks." + std::to_string(l) + ".";
         const size_t o = l * L.blk_stride;
@@ -619,19 +669,28 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
         // ---- mlp.fc2 : X_out = X_mid + H W2^T + b
         // (dXp = bf16 planes of dX and the fc2 bias gradient were left by the LayerNorm backward that produced dX; the weight
         //  gradient reads dXp and HB row-major)
-        DSEG_TRY(wgrad_tn(dXp, L.a_plane, D, HB, L.f_plane, F, L.M, D, F, P, grad(b + "mlp.fc2.weight")));
-        // dHpre = (dX . W2) * gelu'(Hpre)
+        DSEG_TRY(side_begin());
+        DSEG_TRY(wgrad_tn(dXp, L.a_plane, D, HB, L.f_plane, F, L.M, D, F, P, grad(b + "mlp.fc2.weight"), nullptr, ws_));
+        DSEG_TRY(side_end(&w_fc2));
+        // dHpre = (dX . W2) * gelu'(Hpre)      (writes G: the previous block's qkv weight gradient reads it)
+        DSEG_TRY(side_wait(w_qkv));
         DSEG_TRY(dgrad(dXp, L.a_plane, D, L.M, D, tw.at(b + "mlp.fc2.weight"), F, P, EPI_DGELU, nullptr, G, (long)L.M * F, HPRE, L.f_plane));
         // ---- mlp.fc1 : Hpre = A2 W1^T + b
-        DSEG_TRY(wgrad_tn(G, (long)L.M * F, F, A2, L.a_plane, D, L.M, F, D, P, grad(b + "mlp.fc1.weight"), grad(b + "mlp.fc1.bias")));
+        DSEG_TRY(side_begin());
+        DSEG_TRY(wgrad_tn(G, (long)L.M * F, F, A2, L.a_plane, D, L.M, F, D, P, grad(b + "mlp.fc1.weight"), grad(b + "mlp.fc1.bias"), ws_));
+        DSEG_TRY(side_end(&w_fc1));
         DSEG_TRY(dgrad(G, (long)L.M * F, F, L.M, F, tw.at(b + "mlp.fc1.weight"), D, P, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
-        // ---- norm2 (input X_mid); the residual branch keeps dX
+        // ---- norm2 (input X_mid); the residual branch keeps dX      (rewrites dXp: the fc2 weight gradient reads it)
+        DSEG_TRY(side_wait(w_fc2));
         DSEG_TRY(launch_layernorm_bwd(dA, F32(L.Xmid + o), W(h, b + "norm2.weight"), c.ln_eps, L.M, D, dX, 1, gsink(b + "norm2.weight"),
                                       gsink(b + "norm2.bias"), 0, L.ntok, s, dXp, L.a_plane, P, grad(b + "attn.proj.bias")));
         // ---- attn.proj : X_mid = X_in + ctx Wp^T + b
-        DSEG_TRY(wgrad_tn(dXp, L.a_plane, D, CTX, L.a_plane, D, L.M, D, D, P, grad(b + "attn.proj.weight")));
+        DSEG_TRY(side_begin());
+        DSEG_TRY(wgrad_tn(dXp, L.a_plane, D, CTX, L.a_plane, D, L.M, D, D, P, grad(b + "attn.proj.weight"), nullptr, ws_));
+        DSEG_TRY(side_end(&w_proj));
         DSEG_TRY(dgrad(dXp, L.a_plane, D, L.M, D, tw.at(b + "attn.proj.weight"), D, P, EPI_BF16, nullptr, dCTX, L.a_plane, nullptr, 0));
-        // ---- attention
+        // ---- attention      (writes G: the fc1 weight gradient reads it)
+        DSEG_TRY(side_wait(w_fc1));
         {
             AttnBwdParams a = {};
             a.q = Q; a.k = Kb; a.v = V; a.qkv_plane = L.qkv_plane;
@@ -642,17 +701,31 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
             DSEG_TRY(launch_attention_bwd(a, s));
         }
         // ---- attn.qkv : qkv = A1 Wqkv^T + b
+        DSEG_TRY(side_begin());
         DSEG_TRY(wgrad_tn(G, (long)L.M * 3 * D, 3 * D, A1, L.a_plane, D, L.M, 3 * D, D, P, grad(b + "attn.qkv.weight"),
-                          grad(b + "attn.qkv.bias")));
+                          grad(b + "attn.qkv.bias"), ws_));
+        DSEG_TRY(side_end(&w_qkv));
         DSEG_TRY(dgrad(G, (long)L.M * 3 * D, 3 * D, L.M, 3 * D, tw.at(b + "attn.qkv.weight"), D, P, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
-        // ---- norm1 (input X_in)
+        // ---- norm1 (input X_in)      (rewrites dXp: the proj weight gradient reads it)
         // (by-products for mlp.fc2 of block l-1; the embedding step after block 0 packs dX itself: it drops the CLS rows)
+        DSEG_TRY(side_wait(w_proj));
         DSEG_TRY(launch_layernorm_bwd(dA, F32(L.Xin + o), W(h, b + "norm1.weight"), c.ln_eps, L.M, D, dX, 1, gsink(b + "norm1.weight"),
                                       gsink(b + "norm1.bias"), 0, L.ntok, s, l > 0 ? dXp : nullptr, L.a_plane, P,
                                       l > 0 ? grad("dino.blocks." + std::to_string(l - 1) + ".mlp.fc2.bias") : nullptr));
+        // this block's gradients are complete once the side stream has finished its qkv weight gradient; the stage event is
+        // recorded on the side stream (it has waited for everything the block queued on s up to the qkv weight gradient -- the
+        // LayerNorm backward above is covered by the extra fork), so the caller's stream does not stall here
+        if (side) {
+            DSEG_TRY(side_begin());
+            DSEG_TRY(stage_mark_on(1 + (NB - 1 - l), ws_));
+            continue;
+        }
         DSEG_TRY(stage_mark(1 + (NB - 1 - l)));
     }
 
+    // join: the caller's stream continues (and the call returns) behind everything the side stream did; the embedding step
+    // below reuses the split-K workspace
+    DSEG_TRY(side_wait(w_qkv));
     // ---- embeddings: tokens = [cls ; conv(patches)] + pos   (vision_transformer.py:224-235)
     float* dpos = F32(L.DPOS);
     DSEG_TRY(launch_batch_sum_rows(dX, B, L.ntok, D, dpos, s));
