@@ -345,3 +345,69 @@ def test_bad_label_flag_survives_a_change_of_batch_shape(cuda):
     with pytest.raises(IndexError):
         m.check_labels()
     m.check_labels()                                  # reported once, then cleared
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_step_batch8_r480_equals_mean_of_single_frame_steps(cuda, precision):
+    """configs[3]'s per-GPU shape (BASELINE.json: 3-block fine-tune, batch 64 over 8 GPUs = 8 frames @480 per rank): the loss is the
+    mean over all B * 3600 patches (F.nll_loss, pl_torch_modules.py:264), every patch of every frame counted once, so the gradient
+    of the 8-frame step is the mean of the eight 1-frame gradients.  Frames only interact through that mean (pl_torch_modules.py:253
+    flattens them), which makes this a size-independent property of the batch-8 launch shapes: 28 808-row GEMMs, 450-chunk split-K
+    weight gradients, 48 (frame, head) pairs in the flash backward, the side-stream weight gradients.  Tolerance: d logits of the
+    8-frame step are the 1-frame ones times 1/8 -- a power of two, so every bf16 rounding of the backward walk is the same on both
+    sides and only the order of the fp32 sums over the batch rows differs: measured 6e-7 of the gradient's norm, the bar is 1e-5."""
+    cfg = ViTConfig(n_blocks=3)
+    m, sd = build(cfg, precision=precision)
+    m.unfreeze_bb()
+    B = 8
+    frames = torch.from_numpy(synthetic_frames(B, 480, seed=131)).cuda()
+    labels = torch.from_numpy(synthetic_labels(B, 3600, cfg.n_classes, seed=132)).cuda()
+    out = m.fused_training_step((frames, labels), 0)
+    assert torch.isfinite(out["loss"]) and out["probs"].shape == (B * 3600, cfg.n_classes)
+    assert float((out["probs"].exp().sum(dim=-1) - 1).abs().max()) <= 1e-4          # log-probabilities
+    got = {k: p.grad.clone() for k, p in m.named_parameters()}
+    loss8 = float(out["loss"])
+    mean = {k: torch.zeros_like(v) for k, v in got.items()}
+    losses = []
+    for b in range(B):
+        o1 = m.fused_training_step((frames[b:b + 1], labels[b:b + 1]), 0)
+        losses.append(float(o1["loss"]))
+        for k, p in m.named_parameters():
+            mean[k] += p.grad / B
+    assert abs(loss8 - sum(losses) / B) <= 2e-4 * max(1.0, abs(loss8))
+    rel = 1e-5
+    worst = 0.0
+    for k in got:
+        assert torch.isfinite(got[k]).all(), k
+        err = float((got[k] - mean[k]).norm()) / (float(mean[k].norm()) + 1e-20)
+        worst = max(worst, err)
+        assert err <= rel, (k, err)
+    print(f"batch-8 step vs mean of 8 single-frame steps [{precision}]: worst relative gradient error {worst:.2e}")
+
+
+def test_side_stream_weight_gradients_equal_one_stream(cuda):
+    """Option train_streams: 2 (default) runs the blocks' weight-gradient GEMMs on the handle's side stream, 1 keeps everything on
+    the caller's stream.  Same kernels on the same operands: tensors written by plain stores (all weights) are bit-identical,
+    atomically summed ones (biases, LayerNorm gains) agree to summation order; repeated steps are stable (no race on the buffers
+    the side stream reads: dXp, G)."""
+    cfg = ViTConfig(n_blocks=3)
+    m, sd = build(cfg, precision="bf16")
+    m.unfreeze_bb()
+    frames = torch.from_numpy(synthetic_frames(4, 240, seed=141)).cuda()
+    labels = torch.from_numpy(synthetic_labels(4, 900, cfg.n_classes, seed=142)).cuda()
+    lib = capi.lib()
+    try:
+        capi.check(lib.dinoseg_set_option(b"train_streams", 1))
+        m.fused_training_step((frames, labels), 0)
+        one = {k: p.grad.clone() for k, p in m.named_parameters()}
+        capi.check(lib.dinoseg_set_option(b"train_streams", 2))
+        for rep in range(3):
+            m.fused_training_step((frames, labels), 0)
+            torch.cuda.synchronize()
+            for k, p in m.named_parameters():
+                if k.endswith(".weight") and p.dim() == 2 and "norm" not in k:
+                    assert torch.equal(p.grad, one[k]), (k, rep)
+                else:
+                    assert float((p.grad - one[k]).abs().max()) <= 2e-5 * (float(one[k].abs().max()) + 1e-12), (k, rep)
+    finally:
+        capi.check(lib.dinoseg_set_option(b"train_streams", 2))

@@ -79,7 +79,7 @@ def bench_gemm_planes2():
         X = torch.zeros((M, N), device="cuda") if epi == capi.EPI_RESID else None
         O = torch.zeros((2, M, N), dtype=torch.int16, device="cuda") if epi == capi.EPI_GELU else None
         for big in (0, 2):
-            for dbg in (0, 1):
+            for dbg in ((0, 1) if big == 0 else (0, 1, 2, 3)):
                 capi.check(lib.dinoseg_set_option(b"gemm_big", big))
                 capi.check(lib.dinoseg_set_option(b"gemm_dbg", dbg))
 
@@ -88,7 +88,7 @@ def bench_gemm_planes2():
                                                    bias.data_ptr(), capi.ptr(X), capi.ptr(O), M * N, N, capi.stream_ptr()))
                 ms = timeit(run)
                 tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-                print(f"{name:5s} planes=2 N={N:5d} K={K:5d} kernel={('small', 'auto', 'big')[big]:6s} skip_epilogue={dbg}: "
+                print(f"{name:5s} planes=2 N={N:5d} K={K:5d} kernel={('small', 'auto', 'big')[big]:6s} skip_epilogue={dbg & 1} skip_loads={dbg >> 1}: "
                       f"{ms * 1e3:8.1f} us  {tf:7.1f} TFLOP/s ({3 * tf:7.1f} MFMA-equivalent)", flush=True)
         del A, W, X, O
     lib.dinoseg_set_option(b"gemm_big", 1)
