@@ -193,6 +193,7 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
                 h->packed.clear();
                 h->packed_slab.clear();
                 h->packed_mlp.clear();
+                h->packed_proj.clear();
                 h->bound.clear();
                 h->grads.clear();
             }
@@ -261,7 +262,9 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     }
     const int Dm = h->cfg.embed_dim, Fh = h->cfg.embed_dim * h->cfg.mlp_ratio;
     const bool mlp_fusable = mlp_fused_supported(Dm, Fh, h->planes);
-    if (mlp_fusable) total += (size_t)h->cfg.n_blocks * align_up((size_t)mlp_fused_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
+    if (mlp_fusable)
+        total += (size_t)h->cfg.n_blocks * (align_up((size_t)mlp_fused_pack_elems(Dm, Fh) * sizeof(bf16_t), 256) +
+                                            align_up((size_t)mlp_fused_proj_pack_elems(Dm) * sizeof(bf16_t), 256));
     if (total > h->wbuf_bytes) {
         if (h->wbuf) DSEG_CHECK_HIP(hipFree(h->wbuf));
         h->wbuf = nullptr;
@@ -295,12 +298,17 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     }
     DSEG_TRY(launch_multi_pack(jobs.data(), (int)jobs.size(), s));
     h->packed_mlp.clear();
+    h->packed_proj.clear();
     if (mlp_fusable)
         for (int i = 0; i < h->cfg.n_blocks; ++i) {
             const std::string b = "dino.blocks." + std::to_string(i) + ".";
             bf16_t* dst = reinterpret_cast<bf16_t*>(h->wbuf + off);
             off += align_up((size_t)mlp_fused_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
             h->packed_mlp[b] = dst;
+            if (mlp_fused_proj_pack_elems(Dm) > 0) {
+                h->packed_proj[b] = reinterpret_cast<bf16_t*>(h->wbuf + off);
+                off += align_up((size_t)mlp_fused_proj_pack_elems(Dm) * sizeof(bf16_t), 256);
+            }
         }
     // Packed now, except while gradient buffers are bound (a fine-tune in progress refreshes after every optimiser step and its
     // forward never runs the fused kernel): then the first inference forward that wants them packs them (ensure_mlp_packs).
@@ -431,6 +439,7 @@ static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s) {
     const int Dm = h->cfg.embed_dim, Fh = h->cfg.embed_dim * h->cfg.mlp_ratio;
     for (auto& kv : h->packed_mlp)
         DSEG_TRY(launch_pack_mlp(W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc2.weight"), Dm, Fh, kv.second, s));
+    for (auto& kv : h->packed_proj) DSEG_TRY(launch_pack_proj(W(h, kv.first + "attn.proj.weight"), Dm, kv.second, s));
     h->packed_mlp_stale = false;
     return 0;
 }
@@ -569,7 +578,10 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P;
             DSEG_PROF(DINOSEG_PROF_ATTN, DSEG_TRY(launch_attention(a, s)));
         }
-        {
+        const bool fuse_mlp = h->packed_mlp.count(b) && mlp_fuse_wanted(h, L.M);
+        // (the role-split fused MLP kernel takes the attention output projection along: x += proj(ctx) + b, then the MLP, one launch)
+        const bool fuse_proj = fuse_mlp && options().proj_fused && options().mlp_variant != 1 && P == 1 && h->packed_proj.count(b);
+        if (!fuse_proj) {
             const PackedLinear& pk = h->packed.at(b + "attn.proj.weight");
             GemmParams g = {};
             g.A = CTX; g.a_plane = L.ctx_plane; g.lda = D;
@@ -579,7 +591,6 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.out_f32 = X; g.ldo_f32 = D;
             DSEG_PROF(DINOSEG_PROF_PROJ, DSEG_TRY(launch_gemm(g, s)));
         }
-        const bool fuse_mlp = h->packed_mlp.count(b) && mlp_fuse_wanted(h, L.M);
         if (fuse_mlp) {
             DSEG_TRY(ensure_mlp_packs(h, s));      // (a split forward has done this before its fork)
             // LN2 + fc1 + GELU + fc2 + residual in one launch: the hidden activation never reaches HBM (mlp_fused.hip)
@@ -587,6 +598,9 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.X = X; g.ldx = D; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
             g.Wp = h->packed_mlp.at(b); g.b1 = W(h, b + "mlp.fc1.bias"); g.b2 = W(h, b + "mlp.fc2.bias");
             g.M = L.M;
+            if (fuse_proj) {
+                g.ctx = CTX; g.Wproj = h->packed_proj.at(b); g.bproj = W(h, b + "attn.proj.bias");
+            }
             DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(options().mlp_variant == 1 ? launch_mlp_fused(g, s) : launch_mlp_fused2(g, s)));
         } else {
         if (fuse_ln && h->packed_slab.count(b + "mlp.fc1.weight") && L.hb_plane < (1L << 31)) {
@@ -777,6 +791,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().mlp_fused = value;
         return 0;
     }
+    if (strcmp(key, "proj_fused") == 0) {
+        dseg::options().proj_fused = value;
+        return 0;
+    }
     if (strcmp(key, "mlp_grid") == 0) {
         dseg::options().mlp_grid = value;
         return 0;
@@ -911,6 +929,31 @@ extern "C" int dinoseg_op_mlp_fused(float* X, const float* gamma, const float* b
     g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
     return options().mlp_variant == 1 ? launch_mlp_fused(g, reinterpret_cast<hipStream_t>(stream))
                                       : launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t dinoseg_op_proj_pack_elems(int32_t D) { return mlp_fused_proj_pack_elems(D); }
+
+extern "C" int dinoseg_op_pack_proj(const float* Wsrc, int32_t D, void* dst, void* stream) {
+    if (!Wsrc || !dst || mlp_fused_proj_pack_elems(D) <= 0) {
+        dinoseg_set_error("dinoseg_op_pack_proj: null pointer or unsupported width D=%d", D);
+        return -1;
+    }
+    return launch_pack_proj(Wsrc, D, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* Wproj, const float* bproj, const float* gamma,
+                                         const float* beta, float eps, const void* Wp, const float* b1, const float* b2, int32_t M,
+                                         int32_t D, int32_t F, void* stream) {
+    if (!X || !ctx || !Wproj || !bproj || !gamma || !beta || !Wp || !b1 || !b2 || !mlp_fused_supported(D, F, 1) ||
+        mlp_fused_proj_pack_elems(D) <= 0) {
+        dinoseg_set_error("dinoseg_op_proj_mlp_fused: null pointer or unsupported shape D=%d F=%d", D, F);
+        return -1;
+    }
+    MlpFusedParams g = {};
+    g.X = X; g.ldx = D; g.gamma = gamma; g.beta = beta; g.eps = eps;
+    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
+    g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.Wproj = reinterpret_cast<const bf16_t*>(Wproj); g.bproj = bproj;
+    return launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t dinoseg_op_ln_gemm_slab_elems(int32_t N, int32_t K, int32_t planes) {

@@ -75,7 +75,13 @@ struct MlpFusedParams {
     const float* b1; const float* b2;           // [1536], [384]
     int M;
     int* queue;                                 // set by launch_mlp_fused: work counter of the persistent walk (zeroed per launch)
+    // optional (mlp_fused2 only): the block's attention output projection in the same launch, X += ctx . Wproj^T + bproj first
+    const bf16_t* ctx;                          // [M, 384] bf16 attention output (row stride 384), null = MLP only
+    const bf16_t* Wproj;                        // launch_pack_proj
+    const float* bproj;
 };
+long mlp_fused_proj_pack_elems(int D);          // bf16 elements of the packed projection weight (0: unsupported width)
+int launch_pack_proj(const float* W, int D, bf16_t* dst, hipStream_t s);
 bool mlp_fused_supported(int D, int F, int planes);
 long mlp_fused_pack_elems(int D, int F);        // bf16 elements of the packed copy (0: unsupported shape)
 int launch_pack_mlp(const float* W1, const float* W2, int D, int F, bf16_t* dst, hipStream_t s);
@@ -91,6 +97,7 @@ struct Options {
     int mlp_fused = 1;       // the MLP half of a block as one launch (mlp_fused.hip): 0 never, 1 for >= mlp_fused_min_rows rows, 2 wherever supported
     int mlp_fused_min_rows = 24000;
     int mlp_grid = 0;        // experiment: workgroups of the fused MLP launch (0 = one per CU)
+    int proj_fused = 1;      // 1: with mlp_variant 2 the block's attention output projection runs inside the fused MLP launch
     int mlp_variant = 2;     // 1: mlp_fused.hip (one wave per SIMD), 2: mlp_fused2.hip (role-split wave pairs)
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 16;

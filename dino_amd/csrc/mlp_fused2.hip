@@ -15,7 +15,22 @@
 // A workgroup is four such pairs = 8 waves = 128 rows; one barrier per tile step (49 per item: wave B runs one step behind).  Wave A
 // does the next item's LayerNorm prologue while wave B finishes the last tile and stores the rows: the item boundary overlaps too.
 // LDS: W1 ring 3 x 24 KiB, W2 ring 2 x 24 KiB (read one step after it was issued, its pieces go first in the step), P 4 pairs x 2
-// x 2 KiB, constants 10.5 KiB = 147 KiB.
+// x 2 KiB, constants 12 KiB = 148.5 KiB.
+//
+// PROJ = true: the attention output projection of the same block runs in the same launch, ahead of the MLP:
+//     x += proj(ctx) + b_proj;   x += fc2(gelu(fc1(LayerNorm2(x))))      (vision_transformer.py:123 -> :104-105, then :135)
+// x_mid^T = x^T + Wproj . ctx^T has the shape of the fc2 product (A = weight fragments with the sigma23 row order, so that the
+// accumulator registers 8 s2 .. 8 s2 + 7 of a lane are 8 consecutive features = the row layout LayerNorm and the stores use), with
+// the ctx rows as the B operand.  Twelve projection steps (one per 32 input features) run ahead of the 48 tile steps in wave B, whose
+// accumulators start from x + b_proj.  Wave B then normalises the rows from its registers (LayerNorm2: the statistics are sums
+// over the lane's 192 accumulator registers and one cross-half shuffle) and hands xn to wave A as finished B-operand fragments:
+// three rounds of eight fragments through an 8-KiB LDS window per pair.  Wave A reads no rows at all (the MLP-only kernel reads
+// them twice, once per wave).  While the projection runs, the W1 ring carries the Wproj k-tiles (24 KiB each, prefetched two steps
+// ahead; tiles 0..2 of the NEXT item take the place of the W1(0..2) prefetch at steps 46..48) and the W2 ring six 8-KiB slots of
+// ctx k-tiles ([128 rows][32] bf16, chunk-swizzled 64-byte rows); W1(0..2) and W2(0) are fetched while wave B normalises.  b2 is
+// added with the final stores.  (First version: both waves accumulated the projection and wave A normalised its own copy --
+// 390 us per launch at 32 frames against 313 + 88 for the two kernels it replaces; this one: see profiles/r03_mlp_ablation.md.)  The
+// separate proj launch (97 us at 32 frames: 442 MB of HBM traffic, of which 354 MB are the residual stream's round trip) is gone.
 #include <stdio.h>
 
 #include <vector>
@@ -32,8 +47,14 @@ constexpr int P_OFF = W2_OFF + 2 * W_TILE;          // [pair][slot][fragment][64
 constexpr int B1_OFF = P_OFF + NP * 2 * 2048;       // b1 [F] fp32
 constexpr int B2_OFF = B1_OFF + F * 4;              // b2, gamma, beta [D] fp32 each
 constexpr int G_OFF = B2_OFF + D * 4, BE_OFF = G_OFF + D * 4;
-constexpr int LDS_BYTES = BE_OFF + D * 4;
+constexpr int BP_OFF = BE_OFF + D * 4;              // PROJ: b2 (B2_OFF then holds b_proj, the initial value's bias)
+constexpr int LDS_BYTES = BP_OFF + D * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int NPT = D / 32;                         // PROJ: projection k-tiles
+constexpr int CTX_OFF = W2_OFF, CTX_SLOT = BM * 64; // PROJ: six slots of [128 rows][32 k] bf16 in the (idle) W2 ring
+static_assert(6 * CTX_SLOT == 2 * W_TILE, "ctx ring = W2 ring");
+constexpr int H_OFF = W2_OFF + W_TILE;              // PROJ: xn hand-off windows, 8 KiB per pair (W2 slot 1 + the first half of P: idle then)
+static_assert(H_OFF + NP * 8192 <= B1_OFF, "hand-off windows");
 #ifndef MF2_RA
 #define MF2_RA 4
 #endif
@@ -60,6 +81,33 @@ constexpr int RA = MF2_RA, NFR = RA + 1;            // fragment read-ahead (gaps
         }                                                                                                                 \
     } while (0)
 
+// One projection k-tile for one wave: acc^T[384][32] += Wproj(kt) . ctx(kt)^T -- the 24 MFMA gaps of an fc2 step, the weight
+// fragments from a_w (W1-ring slot), the two ctx fragments from ap0 / ap1; piece(j), j = 0..11, is called in every other gap
+// (wave B issues its LDS-DMA pieces there, wave A nothing).
+template <class PieceFn>
+__device__ __forceinline__ void mf2_proj_tile(f32x16 (&acc)[mfc::NDB], uint32_t a_w, uint32_t ap0, uint32_t ap1, PieceFn&& piece) {
+    using namespace mf2;
+    bf16x8 p0, p1, fr[NFR];
+    mf_rd<0>(p0, ap0);
+    mf_rd<0>(p1, ap1);
+    auto issue_read = [&](auto g_tag) __attribute__((always_inline)) {
+        constexpr int G = decltype(g_tag)::value;
+        if constexpr (G < 12) mf_rd<(2 * G) * 1024>(fr[G % NFR], a_w);
+        else mf_rd<(2 * (G - 12) + 1) * 1024>(fr[G % NFR], a_w);
+    };
+    mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
+    mf_for(std::make_integer_sequence<int, 24>{}, [&](auto g_tag) __attribute__((always_inline)) {
+        constexpr int G = decltype(g_tag)::value;
+        if constexpr (G + RA < 24) issue_read(std::integral_constant<int, G + RA>{});
+        mf_wait<(23 - G < RA ? 23 - G : RA)>();
+        acc[G % 12] = mfma32(fr[G % NFR], G < 12 ? p0 : p1, acc[G % 12]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((G & 1) == 0) piece(std::integral_constant<int, G / 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+template <bool PROJ>
 __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedParams p) {
     using namespace mf2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -78,8 +126,11 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         for (int i = tid; i < 3 * D / 4; i += THREADS) {
             const int which = i / (D / 4), j = i - which * (D / 4);
             const float* src = which == 0 ? p.b2 : (which == 1 ? p.gamma : p.beta);
+            if (PROJ && which == 0) src = p.bproj;
             reinterpret_cast<f32x4*>(smem + B2_OFF + which * D * 4)[j] = reinterpret_cast<const f32x4*>(src)[j];
         }
+        if (PROJ)
+            for (int i = tid; i < D / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + BP_OFF)[i] = reinterpret_cast<const f32x4*>(p.b2)[i];
     }
 #ifndef MF2_STAGGER
 #define MF2_STAGGER 0      // experiment: odd workgroups start MF2_STAGGER x 8128 cycles late (desynchronises the HBM bursts of item boundaries)
@@ -96,6 +147,12 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
     };
     const uint64_t wp = reinterpret_cast<uint64_t>(p.Wp);
+    const uint64_t wpj = reinterpret_cast<uint64_t>(p.Wproj), ctxb = reinterpret_cast<uint64_t>(p.ctx);
+    // PROJ: a lane's two ctx fragments of a k-tile (row = pair * 32 + lr of the item, 16-byte chunk (2 s2 + lh) ^ ((row >> 2) & 3))
+    auto ctx_frag_addr = [&](uint32_t lr_, uint32_t lh_) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t rin = (uint32_t)pair * 32 + lr_;
+        return lds_base + CTX_OFF + rin * 64 + ((lh_ ^ ((rin >> 2) & 3)) << 4);      // s2 = 1: ^ 32
+    };
 
     if (is_b) {
         // ================================================================================================= wave B: fc2 + weight stream
@@ -107,12 +164,26 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
             if (!(MF2_ABL & 2))
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    const uint64_t sb = uniform64(wp + (uint32_t)t * TILE_BYTES + frag0);
+                    const uint64_t sb = uniform64(PROJ ? wpj + (uint32_t)t * W_TILE + frag0 : wp + (uint32_t)t * TILE_BYTES + frag0);
                     const uint32_t ld = __builtin_amdgcn_readfirstlane(lds_base + W1_OFF + t * W_TILE + frag0);
                     mf_dma4(lane16, sb, ld);
                     mf_dma1<0>(lane16, sb + 4096, ld + 4096);
                     mf_dma1<1024>(lane16, sb + 4096, ld + 4096);
                 }
+            if (PROJ && !(MF2_ABL & 2)) {      // ctx k-tiles 0..2 of the first item
+                const uint32_t l = (uint32_t)(tid & 63);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint32_t rin = (uint32_t)(2 * pair + j) * 16 + (l >> 2);
+                    int rg = (int)blockIdx.x * BM + (int)rin;
+                    rg = rg < M ? rg : M - 1;
+                    const uint32_t cv = (uint32_t)rg * (D * 2) + (((l & 3) ^ ((rin >> 2) & 3)) << 4);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        mf_dma1<0>(cv, uniform64(ctxb + (uint32_t)t * 64),
+                                   __builtin_amdgcn_readfirstlane(lds_base + CTX_OFF + t * CTX_SLOT + (2 * pair + j) * 1024));
+                }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();      // constants staged; W1(0..2) visible
@@ -160,26 +231,50 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                 constexpr int KIND = decltype(kind_tag)::value;      // 0: step 0 (row loads, no fc2); 1: steps 1..48
                 __builtin_amdgcn_s_barrier();
                 const int v1 = s + 3;
-                const bool has_w2 = s <= NT - 1, has_w1 = v1 != NT;
+                // (PROJ: W2(0) was fetched behind the projection; the tiles past the item's end are the next item's Wproj k-tiles 0..2)
+                const bool has_w2 = PROJ ? (s >= 1 && s <= NT - 1) : s <= NT - 1, has_w1 = v1 != NT;
                 const int t1 = v1 < NT ? v1 : v1 - (NT + 1);
+                const bool nxt = PROJ && v1 > NT;
                 uint64_t gsb[4];
                 uint32_t gld[4];
                 {
-                    const uint32_t so2 = (uint32_t)s * TILE_BYTES + W_TILE + frag0, so1 = (uint32_t)t1 * TILE_BYTES + frag0;
+                    const uint32_t so2 = (uint32_t)s * TILE_BYTES + W_TILE + frag0;
+                    const uint32_t so1 = (nxt ? (uint32_t)t1 * W_TILE : (uint32_t)t1 * TILE_BYTES) + frag0;
                     const uint32_t d2 = lds_base + W2_OFF + (uint32_t)(s & 1) * W_TILE + frag0;
                     const uint32_t d1 = lds_base + W1_OFF + (uint32_t)(t1 % 3) * W_TILE + frag0;
+                    const uint64_t w1src = nxt ? wpj : wp;
                     gsb[0] = uniform64(wp + so2);
                     gsb[1] = uniform64(wp + so2 + 4096);
-                    gsb[2] = uniform64(wp + so1);
-                    gsb[3] = uniform64(wp + so1 + 4096);
+                    gsb[2] = uniform64(w1src + so1);
+                    gsb[3] = uniform64(w1src + so1 + 4096);
                     gld[0] = __builtin_amdgcn_readfirstlane(d2);
                     gld[1] = __builtin_amdgcn_readfirstlane(d2 + 4096);
                     gld[2] = __builtin_amdgcn_readfirstlane(d1);
                     gld[3] = __builtin_amdgcn_readfirstlane(d1 + 4096);
                 }
+                // PROJ, step 48 (no W2 tile): the six free piece slots carry the next item's ctx k-tiles 0..2 (W2 slot 0 is idle: W2(46)
+                // was read in step 47)
+                const bool ctx_pre = PROJ && s == NT && item + (int)gridDim.x < nitems;
+                uint32_t cvn[2] = {0u, 0u};
+                if (ctx_pre) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t rin = (uint32_t)(2 * pair + j) * 16 + (lane_i >> 2);
+                        int rg = (item + (int)gridDim.x) * BM + (int)rin;
+                        rg = rg < M ? rg : M - 1;
+                        cvn[j] = (uint32_t)rg * (D * 2) + (((lane_i & 3) ^ ((rin >> 2) & 3)) << 4);
+                    }
+                }
                 auto piece = [&](auto j_tag) __attribute__((always_inline)) {
                     constexpr int J = decltype(j_tag)::value;      // 0..5: W2, 6..11: W1
                     if (MF2_ABL & 2) return;
+                    if constexpr (PROJ && J < 6) {
+                        if (ctx_pre) {
+                            constexpr int T = J >> 1, JJ = J & 1;
+                            mf_dma1<0>(cvn[JJ], uniform64(ctxb + T * 64),
+                                       __builtin_amdgcn_readfirstlane(lds_base + CTX_OFF + T * CTX_SLOT + (uint32_t)(2 * pair + JJ) * 1024));
+                        }
+                    }
                     if (J < 6 ? !has_w2 : !has_w1) return;
                     constexpr int Q = J % 6, G4 = (J / 6) * 2 + (Q >= 4 ? 1 : 0), OFF = (Q & 3) * 1024;
                     mf_dma1<OFF>(lane16_i, gsb[G4], gld[G4]);
@@ -219,6 +314,119 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 }
             };
+            if constexpr (PROJ) {
+                // ---- projection phase: o^T += Wproj . ctx^T, twelve k-tiles (o already holds x + b_proj + b2)
+                uint32_t cv[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint32_t rin = (uint32_t)(2 * pair + j) * 16 + (lane_i >> 2);
+                    int rg = item * BM + (int)rin;
+                    rg = rg < M ? rg : M - 1;
+                    cv[j] = (uint32_t)rg * (D * 2) + (((lane_i & 3) ^ ((rin >> 2) & 3)) << 4);
+                }
+                const uint32_t cp0 = ctx_frag_addr(lr_i, lh_i);
+#pragma unroll 1
+                for (int kt = 0; kt < NPT; ++kt) {
+                    __builtin_amdgcn_s_barrier();
+                    // k-tile kt + 2 into the slots k-tile kt - 1 has left (tiles 0..2 were issued at the previous item's end)
+                    const bool issue = kt >= 1 && kt + 2 < NPT;
+                    const int t = kt + 2;
+                    const uint32_t so = (uint32_t)t * W_TILE + frag0;
+                    const uint32_t d = lds_base + W1_OFF + (uint32_t)(t % 3) * W_TILE + frag0;
+                    const uint32_t dc = lds_base + CTX_OFF + (uint32_t)(t % 6) * CTX_SLOT + (uint32_t)(2 * pair) * 1024;
+                    const uint64_t gb0 = uniform64(wpj + so), gb1 = uniform64(wpj + so + 4096), cb = uniform64(ctxb + (uint32_t)t * 64);
+                    const uint32_t gl0 = __builtin_amdgcn_readfirstlane(d), gl1 = __builtin_amdgcn_readfirstlane(d + 4096);
+                    const uint32_t cl0 = __builtin_amdgcn_readfirstlane(dc), cl1 = __builtin_amdgcn_readfirstlane(dc + 1024);
+                    auto piece = [&](auto j_tag) __attribute__((always_inline)) {
+                        constexpr int J = decltype(j_tag)::value;      // 0..5: Wproj fragments, 6..7: ctx pieces
+                        if ((MF2_ABL & 2) || !issue) return;
+                        if constexpr (J < 4) mf_dma1<J * 1024>(lane16_i, gb0, gl0);
+                        else if constexpr (J < 6) mf_dma1<(J - 4) * 1024>(lane16_i, gb1, gl1);
+                        else if constexpr (J == 6) mf_dma1<0>(cv[0], cb, cl0);
+                        else if constexpr (J == 7) mf_dma1<0>(cv[1], cb, cl1);
+                    };
+                    const uint32_t cs = (uint32_t)(kt % 6) * CTX_SLOT;
+                    mf2_proj_tile(o, frag_rd_i + W1_OFF + (uint32_t)(kt % 3) * W_TILE, cp0 + cs, (cp0 ^ 32u) + cs, piece);
+                    // k-tile kt + 1 (issued one step ago) has landed; the eight pieces of this step may stay in flight
+                    if (issue) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (wave == 4) MF2_ST(1, item_k, 9);
+                __builtin_amdgcn_s_barrier();      // every wave is done with the projection tiles: both rings are free
+                if (!(MF2_ABL & 2)) {
+                    // the MLP's first tiles, in flight while the rows are normalised: W1(0..2) and W2(0)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint64_t sb = uniform64(wp + (t < 3 ? (uint32_t)t * TILE_BYTES : (uint32_t)W_TILE) + frag0);
+                        const uint32_t ld = __builtin_amdgcn_readfirstlane(lds_base + (t < 3 ? W1_OFF + t * W_TILE : W2_OFF) + frag0);
+                        mf_dma4(lane16_i, sb, ld);
+                        mf_dma1<0>(lane16_i, sb + 4096, ld + 4096);
+                        mf_dma1<1024>(lane16_i, sb + 4096, ld + 4096);
+                    }
+                }
+                // ---- LayerNorm2 of x_mid = o, from the registers (register 8 s2 + j of block db = feature 32 db + 16 s2 + 8 lh + j)
+                {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            sum += ((o[db][8 * h] + o[db][8 * h + 1]) + (o[db][8 * h + 2] + o[db][8 * h + 3])) +
+                                   ((o[db][8 * h + 4] + o[db][8 * h + 5]) + (o[db][8 * h + 6] + o[db][8 * h + 7]));
+                    sum += __shfl_xor(sum, 32);
+                    const float mean = sum * (1.0f / D);
+                    float qv = 0.f;
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            __builtin_amdgcn_sched_barrier(0);      // (192 live accumulators: no room for 192 differences at once)
+                            float part = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float dlt = o[db][4 * q4 + e] - mean;
+                                part = fmaf(dlt, dlt, part);
+                            }
+                            qv += part;
+                        }
+                    qv += __shfl_xor(qv, 32);
+                    const float rstd = 1.0f / sqrtf(qv * (1.0f / D) + p.eps);
+                    float mean_n = mean;      // (opaque copy: otherwise the 192 differences of the variance pass are kept -- in scratch)
+                    asm volatile("" : "+v"(mean_n));
+                    char* const hw = smem + H_OFF + pair * 8192 + lane16_i;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        if (r > 0) __builtin_amdgcn_s_barrier();      // wave A has read the previous round
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) {
+                            __builtin_amdgcn_sched_barrier(0);      // (one k-step at a time: the accumulators leave no room for hoisted loads)
+                            const int k = r * 8 + kk;
+                            const float* gp = sG + k * 16 + lh_i * 8;
+                            const float* bp = sBe + k * 16 + lh_i * 8;
+                            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                            const f32x4 e0 = *reinterpret_cast<const f32x4*>(bp), e1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                            float y[8];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                y[e] = (o[k >> 1][(k & 1) * 8 + e] - mean_n) * rstd * g0[e] + e0[e];
+                                y[4 + e] = (o[k >> 1][(k & 1) * 8 + 4 + e] - mean_n) * rstd * g1[e] + e1[e];
+                            }
+                            uint4 u;
+                            u.x = pack_bf16x2(y[0], y[1]);
+                            u.y = pack_bf16x2(y[2], y[3]);
+                            u.z = pack_bf16x2(y[4], y[5]);
+                            u.w = pack_bf16x2(y[6], y[7]);
+                            *reinterpret_cast<uint4*>(hw + kk * 1024) = u;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (r < 2) __builtin_amdgcn_s_barrier();      // round r is in LDS
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (wave == 4) MF2_ST(1, item_k, 10);
+                __builtin_amdgcn_s_barrier();      // round 2 in LDS; W1(0..2), W2(0) visible
+                if (wave == 4) MF2_ST(1, item_k, 11);
+            }
             step_b(0, std::integral_constant<int, 0>{});
             if (wave == 4) MF2_ST(1, item_k, 2);
 #pragma unroll 1
@@ -245,6 +453,11 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                         a[e] = o[k >> 1][(k & 1) * 8 + e];
                         b[e] = o[k >> 1][(k & 1) * 8 + 4 + e];
                     }
+                    if constexpr (PROJ) {      // (the accumulators started from x + b_proj: LayerNorm2 sees x_mid without the fc2 bias)
+                        const float* fp = reinterpret_cast<const float*>(smem + BP_OFF) + k * 16 + lh_i * 8;
+                        a += *reinterpret_cast<const f32x4*>(fp);
+                        b += *reinterpret_cast<const f32x4*>(fp + 4);
+                    }
                     *reinterpret_cast<f32x4*>(xrow + k * 16) = a;
                     *reinterpret_cast<f32x4*>(xrow + k * 16 + 4) = b;
                 }
@@ -267,25 +480,8 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
     bf16x8 xn[NKS];
     f32x16 sa, sb;
 
-    // LayerNorm2 of this lane's half row -> xn (B-operand fragments, k = 16 s + 8 lh + j), then S(0) (compiler-scheduled)
-    auto prologue = [&](int item) __attribute__((always_inline)) {
-        int lane_p = tid & 63;
-        asm volatile("" : "+v"(lane_p));
-        const int lr = lane_p & 31, lh = lane_p >> 5;
-        const int row = item * BM + pair * 32 + lr;
-        const int row_c = row < M ? row : M - 1;
-        const float* const xrow = p.X + (long)row_c * D + lh * 8;
-        f32x4 x[2 * NKS];
-#pragma unroll
-        for (int k = 0; k < NKS; ++k) {
-            if (MF2_ABL & 32) {
-                x[2 * k] = f32x4{1.f, 2.f, (float)k, (float)lane_p};
-                x[2 * k + 1] = x[2 * k];
-            } else {
-                x[2 * k] = *reinterpret_cast<const f32x4*>(xrow + k * 16);
-                x[2 * k + 1] = *reinterpret_cast<const f32x4*>(xrow + k * 16 + 4);
-            }
-        }
+    // LayerNorm2 of this lane's half row (x[2k], x[2k+1] = features 16 k + 8 lh + 0..7) -> xn (B-operand fragments, k = 16 s + 8 lh + j)
+    auto layernorm = [&](const f32x4 (&x)[2 * NKS], int lh) __attribute__((always_inline)) {
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < 2 * NKS; k += 2) sum += ((x[k][0] + x[k][1]) + (x[k][2] + x[k][3])) + ((x[k + 1][0] + x[k + 1][1]) + (x[k + 1][2] + x[k + 1][3]));
@@ -327,9 +523,11 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
             u.w = pack_bf16x2(y[6], y[7]);
             xn[k] = __builtin_bit_cast(bf16x8, u);
         }
-        // S(0): accumulators start from b1 (tile 0), fragments from W1 ring slot 0
+    };
+    // S(0): accumulators start from b1 (tile 0), fragments from W1 ring slot 0 (compiler-scheduled)
+    auto s_zero = [&](int lane_p) __attribute__((always_inline)) {
         f32x16 s;
-        const float* bp = sB1 + kc;
+        const float* bp = sB1 + (lane_p >> 5) * 8;
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(bp), c1 = *reinterpret_cast<const f32x4*>(bp + 4);
         const f32x4 c2 = *reinterpret_cast<const f32x4*>(bp + 16), c3 = *reinterpret_cast<const f32x4*>(bp + 20);
 #pragma unroll
@@ -345,7 +543,28 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         return s;
     };
-
+    // (not PROJ) rows from global -> LayerNorm -> S(0)
+    auto prologue = [&](int item) __attribute__((always_inline)) {
+        int lane_p = tid & 63;
+        asm volatile("" : "+v"(lane_p));
+        const int lr = lane_p & 31, lh = lane_p >> 5;
+        const int row = item * BM + pair * 32 + lr;
+        const int row_c = row < M ? row : M - 1;
+        const float* const xrow = p.X + (long)row_c * D + lh * 8;
+        f32x4 x[2 * NKS];
+#pragma unroll
+        for (int k = 0; k < NKS; ++k) {
+            if (MF2_ABL & 32) {
+                x[2 * k] = f32x4{1.f, 2.f, (float)k, (float)lane_p};
+                x[2 * k + 1] = x[2 * k];
+            } else {
+                x[2 * k] = *reinterpret_cast<const f32x4*>(xrow + k * 16);
+                x[2 * k + 1] = *reinterpret_cast<const f32x4*>(xrow + k * 16 + 4);
+            }
+        }
+        layernorm(x, lh);
+        return s_zero(lane_p);
+    };
     // ---- the GELU of S(s), spread over the 24 MFMA gaps of the step (+ a tail slot): element n (accumulator register n) starts
     // at slot (14 n) / 15 and issues instruction i of gelu_fast (common.h) at slot start + i; odd elements pack a dword at + 10
     float ex[16], ea[16], eb[16], ec[16];
@@ -378,7 +597,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
     };
 
     if (wave == 0) MF2_ST(0, 0, 15);
-    sa = prologue(blockIdx.x);
+    if constexpr (!PROJ) sa = prologue(blockIdx.x);
     int item_k = 0;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++item_k) {
         if (wave == 0) MF2_ST(0, item_k, 0);
@@ -390,6 +609,22 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         char* const p_wr = smem + P_OFF + pair * 4096 + lane16_i;
         const float* const b1_lane_p = sB1 + attn::sigma23((int)(lane_i & 31));     // + HT * tile: b1 of MFMA A row lr
         const uint4 ones_u = {lh_i == 0 ? 0x3F803F80u : 0u, lh_i == 0 ? 0x00003F80u : 0u, 0u, 0u};     // k = 0, 1, 2 are 1.0
+        if constexpr (PROJ) {
+            // ---- wave B projects and normalises (12 + 1 barriers); xn arrives in three rounds of eight fragments; then S(0)
+#pragma unroll 1
+            for (int kt = 0; kt <= NPT; ++kt) __builtin_amdgcn_s_barrier();
+            const char* const hr = smem + H_OFF + pair * 8192 + lane16_i;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                __builtin_amdgcn_s_barrier();      // round r is in LDS (the last one: with W1(0..2), W2(0))
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) xn[r * 8 + kk] = lds_frag(hr + kk * 1024);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (r < 2) __builtin_amdgcn_s_barrier();      // read: wave B may write the next round
+            }
+            sa = s_zero((int)lane_i);
+            if (wave == 0) MF2_ST(0, item_k, 10);
+        }
 
         // tile step s: S(s+1) (unless LAST) || GELU of S(s) -> P(s) into the pair's LDS buffer s & 1
         auto step_a = [&](f32x16& s_cur, f32x16& s_nxt, int s, auto last_tag) __attribute__((always_inline)) {
@@ -456,16 +691,44 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         if (wave == 0) MF2_ST(0, item_k, 5);
         __builtin_amdgcn_s_barrier();      // step 48: wave B's last tile; this wave already works on the next item
         if (wave == 0) MF2_ST(0, item_k, 6);
-        if (item + (int)gridDim.x < nitems) sa = prologue(item + gridDim.x);
+        if constexpr (!PROJ)
+            if (item + (int)gridDim.x < nitems) sa = prologue(item + gridDim.x);
         if (wave == 0) MF2_ST(0, item_k, 7);
     }
+}
+
+// Wproj [384 out][384 in] fp32 -> bf16 fragments [k-tile kt][fragment db * 2 + s2][lane][8]: the fc2 fragment format of pack_mlp with
+// the 32 input features of k-tile kt in the place of a hidden tile (A row = output feature 32 db + sigma23(lane & 31))
+__global__ __launch_bounds__(256) void pack_proj_kernel(const float* __restrict__ W, bf16_t* __restrict__ dst) {
+    using namespace mf2;
+    const int total = NPT * NKS * 512;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int t = idx;
+        const int e = t & 7; t >>= 3;
+        const int lane = t & 63; t >>= 6;
+        const int frag = t % NKS, kt = t / NKS;
+        const int i = attn::sigma23(lane & 31), h = lane >> 5, db = frag >> 1, s2 = frag & 1;
+        dst[idx] = (bf16_t)(pack_bf16x2(W[(long)(db * 32 + i) * D + kt * 32 + s2 * 16 + h * 8 + e], 0.f) & 0xFFFF);
+    }
+}
+long mlp_fused_proj_pack_elems(int Dm) { return Dm == mf2::D ? (long)mf2::NPT * mf2::W_TILE / 2 : 0; }
+int launch_pack_proj(const float* W, int Dm, bf16_t* dst, hipStream_t s) {
+    if (Dm != mf2::D) {
+        dinoseg_set_error("pack_proj: unsupported width %d", Dm);
+        return -1;
+    }
+    hipLaunchKernelGGL(pack_proj_kernel, dim3(144), dim3(256), 0, s, W, dst);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s) {
     static PerDeviceOnce once;
     if (once.first()) {
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           mf2::LDS_BYTES));
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, mf2::LDS_BYTES));
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, mf2::LDS_BYTES));
         once.mark();
     }
     if (p.M <= 0 || p.ldx != mf2::D) {
@@ -486,7 +749,15 @@ int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s) {
     DSEG_CHECK_HIP(hipMemsetAsync(sbuf, 0, sbytes, s));
     q.queue = reinterpret_cast<int*>(sbuf);
 #endif
-    hipLaunchKernelGGL(mlp_fused2_kernel, dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
+    if (p.ctx) {
+        if (!p.Wproj || !p.bproj) {
+            dinoseg_set_error("mlp_fused2: ctx without the packed projection weight / bias");
+            return -1;
+        }
+        hipLaunchKernelGGL(mlp_fused2_kernel<true>, dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
+    } else {
+        hipLaunchKernelGGL(mlp_fused2_kernel<false>, dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
+    }
     DSEG_CHECK_HIP(hipGetLastError());
 #if MF2_STAMP
     {

@@ -228,6 +228,18 @@ int dinoseg_op_pack_mlp(const float* W1, const float* W2, int32_t D, int32_t F, 
 int dinoseg_op_mlp_fused(float* X, const float* gamma, const float* beta, float eps, const void* Wp, const float* b1,
                          const float* b2, int32_t M, int32_t D, int32_t F, void* stream);
 
+/* The same launch with the block's attention output projection in front (role-split kernel only):
+ *     X += ctx . Wproj^T + bproj;   X += fc2(gelu(fc1(LayerNorm(X))))
+ * = Attention.forward's `x = self.proj(x)` + Block.forward's two residual adds (vision_transformer.py:104-105, :123, :135).
+ * ctx: bf16 [M, 384] (the attention output, row stride 384); Wproj: the [384, 384] weight re-packed by dinoseg_op_pack_proj
+ * (dinoseg_op_proj_pack_elems(D) bf16 elements; 0 = unsupported width).  Library option "proj_fused" (default 1) makes
+ * dinoseg_forward use it wherever the fused MLP runs. */
+int64_t dinoseg_op_proj_pack_elems(int32_t D);
+int dinoseg_op_pack_proj(const float* W, int32_t D, void* dst, void* stream);
+int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* Wproj, const float* bproj, const float* gamma,
+                              const float* beta, float eps, const void* Wp, const float* b1, const float* b2, int32_t M,
+                              int32_t D, int32_t F, void* stream);
+
 /* fused softmax(q k^T) v (vision_transformer.py:85,101,104); q must be pre-scaled by 64^-0.5 * log2(e).
  * q, k, v: [planes][B,heads,npad,64] (rows >= ntok zero); ctx: bf16 planes [planes][B*ntok][heads*64];
  * lse (optional): fp32 [B,heads,ntok], log2 domain. */

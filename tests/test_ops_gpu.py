@@ -485,3 +485,54 @@ def test_mlp_fused(cuda, M_, variant):
     assert err <= 2.0 ** -9 * scale + 1e-3, (err, scale)
     # and the update is not a near-miss of something else: it carries the whole MLP term
     assert float((got - X).abs().max()) > 0.5 * scale
+
+
+@pytest.mark.parametrize("M_", [128, 77, 128 * 5 + 33, 128 * 300 + 19])
+def test_proj_mlp_fused(cuda, M_):
+    """The attention output projection + the MLP half of a block in ONE launch (mlp_fused2.hip, PROJ):
+        x += ctx . Wproj^T + bproj;   x += fc2(gelu(fc1(LayerNorm(x))))      (vision_transformer.py:104-105, :123, :135)
+    against fp64 on the operands the kernel sees (bf16 ctx / weights, bf16 LayerNorm and GELU outputs), and against the two-launch
+    path it replaces (dinoseg_op_gemm EPI_RESID, then dinoseg_op_mlp_fused).  M = 38 419: more items than CUs (the projection
+    k-tiles and ctx tiles of the next item are prefetched across the item boundary); 77 / 673: ragged last item (clamped rows)."""
+    D_, F_ = 384, 1536
+    X = seeded((M_, D_), 41) * 1.7 + 0.4 + torch.arange(D_, device="cuda", dtype=torch.float32)[None, :] * 1e-3
+    ctx = quant_like(seeded((M_, D_), 48) * 0.8, 1)
+    Wpr = seeded((D_, D_), 49) * 0.07 + torch.arange(D_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    bpr = seeded((D_,), 50) * 0.3
+    gam, bet = 1 + 0.2 * seeded((D_,), 42), 0.1 * seeded((D_,), 43)
+    W1 = seeded((F_, D_), 44) * 0.06 + torch.arange(F_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    b1 = seeded((F_,), 45) * 0.5
+    W2 = seeded((D_, F_), 46) * 0.04 + torch.arange(D_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    b2 = seeded((D_,), 47)
+    lib = capi.lib()
+    Wp = pack_mlp(W1, W2)
+    n = lib.dinoseg_op_proj_pack_elems(D_)
+    assert n == D_ * D_
+    Wprp = torch.empty((n,), dtype=torch.int16, device="cuda")
+    capi.check(lib.dinoseg_op_pack_proj(Wpr.data_ptr(), D_, Wprp.data_ptr(), S()))
+    ctx_b = pack(ctx, 1)          # bf16 [1][M][D]
+    got = X.clone()
+    capi.check(lib.dinoseg_op_proj_mlp_fused(got.data_ptr(), ctx_b.data_ptr(), Wprp.data_ptr(), bpr.data_ptr(), gam.data_ptr(),
+                                             bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), M_, D_, F_, S()))
+    torch.cuda.synchronize()
+    # fp64 on the kernel's operands
+    xmid = X.double() + ctx.double() @ quant_like(Wpr, 1).double().t() + bpr.double()
+    A = quant_like(_ln_ref(xmid.float(), gam, bet).cuda(), 1).double()
+    z = A @ quant_like(W1, 1).double().t() + b1.double()
+    Hq = quant_like(O.gelu_erf(z.float().cpu()).cuda(), 1).double()
+    delta = Hq @ quant_like(W2, 1).double().t() + b2.double()
+    want = (xmid + delta).float()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    scale = float(delta.abs().max())
+    assert err <= 2.0 ** -9 * scale + 1e-3, (err, scale)
+    assert float((got - X).abs().max()) > 0.5 * scale
+    # the two launches it replaces
+    two = X.clone()
+    Wq = pack(Wpr, 1)
+    capi.check(lib.dinoseg_op_gemm(ctx_b.data_ptr(), M_ * D_, D_, Wq.data_ptr(), D_ * D_, M_, D_, D_, 1, capi.EPI_RESID, bpr.data_ptr(),
+                                   two.data_ptr(), None, 0, D_, S()))
+    capi.check(lib.dinoseg_op_mlp_fused(two.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(), b2.data_ptr(),
+                                        M_, D_, F_, S()))
+    torch.cuda.synchronize()
+    assert float((got - two).abs().max()) <= 2.0 ** -9 * scale + 1e-3

@@ -1,5 +1,6 @@
 """GPU box: time the fused MLP operator alone: python tools/bench_mlp.py [rows] [iters] [variant]
-(variant 1 = mlp_fused.hip, 2 = mlp_fused2.hip; DINOSEG_LIB selects the build for A/B runs of ablation variants)."""
+(variant 1 = mlp_fused.hip, 2 = mlp_fused2.hip, 3 = mlp_fused2.hip with the attention output projection in the same launch, 0 = the
+separate projection GEMM (dinoseg_op_gemm EPI_RESID); DINOSEG_LIB selects the build for A/B runs of ablation variants)."""
 import os
 import sys
 
@@ -23,14 +24,32 @@ S = capi.stream_ptr
 capi.check(capi.lib().dinoseg_op_pack_mlp(W1.data_ptr(), W2.data_ptr(), D, F, Wp.data_ptr(), S()))
 
 
+from tests.gpu_util import pack  # noqa: E402
+ctx = pack(seeded((M, D), 8) * 0.5, 1)
+Wpr, bpr = seeded((D, D), 9) * 0.01, seeded((D,), 10) * 0.01
+Wprp = torch.empty((capi.lib().dinoseg_op_proj_pack_elems(D),), dtype=torch.int16, device="cuda")
+capi.check(capi.lib().dinoseg_op_pack_proj(Wpr.data_ptr(), D, Wprp.data_ptr(), S()))
+Wq = pack(Wpr, 1)
+mode = 2
+
+
 def run():
-    capi.check(capi.lib().dinoseg_op_mlp_fused(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(),
-                                               b2.data_ptr(), M, D, F, S()))
+    lib = capi.lib()
+    if mode == 3:
+        capi.check(lib.dinoseg_op_proj_mlp_fused(X.data_ptr(), ctx.data_ptr(), Wprp.data_ptr(), bpr.data_ptr(), gam.data_ptr(),
+                                                 bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), M, D, F, S()))
+    elif mode == 0:
+        capi.check(lib.dinoseg_op_gemm(ctx.data_ptr(), M * D, D, Wq.data_ptr(), D * D, M, D, D, 1, capi.EPI_RESID, bpr.data_ptr(),
+                                       X.data_ptr(), None, 0, D, S()))
+    else:
+        capi.check(lib.dinoseg_op_mlp_fused(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(),
+                                            b2.data_ptr(), M, D, F, S()))
 
 
 for rep in range(2):
     for v in variants:
-        capi.check(capi.lib().dinoseg_set_option(b"mlp_variant", v))
+        mode = v
+        capi.check(capi.lib().dinoseg_set_option(b"mlp_variant", 1 if v == 1 else 2))
         for _ in range(5):
             run()
         torch.cuda.synchronize()
