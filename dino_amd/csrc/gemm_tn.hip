@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_tn_kernel(TnP
                 const int c = swz(row, slot);              // logical chunk stored in physical slot `slot`
                 int gm = chunk * BMr + row;
                 gm = gm < M ? gm : M - 1;                  // rows >= M are zeroed at fragment level (ragged last chunk)
-                glds16(p.Y + pl * p.y_plane + (long)gm * p.ldy + n0 + c * 8, sbase + (pl * 2 + 0) * TILE + piece * 1024);
+                // (a dY narrower than the 128-column tile -- the classifier's 64-column d logits -- repeats its last 8 columns: they
+                //  only feed output rows >= N, which are not written)
+                const int yc = n0 + c * 8 <= p.ldy - 8 ? n0 + c * 8 : p.ldy - 8;
+                glds16(p.Y + pl * p.y_plane + (long)gm * p.ldy + yc, sbase + (pl * 2 + 0) * TILE + piece * 1024);
                 glds16(p.X + pl * p.x_plane + (long)gm * p.ldx + k0 + c * 8, sbase + (pl * 2 + 1) * TILE + piece * 1024);
             }
     };

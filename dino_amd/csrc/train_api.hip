@@ -579,8 +579,26 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
     // weight gradient straight from the row-major dY and layer-input planes (gemm_tn.hip): no operand transposes
     // dbias (optional): the layer's bias gradient = column sums of Y, taken inside the weight-gradient kernel; when that kernel
     // does not run (frozen weight, narrow layer) a pack pass over Y produces them
+    // k_pad (optional): the stored width of X when that is a multiple of 128 and k_cols is not (the classifier's zero-padded hidden
+    // activations): the kernel multiplies all k_pad columns, the reduce writes the first k_cols
     auto wgrad_tn = [&](const bf16_t* Y, long y_plane, int ldy, const bf16_t* X, long x_plane, int ldx, int m_rows, int n_rows,
-                        int k_cols, int planes, float* dW, float* dbias, hipStream_t s) -> int {
+                        int k_cols, int planes, float* dW, float* dbias, hipStream_t s, int k_pad = 0) -> int {
+        if (k_pad > 0 && k_pad % 128 == 0 && k_pad <= ldx) {
+            if (!dW && !dbias) return 0;
+            TnParams g = {};
+            g.Y = Y; g.y_plane = y_plane; g.ldy = ldy; g.X = X; g.x_plane = x_plane; g.ldx = ldx;
+            g.M = m_rows; g.N = n_rows; g.Kc = k_pad; g.planes = planes;
+            const int row_tiles = (n_rows + 127) / 128, tiles = row_tiles * (k_pad / 128), nchunks = (m_rows + 63) / 64;
+            int ks = splitk_budget() / tiles;
+            if (ks > nchunks / 2) ks = nchunks / 2;
+            if (ks < 1) ks = 1;
+            const int per = (nchunks + ks - 1) / ks, used = (nchunks + per - 1) / per;
+            g.part = F32(L.SPLITK); g.ld_part = k_pad; g.split_stride = (long)row_tiles * 128 * k_pad; g.ksplit = ks;
+            g.colsum = dbias;
+            DSEG_TRY(launch_gemm_tn(g, s));
+            if (!dW) return 0;
+            return launch_splitk_reduce(g.part, used, g.split_stride, n_rows, k_pad, dW, k_cols, k_cols, s);
+        }
         if (dbias && (!dW || k_cols % 128 != 0))
             DSEG_TRY(launch_transpose_planes(nullptr, Y, y_plane, ldy, m_rows, n_rows, nullptr, 0, pad128(n_rows), L.Mpad, nullptr, 0, 0,
                                              dbias, planes, 0, 0, s));
@@ -616,34 +634,37 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
     float* dA = F32(L.dA);
     bf16_t* G = B16(L.G);
     if (mlp_head) {
-        // layer_3: z = h2 W3^T + b3
-        DSEG_TRY(launch_transpose_planes(nullptr, DZ, L.dz_plane, 64, L.Mp, C, T1, tpl, 128, L.Mppad, nullptr, 0, 0,
-                                         grad("clf.layer_3.bias") ? grad("clf.layer_3.bias") : nullptr, HP, 0, 0, s));
-        DSEG_TRY(launch_transpose_planes(nullptr, H2, L.h2_plane, 128, L.Mp, 128, T2, tpl, 128, L.Mppad, nullptr, 0, 0, nullptr, HP, 0, 0, s));
-        DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, C, 128, 100, HP, grad("clf.layer_3.weight")));
+        // layer_3: z = h2 W3^T + b3      (weight and bias gradients straight from the row-major planes: gemm_tn.hip; h2 / h1 are stored
+        // 128 / 256 wide, zero beyond their 100 / 200 columns)
+        DSEG_TRY(wgrad_tn(DZ, L.dz_plane, 64, H2, L.h2_plane, 128, L.Mp, C, 100, HP, grad("clf.layer_3.weight"), grad("clf.layer_3.bias"), s, 128));
         bf16_t* dH2 = G;                         // [HP][Mp][128]
         const long dh2_plane = (long)L.Mp * 128;
         DSEG_TRY(dgrad(DZ, L.dz_plane, 64, L.Mp, 64, tw.at("clf.layer_3.weight"), 128, HP, EPI_DRELU, nullptr, dH2, dh2_plane, H2, L.h2_plane));
         // layer_2
-        DSEG_TRY(launch_transpose_planes(nullptr, dH2, dh2_plane, 128, L.Mp, 100, T1, tpl, 128, L.Mppad, nullptr, 0, 0,
-                                         grad("clf.layer_2.bias"), HP, 0, 0, s));
-        DSEG_TRY(launch_transpose_planes(nullptr, H1, L.h1_plane, 256, L.Mp, 256, T2, tpl, 256, L.Mppad, nullptr, 0, 0, nullptr, HP, 0, 0, s));
-        DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, 100, 256, 200, HP, grad("clf.layer_2.weight")));
+        DSEG_TRY(wgrad_tn(dH2, dh2_plane, 128, H1, L.h1_plane, 256, L.Mp, 100, 200, HP, grad("clf.layer_2.weight"), grad("clf.layer_2.bias"), s, 256));
         bf16_t* dH1 = B16(L.dCTX);               // [HP][Mp][256] fits: Mp*256 <= M*D
         const long dh1_plane = (long)L.Mp * 256;
         DSEG_TRY(dgrad(dH2, dh2_plane, 128, L.Mp, 128, tw.at("clf.layer_2.weight"), 256, HP, EPI_DRELU, nullptr, dH1, dh1_plane, H1, L.h1_plane));
         // layer_1
-        DSEG_TRY(launch_transpose_planes(nullptr, dH1, dh1_plane, 256, L.Mp, 200, T1, tpl, 256, L.Mppad, nullptr, 0, 0,
-                                         grad("clf.layer_1.bias"), HP, 0, 0, s));
-        DSEG_TRY(launch_transpose_planes(nullptr, FEAT, L.feat_plane, D, L.Mp, D, T2, tpl, pad128(D), L.Mppad, nullptr, 0, 0, nullptr, HP, 0, 0, s));
-        DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, 200, pad128(D), D, HP, grad("clf.layer_1.weight")));
+        if (D % 128 == 0) {
+            DSEG_TRY(wgrad_tn(dH1, dh1_plane, 256, FEAT, L.feat_plane, D, L.Mp, 200, D, HP, grad("clf.layer_1.weight"), grad("clf.layer_1.bias"), s, D));
+        } else {
+            DSEG_TRY(launch_transpose_planes(nullptr, dH1, dh1_plane, 256, L.Mp, 200, T1, tpl, 256, L.Mppad, nullptr, 0, 0,
+                                             grad("clf.layer_1.bias"), HP, 0, 0, s));
+            DSEG_TRY(launch_transpose_planes(nullptr, FEAT, L.feat_plane, D, L.Mp, D, T2, tpl, pad128(D), L.Mppad, nullptr, 0, 0, nullptr, HP, 0, 0, s));
+            DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, 200, pad128(D), D, HP, grad("clf.layer_1.weight")));
+        }
         if (backbone)
             DSEG_TRY(dgrad(dH1, dh1_plane, 256, L.Mp, 256, tw.at("clf.layer_1.weight"), D, HP, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
     } else {
-        DSEG_TRY(launch_transpose_planes(nullptr, DZ, L.dz_plane, 64, L.Mp, C, T1, tpl, 128, L.Mppad, nullptr, 0, 0,
-                                         grad("clf.layer_1.bias"), HP, 0, 0, s));
-        DSEG_TRY(launch_transpose_planes(nullptr, FEAT, L.feat_plane, D, L.Mp, D, T2, tpl, pad128(D), L.Mppad, nullptr, 0, 0, nullptr, HP, 0, 0, s));
-        DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, C, pad128(D), D, HP, grad("clf.layer_1.weight")));
+        if (D % 128 == 0) {
+            DSEG_TRY(wgrad_tn(DZ, L.dz_plane, 64, FEAT, L.feat_plane, D, L.Mp, C, D, HP, grad("clf.layer_1.weight"), grad("clf.layer_1.bias"), s, D));
+        } else {
+            DSEG_TRY(launch_transpose_planes(nullptr, DZ, L.dz_plane, 64, L.Mp, C, T1, tpl, 128, L.Mppad, nullptr, 0, 0,
+                                             grad("clf.layer_1.bias"), HP, 0, 0, s));
+            DSEG_TRY(launch_transpose_planes(nullptr, FEAT, L.feat_plane, D, L.Mp, D, T2, tpl, pad128(D), L.Mppad, nullptr, 0, 0, nullptr, HP, 0, 0, s));
+            DSEG_TRY(wgrad(T1, T2, tpl, L.Mppad, C, pad128(D), D, HP, grad("clf.layer_1.weight")));
+        }
         if (backbone)
             DSEG_TRY(dgrad(DZ, L.dz_plane, 64, L.Mp, 64, tw.at("clf.layer_1.weight"), D, HP, EPI_PLAIN, dA, nullptr, 0, nullptr, 0));
     }
