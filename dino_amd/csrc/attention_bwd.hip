@@ -43,31 +43,58 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
                                                             long plane, int planes, const float* __restrict__ lse, int B,
                                                             int heads, int ntok, int npad, float* __restrict__ neg_lse,
                                                             float* __restrict__ neg_delta) {
-    const int lane = threadIdx.x & 63;
+    // a wave takes 8 consecutive rows of one (frame, head): lane = 8 * row + 16-byte chunk of the row's 64 head dimensions
+    // (the first version gave a whole wave one 128-byte row: 39 us per layer at 8 frames, nearly all of it waiting)
+    const int lane = threadIdx.x & 63, rr = lane >> 3, ch = lane & 7;
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long total = (long)B * heads * npad;
+    const int groups = npad / 8;                                   // npad % 64 == 0
+    const long total = (long)B * heads * groups;
     if (wid >= total) return;
-    const long pair = wid / npad;
-    const int q = (int)(wid - pair * npad);
+    const long pair = wid / groups;
+    const int q = (int)(wid - pair * groups) * 8 + rr;
+    const long out = pair * npad + q;
     if (q >= ntok) {
-        if (lane == 0) {
-            neg_lse[wid] = -INFINITY;
-            neg_delta[wid] = 0.f;
+        if (ch == 0) {
+            neg_lse[out] = -INFINITY;
+            neg_delta[out] = 0.f;
         }
         return;
     }
     const long b = pair / heads;
     const int head = (int)(pair - b * heads);
-    const long off = (b * ntok + q) * (long)(heads * 64) + head * 64 + lane;
-    float a = bf16_to_f32(dO[off]), o = bf16_to_f32(O[off]);
-    if (planes == 2) {
-        a += bf16_to_f32(dO[plane + off]);
-        o += bf16_to_f32(O[plane + off]);
+    const long off = (b * ntok + q) * (long)(heads * 64) + head * 64 + ch * 8;
+    float a[8], o[8];
+    {
+        const uint4 ua = *reinterpret_cast<const uint4*>(dO + off), uo = *reinterpret_cast<const uint4*>(O + off);
+        const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wo[4] = {uo.x, uo.y, uo.z, uo.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[2 * i] = __uint_as_float(wa[i] << 16);
+            a[2 * i + 1] = __uint_as_float(wa[i] & 0xFFFF0000u);
+            o[2 * i] = __uint_as_float(wo[i] << 16);
+            o[2 * i + 1] = __uint_as_float(wo[i] & 0xFFFF0000u);
+        }
     }
-    const float s = wave_sum(a * o);
-    if (lane == 0) {
-        neg_lse[wid] = -lse[pair * ntok + q];
-        neg_delta[wid] = -s;
+    if (planes == 2) {
+        const uint4 ua = *reinterpret_cast<const uint4*>(dO + plane + off), uo = *reinterpret_cast<const uint4*>(O + plane + off);
+        const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wo[4] = {uo.x, uo.y, uo.z, uo.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[2 * i] += __uint_as_float(wa[i] << 16);
+            a[2 * i + 1] += __uint_as_float(wa[i] & 0xFFFF0000u);
+            o[2 * i] += __uint_as_float(wo[i] << 16);
+            o[2 * i + 1] += __uint_as_float(wo[i] & 0xFFFF0000u);
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum = fmaf(a[i], o[i], sum);
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    if (ch == 0) {
+        neg_lse[out] = -lse[pair * ntok + q];
+        neg_delta[out] = -sum;
     }
 }
 
@@ -425,8 +452,8 @@ static int launch_bwd(const AttnBwdParams& p, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
         once.mark();
     }
-    const long rows = (long)p.B * p.heads * p.npad;
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p.dO, p.O, p.dO_plane, PLANES,
+    const long row_groups = (long)p.B * p.heads * (p.npad / 8);      // 8 rows per wave, 4 waves per block
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, p.dO, p.O, p.dO_plane, PLANES,
                        p.lse, p.B, p.heads, p.ntok, p.npad, p.neg_lse, p.neg_delta);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<PLANES>), dim3(grid), dim3(256), lds_dq, s, p);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<PLANES>), dim3(grid), dim3(256), lds_dkv, s, p);
