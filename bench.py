@@ -318,6 +318,10 @@ def main():
         key, val = kv.split("=")
         capi.check(capi.lib().dinoseg_set_option(key.encode(), int(val)))
     if a.mode == "finetune":
+        if rehearsal and world > 1 and not any(kv.startswith("train_streams=") for kv in a.option):
+            # several processes on ONE device oversubscribe its hardware queues once each of them runs a side stream (measured:
+            # 35 ms per step on one stream, 160-2000 ms with the side stream); one process per GPU -- the real layout -- keeps it
+            capi.check(capi.lib().dinoseg_set_option(b"train_streams", 1))
         return bench_finetune(a, world, rank, dev, rehearsal)
     base = VIT_S8 if a.arch == "vit_small" else VIT_B8
     cfg = ViTConfig(embed_dim=base.embed_dim, num_heads=base.num_heads, n_blocks=a.blocks)

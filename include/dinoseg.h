@@ -179,6 +179,13 @@ int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
  *   "gemm_ln"    1 [default] = qkv / fc1 through the LayerNorm-fused kernels where measured faster, 0 never, 2 wherever supported;
  *   "mlp_fused"  1 [default] = the MLP half of a block (LayerNorm2, fc1, GELU, fc2, residual) as ONE launch where it applies (bf16
  *                mode, embed_dim 384, batches of >= 8 frames at 480x480), 0 never, 2 wherever the shape allows;
+ *   "proj_fused" 1 [default] = where that launch runs, it also carries the block's attention output projection + residual
+ *                (x += proj(ctx) + b first: vision_transformer.py:104-105), 0 = the projection stays a GEMM launch of its own;
+ *   "mlp_variant" 2 [default] = the role-split build of the fused MLP kernel (mlp_fused2.hip), 1 = one wave per SIMD (mlp_fused.hip);
+ *   "train_streams" 2 [default] = dinoseg_backward / dinoseg_train_step run the blocks' weight-gradient GEMMs on an internal stream
+ *                beside the input-gradient chain (forked from / joined to the caller's stream by events: stream-ordered, capturable),
+ *                1 = everything on the caller's stream (use it when several processes share one GPU);
+ *   "splitk_tiles" 512 [default]: partial 128x128 tiles of one weight-gradient GEMM (<= 768);
  *   "attn_variant", "gemm_dbg", "attn_dbg": kernel A/B and timing-ablation switches (tools/bench_ops.py). */
 int dinoseg_set_option(const char* key, int32_t value);
 

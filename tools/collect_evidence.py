@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "ev_r03")
 DST = os.path.join(ROOT, "profiles")
 lines = []
-for name in ("headline", "parity", "960", "vitb", "finetune_bf16", "finetune_bf16x3", "L3", "one_stream", "unfused_mlp", "rehearsal2", "rehearsal2_finetune"):
+for name in ("headline", "parity", "960", "vitb", "finetune_bf16", "finetune_bf16x3", "L3", "one_stream", "unfused_mlp", "unfused_proj", "rehearsal2", "rehearsal2_finetune"):
     p = os.path.join(SRC, f"bench_{name}.json")
     if os.path.exists(p):
         txt = [l for l in open(p).read().strip().splitlines() if l.startswith("{")]

@@ -14,6 +14,7 @@ python3 bench.py --config finetune --precision bf16x3 --steps 6 --warmup 2 > $OU
 python3 bench.py --blocks 3 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode > $OUT/bench_L3.json 2>/dev/null
 python3 bench.py --streams 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode > $OUT/bench_one_stream.json 2>/dev/null
 python3 bench.py --option mlp_fused=0 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode > $OUT/bench_unfused_mlp.json 2>/dev/null
+python3 bench.py --option proj_fused=0 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode > $OUT/bench_unfused_proj.json 2>/dev/null
 python3 bench.py --gpus 2 --steps 6 --warmup 2 --no-cpu-baseline --no-parity-mode > $OUT/bench_rehearsal2.json 2>$OUT/bench_rehearsal2.err
 python3 bench.py --gpus 2 --config finetune --steps 4 --warmup 2 > $OUT/bench_rehearsal2_finetune.json 2>$OUT/bench_rehearsal2_finetune.err
 for f in $OUT/bench_*.json; do echo "== $f"; tail -1 $f | cut -c1-260; done
