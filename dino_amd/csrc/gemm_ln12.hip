@@ -434,7 +434,10 @@ static int launch_ln12(const LnGemmParams& p, hipStream_t s) {
 #ifdef LN12_MAXGRID      // experiment: the same per-workgroup work on fewer CUs
     const int grid = npanels < LN12_MAXGRID ? npanels : LN12_MAXGRID;
 #else
-    const int grid = npanels < ncu ? npanels : ncu;
+    // as few workgroups as finish in the same number of rounds (901 panels: 226 instead of 256): the rest of the chip is the other
+    // stream's (mlp_fused2.hip does the same)
+    const int rounds = (npanels + ncu - 1) / ncu;
+    const int grid = (npanels + rounds - 1) / rounds;
 #endif
     if (p.dbg) hipLaunchKernelGGL((gemm_ln12_kernel<EPI, true>), dim3(grid), dim3(ln12::THREADS), ln12::LDS_BYTES, s, p);
     else hipLaunchKernelGGL((gemm_ln12_kernel<EPI, false>), dim3(grid), dim3(ln12::THREADS), ln12::LDS_BYTES, s, p);

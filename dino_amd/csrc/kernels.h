@@ -96,7 +96,7 @@ struct Options {
     int attn_dbg = 0;        // same for AttnParams::dbg
     int mlp_fused = 1;       // the MLP half of a block as one launch (mlp_fused.hip): 0 never, 1 for >= mlp_fused_min_rows rows, 2 wherever supported
     int mlp_fused_min_rows = 24000;
-    int mlp_grid = 0;        // experiment: workgroups of the fused MLP launch (0 = one per CU)
+    int mlp_grid = 0;        // workgroups of the fused MLP launch (0 = the fewest that need no extra round: mlp_fused2.hip)
     int proj_fused = 1;      // 1: with mlp_variant 2 the block's attention output projection runs inside the fused MLP launch
     int mlp_variant = 2;     // 1: mlp_fused.hip (one wave per SIMD), 2: mlp_fused2.hip (role-split wave pairs)
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
