@@ -81,6 +81,10 @@ SIGNATURES = {
     "dinoseg_op_mlp_fused_pack_elems": (_i64, [_i32, _i32]),
     "dinoseg_op_pack_mlp": (C.c_int, [_fp, _fp, _i32, _i32, _vp, _vp]),
     "dinoseg_op_mlp_fused": (C.c_int, [_fp, _fp, _fp, _f32, _vp, _fp, _fp, _i32, _i32, _i32, _vp]),
+    "dinoseg_op_qkv_pack_elems": (_i64, [_i32]),
+    "dinoseg_op_pack_qkv": (C.c_int, [_fp, _i32, _vp, _vp]),
+    "dinoseg_op_block_tail_fused": (C.c_int, [_fp, _vp, _vp, _fp, _fp, _fp, _f32, _vp, _fp, _fp, _vp, _fp, _fp, _fp, _vp, _vp, _vp, _i32,
+                                              _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "dinoseg_op_proj_pack_elems": (_i64, [_i32]),
     "dinoseg_op_pack_proj": (C.c_int, [_fp, _i32, _vp, _vp]),
     "dinoseg_op_proj_mlp_fused": (C.c_int, [_fp, _vp, _vp, _fp, _fp, _fp, _f32, _vp, _fp, _fp, _i32, _i32, _i32, _vp]),

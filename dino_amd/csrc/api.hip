@@ -52,6 +52,7 @@ static void add_expected(dinoseg_handle* h) {
     e["dino.pos_embed"] = {1, (int64_t)c.pos_grid * c.pos_grid + 1, D};
     e["dino.patch_embed.proj.weight"] = {D, 3, p, p};
     e["dino.patch_embed.proj.bias"] = {D};
+    bool qkv_ready = false;      // Q / K / V of block i were written by block i-1's fused launch (mlp_fused2.hip, QKV tail)
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
         e[b + "norm1.weight"] = {D};
@@ -194,6 +195,7 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
                 h->packed_slab.clear();
                 h->packed_mlp.clear();
                 h->packed_proj.clear();
+                h->packed_qkvf.clear();
                 h->bound.clear();
                 h->grads.clear();
             }
@@ -222,6 +224,7 @@ static std::vector<LinSpec> linear_specs(const dinoseg_handle* h) {
     const int D = c.embed_dim, F = c.embed_dim * c.mlp_ratio, P = h->planes;
     std::vector<LinSpec> v;
     v.push_back({"dino.patch_embed.proj.weight", "dino.patch_embed.proj.bias", D, 3 * c.patch * c.patch, D, 192, P});
+    bool qkv_ready = false;      // Q / K / V of block i were written by block i-1's fused launch (mlp_fused2.hip, QKV tail)
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
         v.push_back({b + "attn.qkv.weight", b + "attn.qkv.bias", 3 * D, D, 3 * D, D, P});
@@ -264,7 +267,8 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     const bool mlp_fusable = mlp_fused_supported(Dm, Fh, h->planes);
     if (mlp_fusable)
         total += (size_t)h->cfg.n_blocks * (align_up((size_t)mlp_fused_pack_elems(Dm, Fh) * sizeof(bf16_t), 256) +
-                                            align_up((size_t)mlp_fused_proj_pack_elems(Dm) * sizeof(bf16_t), 256));
+                                            align_up((size_t)mlp_fused_proj_pack_elems(Dm) * sizeof(bf16_t), 256) +
+                                            align_up((size_t)mlp_fused_qkv_pack_elems(Dm) * sizeof(bf16_t), 256));
     if (total > h->wbuf_bytes) {
         if (h->wbuf) DSEG_CHECK_HIP(hipFree(h->wbuf));
         h->wbuf = nullptr;
@@ -299,6 +303,7 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     DSEG_TRY(launch_multi_pack(jobs.data(), (int)jobs.size(), s));
     h->packed_mlp.clear();
     h->packed_proj.clear();
+    h->packed_qkvf.clear();
     if (mlp_fusable)
         for (int i = 0; i < h->cfg.n_blocks; ++i) {
             const std::string b = "dino.blocks." + std::to_string(i) + ".";
@@ -308,6 +313,10 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
             if (mlp_fused_proj_pack_elems(Dm) > 0) {
                 h->packed_proj[b] = reinterpret_cast<bf16_t*>(h->wbuf + off);
                 off += align_up((size_t)mlp_fused_proj_pack_elems(Dm) * sizeof(bf16_t), 256);
+            }
+            if (i > 0 && mlp_fused_qkv_pack_elems(Dm) > 0) {      // (block 0's qkv has no fused kernel in front of it)
+                h->packed_qkvf[b] = reinterpret_cast<bf16_t*>(h->wbuf + off);
+                off += align_up((size_t)mlp_fused_qkv_pack_elems(Dm) * sizeof(bf16_t), 256);
             }
         }
     // Packed now, except while gradient buffers are bound (a fine-tune in progress refreshes after every optimiser step and its
@@ -440,6 +449,7 @@ static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s) {
     for (auto& kv : h->packed_mlp)
         DSEG_TRY(launch_pack_mlp(W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc2.weight"), Dm, Fh, kv.second, s));
     for (auto& kv : h->packed_proj) DSEG_TRY(launch_pack_proj(W(h, kv.first + "attn.proj.weight"), Dm, kv.second, s));
+    for (auto& kv : h->packed_qkvf) DSEG_TRY(launch_pack_qkv(W(h, kv.first + "attn.qkv.weight"), Dm, kv.second, s));
     h->packed_mlp_stale = false;
     return 0;
 }
@@ -507,6 +517,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     const float qscale = 0.125f * 1.44269504088896340736f;   // head_dim^-0.5 (vision_transformer.py:73) * log2(e)
 
     // ---- transformer blocks (vision_transformer.py:122-140) ----
+    bool qkv_ready = false;      // Q / K / V of block i were written by block i-1's fused launch (mlp_fused2.hip, QKV tail)
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
         // gemm_ln: 0 never fused, 2 always, 1 (default) by measurement: bf16 fused; bf16x3 fused only for small batches -- with
@@ -515,7 +526,9 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
         const bool big_x3 = P == 2 && options().gemm_big && (long)((L.M + 127) / 128) * 3 >= 512;
         const bool fuse_ln = options().gemm_ln == 2 || (options().gemm_ln == 1 && !big_x3);
         // (the fused kernel keeps 32-bit output row offsets)
-        if (fuse_ln && h->packed_slab.count(b + "attn.qkv.weight") && L.qkv_plane < (1L << 31)) {
+        if (qkv_ready) {
+            qkv_ready = false;
+        } else if (fuse_ln && h->packed_slab.count(b + "attn.qkv.weight") && L.qkv_plane < (1L << 31)) {
             // LN1 + qkv in one launch: X rows are normalised in the GEMM's prologue, no bf16 A round trip (gemm_ln.hip)
             LnGemmParams g = {};
             g.X = X; g.ldx = D; g.gamma = W(h, b + "norm1.weight"); g.beta = W(h, b + "norm1.bias"); g.eps = c.ln_eps;
@@ -600,6 +613,14 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.M = L.M;
             if (fuse_proj) {
                 g.ctx = CTX; g.Wproj = h->packed_proj.at(b); g.bproj = W(h, b + "attn.proj.bias");
+                const std::string nb = "dino.blocks." + std::to_string(i + 1) + ".";
+                // ... and LayerNorm1 + qkv of the next block (a tap of this block's output still reads X, which is complete)
+                if (options().qkv_fused && i + 1 < c.n_blocks && h->packed_qkvf.count(nb)) {
+                    g.Wqkv = h->packed_qkvf.at(nb); g.bqkv = W(h, nb + "attn.qkv.bias");
+                    g.gamma1 = W(h, nb + "norm1.weight"); g.beta1 = W(h, nb + "norm1.bias");
+                    g.q = Q; g.k = Kb; g.v = V; g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.qscale = qscale;
+                    qkv_ready = true;
+                }
             }
             DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(options().mlp_variant == 1 ? launch_mlp_fused(g, s) : launch_mlp_fused2(g, s)));
         } else {
@@ -791,6 +812,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().mlp_fused = value;
         return 0;
     }
+    if (strcmp(key, "qkv_fused") == 0) {
+        dseg::options().qkv_fused = value;
+        return 0;
+    }
     if (strcmp(key, "proj_fused") == 0) {
         dseg::options().proj_fused = value;
         return 0;
@@ -953,6 +978,37 @@ extern "C" int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* 
     g.X = X; g.ldx = D; g.gamma = gamma; g.beta = beta; g.eps = eps;
     g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
     g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.Wproj = reinterpret_cast<const bf16_t*>(Wproj); g.bproj = bproj;
+    return launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t dinoseg_op_qkv_pack_elems(int32_t D) { return mlp_fused_qkv_pack_elems(D); }
+
+extern "C" int dinoseg_op_pack_qkv(const float* Wsrc, int32_t D, void* dst, void* stream) {
+    if (!Wsrc || !dst || mlp_fused_qkv_pack_elems(D) <= 0) {
+        dinoseg_set_error("dinoseg_op_pack_qkv: null pointer or unsupported width D=%d", D);
+        return -1;
+    }
+    return launch_pack_qkv(Wsrc, D, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_block_tail_fused(float* X, const void* ctx, const void* Wproj, const float* bproj, const float* gamma2,
+                                           const float* beta2, float eps, const void* Wp, const float* b1, const float* b2,
+                                           const void* Wqkv, const float* bqkv, const float* gamma1, const float* beta1, void* q, void* k,
+                                           void* v, int32_t B, int32_t ntok, int32_t npad, int32_t heads, float qscale, int32_t D,
+                                           int32_t F, void* stream) {
+    if (!X || !ctx || !Wproj || !bproj || !gamma2 || !beta2 || !Wp || !b1 || !b2 || !Wqkv || !bqkv || !gamma1 || !beta1 || !q || !k ||
+        !v || B <= 0 || ntok <= 0 || npad < ntok || npad % 64 != 0 || heads * 64 != D || !mlp_fused_supported(D, F, 1) ||
+        mlp_fused_proj_pack_elems(D) <= 0 || mlp_fused_qkv_pack_elems(D) <= 0) {
+        dinoseg_set_error("dinoseg_op_block_tail_fused: null pointer or unsupported shape D=%d F=%d heads=%d", D, F, heads);
+        return -1;
+    }
+    MlpFusedParams g = {};
+    g.X = X; g.ldx = D; g.gamma = gamma2; g.beta = beta2; g.eps = eps;
+    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = B * ntok;
+    g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.Wproj = reinterpret_cast<const bf16_t*>(Wproj); g.bproj = bproj;
+    g.Wqkv = reinterpret_cast<const bf16_t*>(Wqkv); g.bqkv = bqkv; g.gamma1 = gamma1; g.beta1 = beta1;
+    g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
+    g.ntok = ntok; g.npad = npad; g.heads = heads; g.qscale = qscale;
     return launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -79,7 +79,14 @@ struct MlpFusedParams {
     const bf16_t* ctx;                          // [M, 384] bf16 attention output (row stride 384), null = MLP only
     const bf16_t* Wproj;                        // launch_pack_proj
     const float* bproj;
+    // optional (with ctx): LayerNorm1 + the qkv projection of the NEXT block at the end of the same launch (Q pre-scaled by qscale)
+    const bf16_t* Wqkv;                         // launch_pack_qkv: [1152, 384] in fragment order; null = no qkv tail
+    const float* bqkv; const float* gamma1; const float* beta1;
+    bf16_t* q; bf16_t* k; bf16_t* v;            // each [B, heads, npad, 64] bf16 (rows >= ntok are never written)
+    int ntok, npad, heads; float qscale;
 };
+long mlp_fused_qkv_pack_elems(int D);           // bf16 elements of the packed qkv weight (0: unsupported width)
+int launch_pack_qkv(const float* W, int D, bf16_t* dst, hipStream_t s);
 long mlp_fused_proj_pack_elems(int D);          // bf16 elements of the packed projection weight (0: unsupported width)
 int launch_pack_proj(const float* W, int D, bf16_t* dst, hipStream_t s);
 bool mlp_fused_supported(int D, int F, int planes);
@@ -97,6 +104,8 @@ struct Options {
     int mlp_fused = 1;       // the MLP half of a block as one launch (mlp_fused.hip): 0 never, 1 for >= mlp_fused_min_rows rows, 2 wherever supported
     int mlp_fused_min_rows = 24000;
     int mlp_grid = 0;        // workgroups of the fused MLP launch (0 = the fewest that need no extra round: mlp_fused2.hip)
+    int qkv_fused = 0;       // 1: ... and LayerNorm1 + qkv of the NEXT block at its end (blocks 1.. then have no LN+qkv launch); measured
+                             // +1 % on one stream, +-0 on two: the tail is bound by the same HBM write burst as the launch it replaces
     int proj_fused = 1;      // 1: with mlp_variant 2 the block's attention output projection runs inside the fused MLP launch
     int mlp_variant = 2;     // 1: mlp_fused.hip (one wave per SIMD), 2: mlp_fused2.hip (role-split wave pairs)
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)

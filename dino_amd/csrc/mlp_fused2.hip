@@ -48,7 +48,10 @@ constexpr int B1_OFF = P_OFF + NP * 2 * 2048;       // b1 [F] fp32
 constexpr int B2_OFF = B1_OFF + F * 4;              // b2, gamma, beta [D] fp32 each
 constexpr int G_OFF = B2_OFF + D * 4, BE_OFF = G_OFF + D * 4;
 constexpr int BP_OFF = BE_OFF + D * 4;              // PROJ: b2 (B2_OFF then holds b_proj, the initial value's bias)
-constexpr int LDS_BYTES = BP_OFF + D * 4;
+constexpr int G1_OFF = BP_OFF + D * 4, BE1_OFF = G1_OFF + D * 4;      // QKV: norm1 weight / bias of the NEXT block
+constexpr int BQ_OFF = BE1_OFF + D * 4;             // QKV: its qkv bias [1152]
+constexpr int NQT = 3 * D / 32;                     // QKV: output tiles of 32 features (36)
+constexpr int LDS_BYTES = BQ_OFF + 3 * D * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr int NPT = D / 32;                         // PROJ: projection k-tiles
 constexpr int CTX_OFF = W2_OFF, CTX_SLOT = BM * 64; // PROJ: six slots of [128 rows][32 k] bf16 in the (idle) W2 ring
@@ -63,7 +66,7 @@ constexpr int RA = MF2_RA, NFR = RA + 1;            // fragment read-ahead (gaps
 
 #ifndef MF2_ABL
 #define MF2_ABL 0      // timing ablations (wrong results): 1 no GELU, 2 no W DMA, 4 no fc1 MFMAs, 8 no fc2 MFMAs, 16 no fragment reads,
-                       // 32 no row loads / stores
+                       // 32 no row loads / stores, 64 no LDS-DMA in the qkv tail, 128 no MFMAs in the qkv tail
 #endif
 
 #ifndef MF2_STAMP
@@ -107,8 +110,9 @@ __device__ __forceinline__ void mf2_proj_tile(f32x16 (&acc)[mfc::NDB], uint32_t 
     });
 }
 
-template <bool PROJ>
+template <bool PROJ, bool QKV>
 __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedParams p) {
+    static_assert(PROJ || !QKV, "the qkv tail needs the hand-off machinery of the projection build");
     using namespace mf2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -131,6 +135,11 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         }
         if (PROJ)
             for (int i = tid; i < D / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + BP_OFF)[i] = reinterpret_cast<const f32x4*>(p.b2)[i];
+        if (QKV) {
+            for (int i = tid; i < 2 * D / 4; i += THREADS)
+                reinterpret_cast<f32x4*>(smem + G1_OFF)[i] = reinterpret_cast<const f32x4*>(i < D / 4 ? p.gamma1 : p.beta1)[i < D / 4 ? i : i - D / 4];
+            for (int i = tid; i < 3 * D / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + BQ_OFF)[i] = reinterpret_cast<const f32x4*>(p.bqkv)[i];
+        }
     }
 #ifndef MF2_STAGGER
 #define MF2_STAGGER 0      // experiment: odd workgroups start MF2_STAGGER x 8128 cycles late (desynchronises the HBM bursts of item boundaries)
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
     };
     const uint64_t wp = reinterpret_cast<uint64_t>(p.Wp);
     const uint64_t wpj = reinterpret_cast<uint64_t>(p.Wproj), ctxb = reinterpret_cast<uint64_t>(p.ctx);
+    const uint64_t wq = reinterpret_cast<uint64_t>(p.Wqkv);
     // PROJ: a lane's two ctx fragments of a k-tile (row = pair * 32 + lr of the item, 16-byte chunk (2 s2 + lh) ^ ((row >> 2) & 3))
     auto ctx_frag_addr = [&](uint32_t lr_, uint32_t lh_) __attribute__((always_inline)) -> uint32_t {
         const uint32_t rin = (uint32_t)pair * 32 + lr_;
@@ -223,6 +233,17 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                     }
                 }
             };
+            auto load_rows_k = [&](const float* xr, auto k_tag) __attribute__((always_inline)) {
+                constexpr int k = decltype(k_tag)::value;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k * 16), b = *reinterpret_cast<const f32x4*>(xr + k * 16 + 4);
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(sB2 + k * 16 + lh_i * 8);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(sB2 + k * 16 + lh_i * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[k >> 1][(k & 1) * 8 + e] = a[e] + c0[e];
+                    o[k >> 1][(k & 1) * 8 + 4 + e] = b[e] + c1[e];
+                }
+            };
             if (item == (int)blockIdx.x) load_rows(xrow);
             if (wave == 4) MF2_ST(1, item_k, 1);
 
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                     const uint32_t so1 = (nxt ? (uint32_t)t1 * W_TILE : (uint32_t)t1 * TILE_BYTES) + frag0;
                     const uint32_t d2 = lds_base + W2_OFF + (uint32_t)(s & 1) * W_TILE + frag0;
                     const uint32_t d1 = lds_base + W1_OFF + (uint32_t)(t1 % 3) * W_TILE + frag0;
-                    const uint64_t w1src = nxt ? wpj : wp;
+                    const uint64_t w1src = nxt ? (QKV ? wq : wpj) : wp;      // (QKV: the qkv tail's first tiles; Wproj follows the tail)
                     gsb[0] = uniform64(wp + so2);
                     gsb[1] = uniform64(wp + so2 + 4096);
                     gsb[2] = uniform64(w1src + so1);
@@ -314,8 +335,69 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 }
             };
+            // ---- LayerNorm of the rows in o, from the registers (register 8 s2 + j of block db = feature 32 db + 16 s2 + 8 lh + j), handed to
+            // wave A as B-operand fragments in three rounds of eight through the pair's 8-KiB window (4 barriers inside, the caller adds
+            // the one that publishes round 2)
+            auto ln_handoff = [&](const float* sGam, const float* sBet) __attribute__((always_inline)) {
+                float sum = 0.f;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        sum += ((o[db][8 * h] + o[db][8 * h + 1]) + (o[db][8 * h + 2] + o[db][8 * h + 3])) +
+                               ((o[db][8 * h + 4] + o[db][8 * h + 5]) + (o[db][8 * h + 6] + o[db][8 * h + 7]));
+                sum += __shfl_xor(sum, 32);
+                const float mean = sum * (1.0f / D);
+                float qv = 0.f;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        __builtin_amdgcn_sched_barrier(0);      // (192 live accumulators: no room for 192 differences at once)
+                        float part = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float dlt = o[db][4 * q4 + e] - mean;
+                            part = fmaf(dlt, dlt, part);
+                        }
+                        qv += part;
+                    }
+                qv += __shfl_xor(qv, 32);
+                const float rstd = 1.0f / sqrtf(qv * (1.0f / D) + p.eps);
+                float mean_n = mean;      // (opaque copy: otherwise the 192 differences of the variance pass are kept -- in scratch)
+                asm volatile("" : "+v"(mean_n));
+                char* const hw = smem + H_OFF + pair * 8192 + lane16_i;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    if (r > 0) __builtin_amdgcn_s_barrier();      // wave A has read the previous round
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        __builtin_amdgcn_sched_barrier(0);      // (one k-step at a time: the accumulators leave no room for hoisted loads)
+                        const int k = r * 8 + kk;
+                        const float* gp = sGam + k * 16 + lh_i * 8;
+                        const float* bp = sBet + k * 16 + lh_i * 8;
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                        const f32x4 e0 = *reinterpret_cast<const f32x4*>(bp), e1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                        float y[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            y[e] = (o[k >> 1][(k & 1) * 8 + e] - mean_n) * rstd * g0[e] + e0[e];
+                            y[4 + e] = (o[k >> 1][(k & 1) * 8 + 4 + e] - mean_n) * rstd * g1[e] + e1[e];
+                        }
+                        uint4 u;
+                        u.x = pack_bf16x2(y[0], y[1]);
+                        u.y = pack_bf16x2(y[2], y[3]);
+                        u.z = pack_bf16x2(y[4], y[5]);
+                        u.w = pack_bf16x2(y[6], y[7]);
+                        *reinterpret_cast<uint4*>(hw + kk * 1024) = u;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (r < 2) __builtin_amdgcn_s_barrier();      // round r is in LDS
+                }
+            };
+
             if constexpr (PROJ) {
-                // ---- projection phase: o^T += Wproj . ctx^T, twelve k-tiles (o already holds x + b_proj + b2)
+                // ---- projection phase: o^T += Wproj . ctx^T, twelve k-tiles (o already holds x + b_proj)
                 uint32_t cv[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -364,64 +446,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                         mf_dma1<1024>(lane16_i, sb + 4096, ld + 4096);
                     }
                 }
-                // ---- LayerNorm2 of x_mid = o, from the registers (register 8 s2 + j of block db = feature 32 db + 16 s2 + 8 lh + j)
-                {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-                            sum += ((o[db][8 * h] + o[db][8 * h + 1]) + (o[db][8 * h + 2] + o[db][8 * h + 3])) +
-                                   ((o[db][8 * h + 4] + o[db][8 * h + 5]) + (o[db][8 * h + 6] + o[db][8 * h + 7]));
-                    sum += __shfl_xor(sum, 32);
-                    const float mean = sum * (1.0f / D);
-                    float qv = 0.f;
-#pragma unroll
-                    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            __builtin_amdgcn_sched_barrier(0);      // (192 live accumulators: no room for 192 differences at once)
-                            float part = 0.f;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float dlt = o[db][4 * q4 + e] - mean;
-                                part = fmaf(dlt, dlt, part);
-                            }
-                            qv += part;
-                        }
-                    qv += __shfl_xor(qv, 32);
-                    const float rstd = 1.0f / sqrtf(qv * (1.0f / D) + p.eps);
-                    float mean_n = mean;      // (opaque copy: otherwise the 192 differences of the variance pass are kept -- in scratch)
-                    asm volatile("" : "+v"(mean_n));
-                    char* const hw = smem + H_OFF + pair * 8192 + lane16_i;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        if (r > 0) __builtin_amdgcn_s_barrier();      // wave A has read the previous round
-#pragma unroll
-                        for (int kk = 0; kk < 8; ++kk) {
-                            __builtin_amdgcn_sched_barrier(0);      // (one k-step at a time: the accumulators leave no room for hoisted loads)
-                            const int k = r * 8 + kk;
-                            const float* gp = sG + k * 16 + lh_i * 8;
-                            const float* bp = sBe + k * 16 + lh_i * 8;
-                            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-                            const f32x4 e0 = *reinterpret_cast<const f32x4*>(bp), e1 = *reinterpret_cast<const f32x4*>(bp + 4);
-                            float y[8];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                y[e] = (o[k >> 1][(k & 1) * 8 + e] - mean_n) * rstd * g0[e] + e0[e];
-                                y[4 + e] = (o[k >> 1][(k & 1) * 8 + 4 + e] - mean_n) * rstd * g1[e] + e1[e];
-                            }
-                            uint4 u;
-                            u.x = pack_bf16x2(y[0], y[1]);
-                            u.y = pack_bf16x2(y[2], y[3]);
-                            u.z = pack_bf16x2(y[4], y[5]);
-                            u.w = pack_bf16x2(y[6], y[7]);
-                            *reinterpret_cast<uint4*>(hw + kk * 1024) = u;
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (r < 2) __builtin_amdgcn_s_barrier();      // round r is in LDS
-                    }
-                }
+                ln_handoff(sG, sBe);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (wave == 4) MF2_ST(1, item_k, 10);
                 __builtin_amdgcn_s_barrier();      // round 2 in LDS; W1(0..2), W2(0) visible
@@ -438,6 +463,79 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
             }
             if (wave == 4) MF2_ST(1, item_k, 6);
 
+            if constexpr (QKV) {
+                // ---- qkv tail: LayerNorm1 of the NEXT block on the finished rows, handed to wave A; wave A multiplies (36 tiles of 32
+                // output features, its own LDS-DMA stream through the W1 ring: a wave that stores must not wait on a vmcnt it shares
+                // with a DMA ring) and leaves each tile's bf16 block in the pair's P buffer; this wave writes the blocks to Q / K / V one
+                // step later, its own row stores and the next item's row loads in between
+                const bool has_next = item + (int)gridDim.x < nitems;
+                {
+                    const float* fp = reinterpret_cast<const float*>(smem + BP_OFF) + lh_i * 8;      // b2: o becomes the block's output
+#pragma unroll
+                    for (int k = 0; k < NKS; ++k) {
+                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(fp + k * 16), c1 = *reinterpret_cast<const f32x4*>(fp + k * 16 + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o[k >> 1][(k & 1) * 8 + e] += c0[e];
+                            o[k >> 1][(k & 1) * 8 + 4 + e] += c1[e];
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_barrier();      // every wave is done with step 48: W2 slot 1 and the P buffers are idle (the windows)
+                ln_handoff(reinterpret_cast<const float*>(smem + G1_OFF), reinterpret_cast<const float*>(smem + BE1_OFF));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // Wqkv(0..2), issued at steps 46..48
+                __builtin_amdgcn_s_barrier();      // round 2 in LDS; Wqkv(0..2) visible
+                // destination of this lane's row: ((frame * heads) * npad + token) * 64 in each of Q, K, V
+                const int fr_ = row_c / p.ntok, tok_ = row_c - fr_ * p.ntok;
+                const long qkv_row = ((long)fr_ * p.heads * p.npad + tok_) * 64 + lh_i * 8;
+                const float* const nxr = p.X + (long)((row + BM * (int)gridDim.x) < M ? row + BM * (int)gridDim.x : M - 1) * D + lh_i * 8;
+                mf_for(std::make_integer_sequence<int, NQT + 1>{}, [&](auto t_tag) __attribute__((always_inline)) {
+                    constexpr int T = decltype(t_tag)::value;
+                    __builtin_amdgcn_s_barrier();
+                    if constexpr (T >= 1) {      // tile T - 1 from the pair's P buffer to its place
+                        constexpr int TT = T - 1, WHICH = TT / NDB, HB = TT % NDB;
+                        const char* pr = smem + P_OFF + pair * 4096 + lane16_i + (TT & 1) * 2048;
+                        const uint4 u0 = *reinterpret_cast<const uint4*>(pr), u1 = *reinterpret_cast<const uint4*>(pr + 1024);
+                        bf16_t* dst = (WHICH == 0 ? p.q : (WHICH == 1 ? p.k : p.v)) + qkv_row + (long)(HB >> 1) * p.npad * 64 + (HB & 1) * 32;
+                        if (row < M) {
+                            *reinterpret_cast<uint4*>(dst) = u0;
+                            *reinterpret_cast<uint4*>(dst + 16) = u1;
+                        }
+                    }
+                    if constexpr (T >= 1 && T <= NKS) {      // this wave's own rows: two stores per step
+                        constexpr int k = T - 1;
+                        if (row < M) {
+                            f32x4 a, b;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                a[e] = o[k >> 1][(k & 1) * 8 + e];
+                                b[e] = o[k >> 1][(k & 1) * 8 + 4 + e];
+                            }
+                            *reinterpret_cast<f32x4*>(xrow + k * 16) = a;
+                            *reinterpret_cast<f32x4*>(xrow + k * 16 + 4) = b;
+                        }
+                    }
+                    if constexpr (T > NKS) {      // the next item's rows: two k-steps per step
+                        if (has_next) {
+                            load_rows_k(nxr, std::integral_constant<int, 2 * (T - NKS - 1)>{});
+                            load_rows_k(nxr, std::integral_constant<int, 2 * (T - NKS - 1) + 1>{});
+                        }
+                    }
+                });
+                static_assert(NQT + 1 - NKS - 1 == NKS / 2, "row loads fill the steps behind the row stores");
+                if (has_next && !(MF2_ABL & 2)) {      // the next item's first projection k-tiles (the W1 ring is free again)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const uint64_t sb = uniform64(wpj + (uint32_t)t * W_TILE + frag0);
+                        const uint32_t ld = __builtin_amdgcn_readfirstlane(lds_base + W1_OFF + t * W_TILE + frag0);
+                        mf_dma4(lane16_i, sb, ld);
+                        mf_dma1<0>(lane16_i, sb + 4096, ld + 4096);
+                        mf_dma1<1024>(lane16_i, sb + 4096, ld + 4096);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (before the first projection barrier publishes them)
+                continue;
+            }
             // ---- epilogue: o = x + b2 + fc2(...) back to the residual stream
             if (MF2_ABL & 32) {
 #pragma unroll
@@ -525,9 +623,9 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         }
     };
     // S(0): accumulators start from b1 (tile 0), fragments from W1 ring slot 0 (compiler-scheduled)
-    auto s_zero = [&](int lane_p) __attribute__((always_inline)) {
+    auto s_zero = [&](int lane_p, const float* sBias) __attribute__((always_inline)) {
         f32x16 s;
-        const float* bp = sB1 + (lane_p >> 5) * 8;
+        const float* bp = sBias + (lane_p >> 5) * 8;
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(bp), c1 = *reinterpret_cast<const f32x4*>(bp + 4);
         const f32x4 c2 = *reinterpret_cast<const f32x4*>(bp + 16), c3 = *reinterpret_cast<const f32x4*>(bp + 20);
 #pragma unroll
@@ -563,7 +661,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
             }
         }
         layernorm(x, lh);
-        return s_zero(lane_p);
+        return s_zero(lane_p, sB1);
     };
     // ---- the GELU of S(s), spread over the 24 MFMA gaps of the step (+ a tail slot): element n (accumulator register n) starts
     // at slot (14 n) / 15 and issues instruction i of gelu_fast (common.h) at slot start + i; odd elements pack a dword at + 10
@@ -609,20 +707,24 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         char* const p_wr = smem + P_OFF + pair * 4096 + lane16_i;
         const float* const b1_lane_p = sB1 + attn::sigma23((int)(lane_i & 31));     // + HT * tile: b1 of MFMA A row lr
         const uint4 ones_u = {lh_i == 0 ? 0x3F803F80u : 0u, lh_i == 0 ? 0x00003F80u : 0u, 0u, 0u};     // k = 0, 1, 2 are 1.0
-        if constexpr (PROJ) {
-            // ---- wave B projects and normalises (12 + 1 barriers); xn arrives in three rounds of eight fragments; then S(0)
-#pragma unroll 1
-            for (int kt = 0; kt <= NPT; ++kt) __builtin_amdgcn_s_barrier();
+        // normalised rows from wave B: three rounds of eight fragments through the pair's window (5 barriers)
+        auto receive_xn = [&]() __attribute__((always_inline)) {
             const char* const hr = smem + H_OFF + pair * 8192 + lane16_i;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                __builtin_amdgcn_s_barrier();      // round r is in LDS (the last one: with W1(0..2), W2(0))
+                __builtin_amdgcn_s_barrier();      // round r is in LDS (the last one: with the first weight tiles of what follows)
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) xn[r * 8 + kk] = lds_frag(hr + kk * 1024);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (r < 2) __builtin_amdgcn_s_barrier();      // read: wave B may write the next round
             }
-            sa = s_zero((int)lane_i);
+        };
+        if constexpr (PROJ) {
+            // ---- wave B projects and normalises (12 + 1 barriers); xn arrives in three rounds of eight fragments; then S(0)
+#pragma unroll 1
+            for (int kt = 0; kt <= NPT; ++kt) __builtin_amdgcn_s_barrier();
+            receive_xn();
+            sa = s_zero((int)lane_i, sB1);
             if (wave == 0) MF2_ST(0, item_k, 10);
         }
 
@@ -691,6 +793,92 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         if (wave == 0) MF2_ST(0, item_k, 5);
         __builtin_amdgcn_s_barrier();      // step 48: wave B's last tile; this wave already works on the next item
         if (wave == 0) MF2_ST(0, item_k, 6);
+        if constexpr (QKV) {
+            // ---- qkv tail: LayerNorm1 of the next block arrives from wave B; Z(t)^T = Wqkv_t . xn^T + b (36 tiles of 32 output features)
+            // with the step skeleton of fc1 -- Z(t+1) on the matrix pipe while Z(t) is scaled (Q: 64^-0.5 log2 e), packed and left in the
+            // pair's P buffer for wave B to store -- and THIS wave's own LDS-DMA stream: tile t + 3 into the W1 ring slot tile t left
+            __builtin_amdgcn_s_barrier();      // (wave B: step 48 done everywhere, the hand-off windows are free)
+            receive_xn();
+            const float* const sBq = reinterpret_cast<const float*>(smem + BQ_OFF);
+            const float* const bq_lane_p = sBq + attn::sigma23((int)(lane_i & 31));
+            const uint32_t frag0 = (uint32_t)pair * 6 * 1024;
+            sa = s_zero((int)lane_i, sBq);
+            auto step_q = [&](f32x16& s_cur, f32x16& s_nxt, int t, auto last_tag) __attribute__((always_inline)) {
+                constexpr bool LAST = decltype(last_tag)::value;
+                bf16x8 bias_frag;
+                if (!LAST) {
+                    const float bj = bq_lane_p[(t + 1) * 32];
+                    const uint32_t hi = pack_bf16x2(bj, 0.f);
+                    const float r1f = bj - bf16_lo_to_f32(hi);
+                    const uint32_t mid = pack_bf16x2(r1f, 0.f);
+                    const uint32_t lo = pack_bf16x2(r1f - bf16_lo_to_f32(mid), 0.f);
+                    const uint4 fu = {lh_i == 0 ? ((hi & 0xFFFFu) | (mid << 16)) : 0u, lh_i == 0 ? (lo & 0xFFFFu) : 0u, 0u, 0u};
+                    bias_frag = __builtin_bit_cast(bf16x8, fu);
+                }
+                const float sc = t < NDB ? p.qscale : 1.0f;
+                const bool issue = t + 3 < NQT;
+                const uint32_t so = (uint32_t)(t + 3) * W_TILE + frag0;
+                const uint32_t d = lds_base + W1_OFF + (uint32_t)((t + 3) % 3) * W_TILE + frag0;
+                const uint64_t gb0 = uniform64(wq + so), gb1 = uniform64(wq + so + 4096);
+                const uint32_t gl0 = __builtin_amdgcn_readfirstlane(d), gl1 = __builtin_amdgcn_readfirstlane(d + 4096);
+                auto piece = [&](auto j_tag) __attribute__((always_inline)) {
+                    constexpr int J = decltype(j_tag)::value;
+                    if ((MF2_ABL & (2 | 64)) || !issue) return;
+                    if constexpr (J < 4) mf_dma1<J * 1024>(lane16_i, gb0, gl0);
+                    else if constexpr (J < 6) mf_dma1<(J - 4) * 1024>(lane16_i, gb1, gl1);
+                };
+                auto q_slot = [&](auto g_tag) __attribute__((always_inline)) {
+                    constexpr int G = decltype(g_tag)::value;
+                    if constexpr (G < 16) ex[G] = s_cur[G] * sc;
+                    else if constexpr (G < 24) pd[G - 16] = pack_bf16x2(ex[2 * (G - 16)], ex[2 * (G - 16) + 1]);
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                if constexpr (!LAST) {
+                    const uint32_t a1 = frag_rd_i + W1_OFF + (uint32_t)((t + 1) % 3) * W_TILE;
+                    bf16x8 fr[NFR];
+                    auto issue_read = [&](auto g_tag) __attribute__((always_inline)) {
+                        constexpr int G = decltype(g_tag)::value;
+                        mf_rd<G * 1024>(fr[G % NFR], a1);
+                    };
+                    mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
+                    {
+                        f32x16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        s_nxt = mfma32(bias_frag, __builtin_bit_cast(bf16x8, ones_u), z);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mf_for(std::make_integer_sequence<int, 24>{}, [&](auto g_tag) __attribute__((always_inline)) {
+                        constexpr int G = decltype(g_tag)::value;
+                        if constexpr (G + RA < 24) issue_read(std::integral_constant<int, G + RA>{});
+                        mf_wait<(23 - G < RA ? 23 - G : RA)>();
+                        if (!(MF2_ABL & 128)) s_nxt = mfma32(fr[G % NFR], xn[G], s_nxt);
+                        __builtin_amdgcn_sched_barrier(0);
+                        q_slot(g_tag);
+                        if constexpr ((G & 1) == 0 && G < 12) piece(std::integral_constant<int, G / 2>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                } else {
+                    mf_for(std::make_integer_sequence<int, 24>{}, q_slot);
+                }
+                const uint4 u0 = {pd[0], pd[1], pd[2], pd[3]}, u1 = {pd[4], pd[5], pd[6], pd[7]};
+                *reinterpret_cast<uint4*>(p_wr + (t & 1) * 2048) = u0;
+                *reinterpret_cast<uint4*>(p_wr + (t & 1) * 2048 + 1024) = u1;
+                // tile t + 2 (issued one step ago) has landed before the next barrier publishes it; this step's six pieces may fly
+                if (issue) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll 1
+            for (int t = 0; t < NQT - 2; t += 2) {
+                step_q(sa, sb, t, std::false_type{});
+                step_q(sb, sa, t + 1, std::false_type{});
+            }
+            step_q(sa, sb, NQT - 2, std::false_type{});
+            step_q(sb, sa, NQT - 1, std::true_type{});
+            __builtin_amdgcn_s_barrier();      // wave B's last store step
+        }
         if constexpr (!PROJ)
             if (item + (int)gridDim.x < nitems) sa = prologue(item + gridDim.x);
         if (wave == 0) MF2_ST(0, item_k, 7);
@@ -711,6 +899,30 @@ __global__ __launch_bounds__(256) void pack_proj_kernel(const float* __restrict_
         dst[idx] = (bf16_t)(pack_bf16x2(W[(long)(db * 32 + i) * D + kt * 32 + s2 * 16 + h * 8 + e], 0.f) & 0xFFFF);
     }
 }
+// Wqkv [1152 out][384 in] fp32 -> bf16 fragments [tile of 32 outputs][k-step][lane][8]: the fc1 fragment format of pack_mlp
+__global__ __launch_bounds__(256) void pack_qkv_kernel(const float* __restrict__ W, bf16_t* __restrict__ dst) {
+    using namespace mf2;
+    const int total = NQT * NKS * 512;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int t = idx;
+        const int e = t & 7; t >>= 3;
+        const int lane = t & 63; t >>= 6;
+        const int frag = t % NKS, tile = t / NKS;
+        const int i = attn::sigma23(lane & 31), h = lane >> 5;
+        dst[idx] = (bf16_t)(pack_bf16x2(W[(long)(tile * 32 + i) * D + frag * 16 + h * 8 + e], 0.f) & 0xFFFF);
+    }
+}
+long mlp_fused_qkv_pack_elems(int Dm) { return Dm == mf2::D ? (long)mf2::NQT * mf2::W_TILE / 2 : 0; }
+int launch_pack_qkv(const float* W, int Dm, bf16_t* dst, hipStream_t s) {
+    if (Dm != mf2::D) {
+        dinoseg_set_error("pack_qkv: unsupported width %d", Dm);
+        return -1;
+    }
+    hipLaunchKernelGGL(pack_qkv_kernel, dim3(432), dim3(256), 0, s, W, dst);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 long mlp_fused_proj_pack_elems(int Dm) { return Dm == mf2::D ? (long)mf2::NPT * mf2::W_TILE / 2 : 0; }
 int launch_pack_proj(const float* W, int Dm, bf16_t* dst, hipStream_t s) {
     if (Dm != mf2::D) {
@@ -725,9 +937,11 @@ int launch_pack_proj(const float* W, int Dm, bf16_t* dst, hipStream_t s) {
 int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s) {
     static PerDeviceOnce once;
     if (once.first()) {
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<false>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<false, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, mf2::LDS_BYTES));
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<true>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<true, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, mf2::LDS_BYTES));
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<true, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, mf2::LDS_BYTES));
         once.mark();
     }
@@ -762,9 +976,21 @@ int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s) {
             dinoseg_set_error("mlp_fused2: ctx without the packed projection weight / bias");
             return -1;
         }
-        hipLaunchKernelGGL(mlp_fused2_kernel<true>, dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
+        if (p.Wqkv) {
+            if (!p.bqkv || !p.gamma1 || !p.beta1 || !p.q || !p.k || !p.v || p.ntok <= 0 || p.npad < p.ntok || p.heads * 64 != mf2::D) {
+                dinoseg_set_error("mlp_fused2: incomplete qkv tail (bias / norm1 / q / k / v / geometry)");
+                return -1;
+            }
+            hipLaunchKernelGGL((mlp_fused2_kernel<true, true>), dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
+        } else {
+            hipLaunchKernelGGL((mlp_fused2_kernel<true, false>), dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
+        }
     } else {
-        hipLaunchKernelGGL(mlp_fused2_kernel<false>, dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
+        if (p.Wqkv) {
+            dinoseg_set_error("mlp_fused2: the qkv tail needs the projection in the same launch (ctx)");
+            return -1;
+        }
+        hipLaunchKernelGGL((mlp_fused2_kernel<false, false>), dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
     }
     DSEG_CHECK_HIP(hipGetLastError());
 #if MF2_STAMP

@@ -181,6 +181,8 @@ int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
  *                mode, embed_dim 384, batches of >= 8 frames at 480x480), 0 never, 2 wherever the shape allows;
  *   "proj_fused" 1 [default] = where that launch runs, it also carries the block's attention output projection + residual
  *                (x += proj(ctx) + b first: vision_transformer.py:104-105), 0 = the projection stays a GEMM launch of its own;
+ *   "qkv_fused"  0 [default] / 1 = ... and LayerNorm1 + qkv of the next block at its end (blocks 1.. have no LN + qkv launch then:
+ *                +1 % frames/s on one stream, none on two -- the tail writes Q / K / V in the same HBM burst as the launch it replaces);
  *   "mlp_variant" 2 [default] = the role-split build of the fused MLP kernel (mlp_fused2.hip), 1 = one wave per SIMD (mlp_fused.hip);
  *   "train_streams" 2 [default] = dinoseg_backward / dinoseg_train_step run the blocks' weight-gradient GEMMs on an internal stream
  *                beside the input-gradient chain (forked from / joined to the caller's stream by events: stream-ordered, capturable),
@@ -246,6 +248,18 @@ int dinoseg_op_pack_proj(const float* W, int32_t D, void* dst, void* stream);
 int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* Wproj, const float* bproj, const float* gamma,
                               const float* beta, float eps, const void* Wp, const float* b1, const float* b2, int32_t M,
                               int32_t D, int32_t F, void* stream);
+
+/* ... and with LayerNorm1 + the qkv projection of the NEXT block at its end (Block.forward of block i from `x = x + attn` on, then
+ * block i+1 up to `qkv = self.qkv(self.norm1(x))`: vision_transformer.py:123, :135, :122 -> :75): after the launch X holds block i's
+ * output and q / k / v ([B, heads, npad, 64] bf16 each, q pre-scaled by qscale = 64^-0.5 * log2(e), rows >= ntok untouched) hold what
+ * dinoseg_op_ln_gemm(EPI_QKV) would have written from it.  M = B * ntok rows.  Wqkv: the [1152, 384] weight re-packed by
+ * dinoseg_op_pack_qkv (dinoseg_op_qkv_pack_elems(D) bf16 elements).  Library option "qkv_fused" (default 0: see there). */
+int64_t dinoseg_op_qkv_pack_elems(int32_t D);
+int dinoseg_op_pack_qkv(const float* W, int32_t D, void* dst, void* stream);
+int dinoseg_op_block_tail_fused(float* X, const void* ctx, const void* Wproj, const float* bproj, const float* gamma2,
+                                const float* beta2, float eps, const void* Wp, const float* b1, const float* b2, const void* Wqkv,
+                                const float* bqkv, const float* gamma1, const float* beta1, void* q, void* k, void* v, int32_t B,
+                                int32_t ntok, int32_t npad, int32_t heads, float qscale, int32_t D, int32_t F, void* stream);
 
 /* fused softmax(q k^T) v (vision_transformer.py:85,101,104); q must be pre-scaled by 64^-0.5 * log2(e).
  * q, k, v: [planes][B,heads,npad,64] (rows >= ntok zero); ctx: bf16 planes [planes][B*ntok][heads*64];

@@ -536,3 +536,66 @@ def test_proj_mlp_fused(cuda, M_):
                                         M_, D_, F_, S()))
     torch.cuda.synchronize()
     assert float((got - two).abs().max()) <= 2.0 ** -9 * scale + 1e-3
+
+
+@pytest.mark.parametrize("B,ntok", [(1, 65), (3, 130), (2, 901), (11, 3601)])
+def test_block_tail_fused(cuda, B, ntok):
+    """One launch from `x = x + proj(attn)` of block i to `qkv = qkv(norm1(x))` of block i+1 (mlp_fused2.hip, PROJ + QKV):
+        x += ctx . Wproj^T + bproj;  x += fc2(gelu(fc1(LN2(x))));  q, k, v = split(LN1'(x) . Wqkv'^T + bqkv')     (vision_transformer.py
+        :104-105, :123, :135, then :122 -> :75 of the next block).
+    X against the projection + MLP launch (the same arithmetic: bit-identical), Q / K / V against fp64 on the operands the kernel
+    sees (bf16 LayerNorm output of ITS x, bf16 weights) and against the LayerNorm-fused qkv GEMM run on that x; pad rows stay zero.
+    (11, 3601): 39 611 rows = 310 items, more than the 256 CUs (the qkv tail's tiles, the next item's projection tiles and row
+    loads interleave across the item boundary); (1, 65) / (3, 130): ragged single items, frames that straddle 32-row blocks."""
+    D_, F_, H = 384, 1536, 6
+    M_, npad = B * ntok, (ntok + 63) // 64 * 64
+    X = seeded((M_, D_), 61) * 1.7 + 0.4 + torch.arange(D_, device="cuda", dtype=torch.float32)[None, :] * 1e-3
+    ctx = quant_like(seeded((M_, D_), 62) * 0.8, 1)
+    Wpr, bpr = seeded((D_, D_), 63) * 0.07, seeded((D_,), 64) * 0.3
+    gam2, bet2 = 1 + 0.2 * seeded((D_,), 65), 0.1 * seeded((D_,), 66)
+    W1, b1 = seeded((F_, D_), 67) * 0.06, seeded((F_,), 68) * 0.5
+    W2, b2 = seeded((D_, F_), 69) * 0.04, seeded((D_,), 70)
+    gam1, bet1 = 1 + 0.2 * seeded((D_,), 71), 0.1 * seeded((D_,), 72)
+    Wqkv, bqkv = seeded((3 * D_, D_), 73) * 0.1, seeded((3 * D_,), 74)
+    lib = capi.lib()
+    Wp = pack_mlp(W1, W2)
+    Wprp = torch.empty((lib.dinoseg_op_proj_pack_elems(D_),), dtype=torch.int16, device="cuda")
+    capi.check(lib.dinoseg_op_pack_proj(Wpr.data_ptr(), D_, Wprp.data_ptr(), S()))
+    nq = lib.dinoseg_op_qkv_pack_elems(D_)
+    assert nq == 3 * D_ * D_
+    Wqp = torch.empty((nq,), dtype=torch.int16, device="cuda")
+    capi.check(lib.dinoseg_op_pack_qkv(Wqkv.data_ptr(), D_, Wqp.data_ptr(), S()))
+    ctx_b = pack(ctx, 1)
+    qscale = 0.125 * LOG2E
+    q = torch.zeros((1, B, H, npad, 64), dtype=torch.int16, device="cuda")
+    k, v = torch.zeros_like(q), torch.zeros_like(q)
+    got = X.clone()
+    capi.check(lib.dinoseg_op_block_tail_fused(got.data_ptr(), ctx_b.data_ptr(), Wprp.data_ptr(), bpr.data_ptr(), gam2.data_ptr(),
+                                               bet2.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), Wqp.data_ptr(),
+                                               bqkv.data_ptr(), gam1.data_ptr(), bet1.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                               B, ntok, npad, H, qscale, D_, F_, S()))
+    torch.cuda.synchronize()
+    # the block output: same kernel arithmetic as the launch without the tail
+    two = X.clone()
+    capi.check(lib.dinoseg_op_proj_mlp_fused(two.data_ptr(), ctx_b.data_ptr(), Wprp.data_ptr(), bpr.data_ptr(), gam2.data_ptr(),
+                                             bet2.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), M_, D_, F_, S()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and torch.equal(got, two)
+    # q / k / v from that output: fp64 on the kernel's operands
+    A = quant_like(_ln_ref(got, gam1, bet1).cuda(), 1)
+    ref = (A.double() @ quant_like(Wqkv, 1).double().t() + bqkv.double()).float().reshape(B, ntok, 3, H, 64).permute(2, 0, 3, 1, 4)
+    tol = 2.0 ** -7 * float(ref.abs().max()) + 1e-4
+    gq, gk, gv = unpack(q), unpack(k), unpack(v)
+    assert float((gq[:, :, :ntok] - ref[0] * qscale).abs().max()) <= tol
+    assert float((gk[:, :, :ntok] - ref[1]).abs().max()) <= tol
+    assert float((gv[:, :, :ntok] - ref[2]).abs().max()) <= tol
+    assert torch.all(gq[:, :, ntok:] == 0) and torch.all(gk[:, :, ntok:] == 0) and torch.all(gv[:, :, ntok:] == 0)
+    # ... and the launch it replaces for the next block
+    Ws = pack_slabs(Wqkv, 1)
+    q2, k2, v2 = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
+    capi.check(lib.dinoseg_op_ln_gemm(got.data_ptr(), gam1.data_ptr(), bet1.data_ptr(), 1e-6, Ws.data_ptr(), 3 * D_ * D_, bqkv.data_ptr(),
+                                      M_, 3 * D_, D_, 1, 4, None, 0, q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), B * H * npad * 64, ntok,
+                                      npad, H, qscale, None, None, S()))
+    torch.cuda.synchronize()
+    for a, b_ in ((gq, unpack(q2)), (gk, unpack(k2)), (gv, unpack(v2))):
+        assert float((a - b_).abs().max()) <= tol

@@ -1,5 +1,5 @@
 """GPU box: time the fused MLP operator alone: python tools/bench_mlp.py [rows] [iters] [variant]
-(variant 1 = mlp_fused.hip, 2 = mlp_fused2.hip, 3 = mlp_fused2.hip with the attention output projection in the same launch, 0 = the
+(variant 1 = mlp_fused.hip, 2 = mlp_fused2.hip, 3 = mlp_fused2.hip with the attention output projection in the same launch, 4 = ... and LayerNorm1 + qkv of the next block, 0 = the
 separate projection GEMM (dinoseg_op_gemm EPI_RESID); DINOSEG_LIB selects the build for A/B runs of ablation variants)."""
 import os
 import sys
@@ -30,6 +30,12 @@ Wpr, bpr = seeded((D, D), 9) * 0.01, seeded((D,), 10) * 0.01
 Wprp = torch.empty((capi.lib().dinoseg_op_proj_pack_elems(D),), dtype=torch.int16, device="cuda")
 capi.check(capi.lib().dinoseg_op_pack_proj(Wpr.data_ptr(), D, Wprp.data_ptr(), S()))
 Wq = pack(Wpr, 1)
+NB = M // 3601      # mode 4 (projection + MLP + LayerNorm1 + qkv of the next block): whole frames of 3601 tokens
+Wqkv, bq = seeded((3 * D, D), 11) * 0.05, seeded((3 * D,), 12) * 0.1
+Wqp = torch.empty((capi.lib().dinoseg_op_qkv_pack_elems(D),), dtype=torch.int16, device="cuda")
+capi.check(capi.lib().dinoseg_op_pack_qkv(Wqkv.data_ptr(), D, Wqp.data_ptr(), S()))
+qb = torch.zeros((max(NB, 1), 6, 3648, 64), dtype=torch.int16, device="cuda")
+kb, vb = torch.zeros_like(qb), torch.zeros_like(qb)
 mode = 2
 
 
@@ -38,6 +44,11 @@ def run():
     if mode == 3:
         capi.check(lib.dinoseg_op_proj_mlp_fused(X.data_ptr(), ctx.data_ptr(), Wprp.data_ptr(), bpr.data_ptr(), gam.data_ptr(),
                                                  bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), M, D, F, S()))
+    elif mode == 4:
+        capi.check(lib.dinoseg_op_block_tail_fused(X.data_ptr(), ctx.data_ptr(), Wprp.data_ptr(), bpr.data_ptr(), gam.data_ptr(),
+                                                   bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), Wqp.data_ptr(),
+                                                   bq.data_ptr(), gam.data_ptr(), bet.data_ptr(), qb.data_ptr(), kb.data_ptr(), vb.data_ptr(),
+                                                   NB, 3601, 3648, 6, 0.18, D, F, S()))
     elif mode == 0:
         capi.check(lib.dinoseg_op_gemm(ctx.data_ptr(), M * D, D, Wq.data_ptr(), D * D, M, D, D, 1, capi.EPI_RESID, bpr.data_ptr(),
                                        X.data_ptr(), None, 0, D, S()))
