@@ -178,7 +178,7 @@ int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
  *                kernel, 2 = wherever its shape rules allow;
  *   "gemm_ln"    1 [default] = qkv / fc1 through the LayerNorm-fused kernels where measured faster, 0 never, 2 wherever supported;
  *   "mlp_fused"  1 [default] = the MLP half of a block (LayerNorm2, fc1, GELU, fc2, residual) as ONE launch where it applies (bf16
- *                mode, embed_dim 384, batches of >= 8 frames at 480x480), 0 never, 2 wherever the shape allows;
+ *                mode, embed_dim 384, batches of >= 4 frames at 480x480), 0 never, 2 wherever the shape allows;
  *   "proj_fused" 1 [default] = where that launch runs, it also carries the block's attention output projection + residual
  *                (x += proj(ctx) + b first: vision_transformer.py:104-105), 0 = the projection stays a GEMM launch of its own;
  *   "qkv_fused"  0 [default] / 1 = ... and LayerNorm1 + qkv of the next block at its end (blocks 1.. have no LN + qkv launch then:
