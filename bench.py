@@ -213,7 +213,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 sub-record of the headline line")
     ap.add_argument("--no-two-stream", action="store_true", help="skip the one-stream sub-record")
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2],
-                    help="0 = the library default (2: a batch of >= 16 frames runs as two half-batches on two streams); 1 / 2 force it")
+                    help="0 = the library default (2: a batch of >= 8 frames runs as two half-batches on two streams); 1 / 2 force it")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check only: no model, no GPU (gloo); prints the JSON line with value 0")
     a = ap.parse_args(argv)
@@ -336,9 +336,9 @@ def main():
     torch.cuda.synchronize()
 
     lib = capi.lib()
-    streams = a.streams if a.streams else 2         # the library default: two half-batches on two streams from 16 frames on
+    streams = a.streams if a.streams else 2         # the library default: two half-batches on two streams from 8 frames on
     capi.check(lib.dinoseg_set_option(b"streams", streams))
-    split = streams == 2 and a.batch >= 16
+    split = streams == 2 and a.batch >= 8
 
     def step():
         return model.forward_frames(frames, want_logp=True)
@@ -442,7 +442,7 @@ def main():
                          "frac": None if achieved is None else round(achieved / peak, 4),
                          "measured_how": "HIP events around every launch on the forward's stream, in an untimed pass of the same steps on "
                                          "ONE stream (exclusive launches) right after the timed loop; `value` above is timed with the "
-                                         "library default (two half-batches on two streams from 16 frames on)",
+                                         "library default (two half-batches on two streams from 8 frames on)",
                          "peak_note": "peak = dense bf16 MFMA at the nominal 2.4 GHz (MI355X_MICROARCH.md).  clock_ghz_under_load = what "
                                       "this kernel was measured to hold (rocprofv3 PMC GRBM_GUI_ACTIVE / 8 / duration, committed in "
                                       "profiles/attention_traffic.json); peak_at_measured_clock scales the peak by it",

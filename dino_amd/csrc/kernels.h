@@ -109,7 +109,7 @@ struct Options {
     int proj_fused = 1;      // 1: with mlp_variant 2 the block's attention output projection runs inside the fused MLP launch
     int mlp_variant = 2;     // 1: mlp_fused.hip (one wave per SIMD), 2: mlp_fused2.hip (role-split wave pairs)
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
-    int split_min = 16;
+    int split_min = 8;       // (8 frames @480: +6 %, 12: +16 %, 16: +12 %; 6 frames and fewer: slower split)
     int train_streams = 2;   // 2: backward runs the weight-gradient GEMMs of the blocks on the handle's side stream (train_api.hip)
     int splitk_tiles = 512;  // weight-gradient GEMMs: partial 128x128 tiles per launch (<= 768, the workspace holds that many)
     int attn_variant = 11;   // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the

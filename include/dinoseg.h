@@ -170,7 +170,7 @@ int dinoseg_profile(dinoseg_handle* h, int32_t level);
 int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
 
 /* Process-wide switches.  Keys:
- *   "streams"    2 [default] / 1: with 2, dinoseg_forward runs a batch of >= "split_min" (default 16) frames as two half-batches,
+ *   "streams"    2 [default] / 1: with 2, dinoseg_forward runs a batch of >= "split_min" (default 8) frames as two half-batches,
  *                the first on the caller's stream, the second on an internal stream forked from / joined to it by events (the
  *                call stays stream-ordered and capturable; outputs identical; +6 to +9 % frames/s at B = 32 on MI355X: one
  *                half's attention fills the CUs the other half's GEMM tails and memory phases leave idle); 1 = one stream;

@@ -402,7 +402,7 @@ def test_g4_960_batch8_frames_are_independent(cuda, precision, tol, flip_frac):
 @pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("B", [16, 17])
 def test_two_stream_split_equals_one_stream(cuda, precision, B):
-    """Option 'streams' = 2 (api.hip: dinoseg_forward): a batch of >= 16 frames runs as two half-batches on two streams.  Frames are
+    """Option 'streams' = 2 (api.hip: dinoseg_forward): a batch of >= 8 frames runs as two half-batches on two streams.  Frames are
     independent (pl_torch_modules.py:253), the kernels and the per-row arithmetic are the same: identical outputs, also for an odd
     batch, also when the call is repeated (workspaces / events reused) and when other work is queued on the caller's stream."""
     import dino_amd
