@@ -820,6 +820,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().proj_fused = value;
         return 0;
     }
+    if (strcmp(key, "mlp_stagger") == 0) {
+        dseg::options().mlp_stagger = value;
+        return 0;
+    }
     if (strcmp(key, "mlp_grid") == 0) {
         dseg::options().mlp_grid = value;
         return 0;

@@ -75,6 +75,7 @@ struct MlpFusedParams {
     const float* b1; const float* b2;           // [1536], [384]
     int M;
     int* queue;                                 // set by launch_mlp_fused: work counter of the persistent walk (zeroed per launch)
+    int n_long, sleep_max;                      // set by launch_mlp_fused2: start-time spread of the workgroups with one item fewer
     // optional (mlp_fused2 only): the block's attention output projection in the same launch, X += ctx . Wproj^T + bproj first
     const bf16_t* ctx;                          // [M, 384] bf16 attention output (row stride 384), null = MLP only
     const bf16_t* Wproj;                        // launch_pack_proj
@@ -103,6 +104,7 @@ struct Options {
     int attn_dbg = 0;        // same for AttnParams::dbg
     int mlp_fused = 1;       // the MLP half of a block as one launch (mlp_fused.hip): 0 never, 1 for >= mlp_fused_min_rows rows, 2 wherever supported
     int mlp_fused_min_rows = 12000;      // (4 frames @480: +3 %; 6 frames: +18 % with the projection inside; 2 frames: even)
+    int mlp_stagger = 0;     // experiment: > 0 = one workgroup per CU, those with one item fewer start up to this many x 3.9 us late
     int mlp_grid = 0;        // workgroups of the fused MLP launch (0 = the fewest that need no extra round: mlp_fused2.hip)
     int qkv_fused = 0;       // 1: ... and LayerNorm1 + qkv of the NEXT block at its end (blocks 1.. then have no LN+qkv launch); measured
                              // +1 % on one stream, +-0 on two: the tail is bound by the same HBM write burst as the launch it replaces

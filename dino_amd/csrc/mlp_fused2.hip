@@ -141,11 +141,14 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
             for (int i = tid; i < 3 * D / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + BQ_OFF)[i] = reinterpret_cast<const f32x4*>(p.bqkv)[i];
         }
     }
-#ifndef MF2_STAGGER
-#define MF2_STAGGER 0      // experiment: odd workgroups start MF2_STAGGER x 8128 cycles late (desynchronises the HBM bursts of item boundaries)
-#endif
-    if (MF2_STAGGER > 0 && (blockIdx.x & 1))
-        for (int i = 0; i < MF2_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    // Free desynchronisation (p.sleep_max > 0): with nitems = q * grid + r the workgroups >= r walk one item fewer than the others, so
+    // they may start up to one item late without lengthening the launch -- spread over that window they leave the lock step in which
+    // every CU stores / loads its rows at the same moment (the HBM bursts of the item boundaries)
+    if (p.sleep_max > 0 && (int)blockIdx.x >= p.n_long) {
+        const int n_short = (int)gridDim.x - p.n_long;
+        const int reps = (int)(((long)p.sleep_max * ((int)blockIdx.x - p.n_long + 1)) / n_short);
+        for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
     const float* const sB1 = reinterpret_cast<const float*>(smem + B1_OFF);
     const float* const sB2 = reinterpret_cast<const float*>(smem + B2_OFF);
@@ -955,7 +958,9 @@ int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s) {
     // persistent grid: as few workgroups as finish in the same number of rounds (901 items on 256 CUs take 4 rounds: 226 workgroups
     // do it too and leave 30 CUs to the other stream's kernels; measured +0.4 % frames/s); option mlp_grid overrides
     int grid;
-    if (options().mlp_grid > 0) {
+    if (options().mlp_stagger > 0) {
+        grid = nitems < ncu ? nitems : ncu;
+    } else if (options().mlp_grid > 0) {
         grid = options().mlp_grid < ncu ? options().mlp_grid : ncu;
         if (grid > nitems) grid = nitems;
     } else {
@@ -964,6 +969,8 @@ int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s) {
     }
     MlpFusedParams q = p;
     q.queue = nullptr;
+    q.n_long = nitems % grid;      // workgroups 0 .. n_long-1 walk one item more than the others (0: all the same)
+    q.sleep_max = q.n_long > 0 && nitems > grid ? options().mlp_stagger : 0;
 #if MF2_STAMP
     static unsigned long long* sbuf = nullptr;
     const size_t sbytes = (size_t)grid * 2 * 4 * 16 * 2 * 8;
