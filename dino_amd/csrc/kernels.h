@@ -198,7 +198,7 @@ struct TnParams {
 int launch_gemm_tn(const TnParams& p, hipStream_t s);
 int launch_splitk_reduce(const float* part, int ks, long stride, int rows, int ld_part, float* out, int ldo, int cols, hipStream_t s);
 int launch_batch_sum_rows(const float* X, int B, int ntok, int D, float* out, hipStream_t s);
-int launch_pos_resample_bwd(const float* dpos, int g, int D, int o, float* dpe, hipStream_t s);
+int launch_pos_resample_bwd(const float* dpos, int g, int D, int o, float* dpe, float* scratch /* g*o*D floats */, hipStream_t s);
 constexpr int MULTI_MAX = 64;       // tensors per multi-tensor launch (table passed as a kernel argument)
 int launch_multi_adam(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const long* n, float lr,
                       float b1, float b2, float eps, float wd, int decoupled, int step, float gscale, hipStream_t s);

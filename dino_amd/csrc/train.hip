@@ -364,9 +364,9 @@ __device__ __forceinline__ void cubic_w_bwd(float t, float w[4]) {
     w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
 }
 
-// Gather form (deterministic, no atomics): one thread per stored element (yy, xx, d) sums the resampled-grid gradients whose
-// clamped 4 x 4 taps include it -- separable: sum_y Wy(y, yy) sum_x Wx(x, xx) dpos[y][x][d], Wy(y, yy) = the sum of the taps of y that
-// clamp to yy.  (The scatter form -- 16 fp32 atomics per resampled element onto 785 x 384 addresses -- took 70 us at 28 -> 60.)
+// Gather form (deterministic, no atomics): a stored element (yy, xx, d) is the sum of the resampled-grid gradients whose clamped
+// 4 x 4 taps include it -- separable: sum_x Wx(x, xx) sum_y Wy(y, yy) dpos[y][x][d], Wy(y, yy) = the sum of the taps of y that clamp
+// to yy; two passes through a [g][o][D] scratch (the one-pass gather read 144 values per element: 44 us).  (The scatter form -- 16 fp32 atomics per resampled element onto 785 x 384 addresses -- took 70 us at 28 -> 60.)
 __device__ __forceinline__ float tap_weight(int y, int yy, int g, float scale) {
     const float sy = (y + 0.5f) * scale - 0.5f;
     const float fy = floorf(sy);
@@ -389,38 +389,57 @@ __device__ __forceinline__ void tap_range(int yy, int g, int o, float scale, int
     if (yy == 0 || lo < 0) lo = 0;
     if (yy == g - 1 || hi > o - 1) hi = o - 1;
 }
-__global__ void pos_resample_bwd_kernel(const float* __restrict__ dpos, int g, int D, int o, float scale,
-                                        float* __restrict__ dpe) {
+// separable: pass 1 sums the rows (tmp[yy][x][d] = sum_y Wy(y, yy) dpos[y][x][d]), pass 2 the columns into the stored gradient
+__global__ void pos_resample_bwd_rows_kernel(const float* __restrict__ dpos, int g, int D, int o, float scale, float* __restrict__ tmp) {
+    const long total = (long)g * o * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const long t = i / D;
+        const int x = (int)(t % o), yy = (int)(t / o);
+        int ylo, yhi;
+        tap_range(yy, g, o, scale, ylo, yhi);
+        float acc = 0.f;
+        for (int y = ylo; y <= yhi; ++y) acc = fmaf(tap_weight(y, yy, g, scale), dpos[(1 + (long)y * o + x) * D + d], acc);
+        tmp[i] = acc;
+    }
+}
+__global__ void pos_resample_bwd_cols_kernel(const float* __restrict__ dpos, const float* __restrict__ tmp, int g, int D, int o,
+                                             float scale, float* __restrict__ dpe) {
     const long total = ((long)g * g + 1) * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int d = (int)(i % D);
         const long tokn = i / D;
-        if (tokn == 0 || o == g) {
-            dpe[i] += dpos[i];      // class pos / identity grid: same index
+        if (tokn == 0) {
+            dpe[i] += dpos[i];      // class pos: same index
             continue;
         }
         const int yy = (int)((tokn - 1) / g), xx = (int)((tokn - 1) % g);
-        int ylo, yhi, xlo, xhi;
-        tap_range(yy, g, o, scale, ylo, yhi);
+        int xlo, xhi;
         tap_range(xx, g, o, scale, xlo, xhi);
         float acc = 0.f;
-        for (int y = ylo; y <= yhi; ++y) {
-            const float wy = tap_weight(y, yy, g, scale);
-            if (wy == 0.f) continue;
-            float row = 0.f;
-            for (int x = xlo; x <= xhi; ++x) row = fmaf(tap_weight(x, xx, g, scale), dpos[(1 + (long)y * o + x) * D + d], row);
-            acc = fmaf(wy, row, acc);
-        }
+        for (int x = xlo; x <= xhi; ++x) acc = fmaf(tap_weight(x, xx, g, scale), tmp[((long)yy * o + x) * D + d], acc);
         dpe[i] += acc;
     }
 }
+__global__ void pos_identity_bwd_kernel(const float* __restrict__ dpos, long total, float* __restrict__ dpe) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) dpe[i] += dpos[i];
+}
 
-int launch_pos_resample_bwd(const float* dpos, int g, int D, int o, float* dpe, hipStream_t s) {
-    const long total = ((long)g * g + 1) * D;
-    int grid = (int)((total + 255) / 256);
-    if (grid > 4096) grid = 4096;
+// scratch: g * o * D floats (the row pass)
+int launch_pos_resample_bwd(const float* dpos, int g, int D, int o, float* dpe, float* scratch, hipStream_t s) {
     const float scale = (float)(1.0 / (((double)o + 0.1) / (double)g));
-    hipLaunchKernelGGL(pos_resample_bwd_kernel, dim3(grid), dim3(256), 0, s, dpos, g, D, o, scale, dpe);
+    if (o == g) {      // identity grid
+        const long total = ((long)g * g + 1) * D;
+        hipLaunchKernelGGL(pos_identity_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpos, total, dpe);
+        DSEG_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    const long t1 = (long)g * o * D, t2 = ((long)g * g + 1) * D;
+    int g1 = (int)((t1 + 255) / 256), g2 = (int)((t2 + 255) / 256);
+    if (g1 > 8192) g1 = 8192;
+    if (g2 > 8192) g2 = 8192;
+    hipLaunchKernelGGL(pos_resample_bwd_rows_kernel, dim3(g1), dim3(256), 0, s, dpos, g, D, o, scale, scratch);
+    hipLaunchKernelGGL(pos_resample_bwd_cols_kernel, dim3(g2), dim3(256), 0, s, dpos, scratch, g, D, o, scale, dpe);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -752,7 +752,14 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
     DSEG_TRY(launch_batch_sum_rows(dX, B, L.ntok, D, dpos, s));
     if (grad("dino.cls_token"))
         DSEG_CHECK_HIP(hipMemcpyAsync(grad("dino.cls_token"), dpos, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
-    if (grad("dino.pos_embed")) DSEG_TRY(launch_pos_resample_bwd(dpos, c.pos_grid, D, r / 8, grad("dino.pos_embed"), s));
+    // (scratch: the T2 transpose buffer, idle until the patch-embed gradient below; [pos_grid][r/8][D] floats fit its >= Mppad x 256 bf16)
+    if (grad("dino.pos_embed")) {
+        if ((size_t)c.pos_grid * (r / 8) * D * sizeof(float) > (size_t)L.t_plane * P * sizeof(bf16_t)) {
+            dinoseg_set_error("dinoseg_backward: pos-embed scratch does not fit (pos_grid %d, grid %d)", c.pos_grid, r / 8);
+            return -1;
+        }
+        DSEG_TRY(launch_pos_resample_bwd(dpos, c.pos_grid, D, r / 8, grad("dino.pos_embed"), reinterpret_cast<float*>(T2), s));
+    }
     DSEG_TRY(launch_transpose_planes(dX, nullptr, 0, D, L.Mp, D, T1, tpl, pad128(D), L.Mppad, nullptr, 0, 0,
                                      grad("dino.patch_embed.proj.bias"), P, 1, L.ntok, s));
     if (grad("dino.patch_embed.proj.weight")) {
