@@ -419,7 +419,12 @@ def main():
         measured_peak = (tj.get("measured_mfma_peak_tflops") or {}).get("random_operands") if a.precision == "bf16" else None
 
     if rank == 0:
-        attn_symbol = ("dseg::attn_fwd_z_kernel<1, 4, 4> (attention_z.hip: fused QK^T-softmax-PV, head_dim 64, zero-reference softmax)"
+        # the instantiation the one-stream roofline pass launches (attention_z.hip's rule: 256-query workgroups from one round of
+        # 128-query ones on)
+        heads_ = 6 if a.arch == "vit_small" else 12
+        wgs4 = (a.batch * heads_ + 7) // 8 * 8 * (((a.res // 8) ** 2 + 1 + 127) // 128)
+        nw = 8 if wgs4 >= 4 * torch.cuda.get_device_properties(dev).multi_processor_count else 4
+        attn_symbol = (f"dseg::attn_fwd_z_kernel<1, 4, {nw}> (attention_z.hip: fused QK^T-softmax-PV, head_dim 64, zero-reference softmax)"
                        if a.precision == "bf16" else
                        "dseg::attn_fwd_kernel<2, 4, false, 3> (attention.hip: fused QK^T-softmax-PV, head_dim 64, hi+lo planes)")
         out = {

@@ -589,6 +589,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             a.q = Q; a.k = Kb; a.v = V; a.qkv_plane = L.qkv_plane;
             a.ctx = CTX; a.ctx_plane = L.ctx_plane; a.lse = nullptr;
             a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P;
+            a.shared_gpu = h->in_split ? 1 : 0;
             DSEG_PROF(DINOSEG_PROF_ATTN, DSEG_TRY(launch_attention(a, s)));
         }
         const bool fuse_mlp = h->packed_mlp.count(b) && mlp_fuse_wanted(h, L.M);
@@ -732,9 +733,11 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
     if (mlp_fuse_wanted(h, B0 * ntok_) || mlp_fuse_wanted(h, B1 * ntok_)) DSEG_TRY(ensure_mlp_packs(h, s));   // before the fork: both halves read them
     DSEG_CHECK_HIP(hipEventRecord(h->ev_fork, s));
     DSEG_CHECK_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+    h->in_split = true;
     const int rc0 = forward_impl(h, x, x_kind, B0, r, logp_out, argmax_out, -1, nullptr, nullptr, stream);
     const int rc1 = forward_impl(h, x1, x_kind, B1, r, logp_out ? logp_out + (size_t)B0 * n * h->cfg.n_classes : nullptr,
                                  argmax_out ? argmax_out + (size_t)B0 * n : nullptr, -1, nullptr, nullptr, h->aux_stream, nullptr, 1);
+    h->in_split = false;
     // join even after an error: the caller's stream must not run ahead of work already queued on the internal one
     DSEG_CHECK_HIP(hipEventRecord(h->ev_join, h->aux_stream));
     DSEG_CHECK_HIP(hipStreamWaitEvent(s, h->ev_join, 0));

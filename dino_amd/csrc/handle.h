@@ -60,6 +60,7 @@ struct dinoseg_handle {
     int ws2_B = -1, ws2_r = -1;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool in_split = false;                 // a split forward is being queued (both halves' launches share the chip)
     // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
     // fine-tune step state (train_api.hip)
     std::map<std::string, float*> grads;   // bound gradient buffers (absent / null = frozen tensor)

@@ -127,6 +127,7 @@ struct AttnParams {
     float* lse;                        // optional [B,H,ntok] log2-domain log-sum-exp (for backward), may be null
     int B, heads, ntok, npad, planes;
     int dbg;                           // timing-only ablations: bit0 skip max/exp, bit1 skip steady-state loads, bit2 skip PV
+    int shared_gpu;                    // hint: another stream's kernels run beside this launch (the split forward): prefer wide workgroups
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
 int launch_attention_z(const AttnParams& p, hipStream_t s);    // zero-reference softmax, <= 128 registers: 4 waves per SIMD (attention_z.hip)
