@@ -99,15 +99,18 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
-template <int PLANES>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
+// NW waves (32 queries each) per workgroup share the K/V tiles: 16 / NW LDS-DMA pieces per wave and tile
+template <int PLANES, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
+    constexpr int QBLK = NW * 32;
+    static_assert(16 % NW == 0, "pieces per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = PLANES * 2 * BKV_TILE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
 
-    const int nq = (p.ntok + 127) / 128;
+    const int nq = (p.ntok + QBLK - 1) / QBLK;
     const int npairs = p.B * p.heads;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int pair = (slot / nq) * 8 + xcd, qt = slot % nq;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     const bf16_t* Kg = p.k + pair_off;
     const bf16_t* Vg = p.v + pair_off;
 
-    const int qrow = qt * 128 + wave * 32 + lr;
+    const int qrow = qt * QBLK + wave * 32 + lr;
     const int qc = qrow < ntok ? qrow : ntok - 1;
     bf16x8 qf[PLANES][4], df[PLANES][4];
     const bf16_t* dOrow = p.dO + ((long)b * ntok + qc) * dm + head * 64;
@@ -145,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int piece = wave * 4 + i;
+            for (int i = 0; i < 16 / NW; ++i) {
+                const int piece = wave * (16 / NW) + i;
                 const int row = (piece & 7) * 8 + (lane >> 3);
                 const int c = bswz(row, lane & 7);
                 const bf16_t* src = (piece < 8 ? Kg : Vg) + pl * p.qkv_plane + (long)(key0 + row) * 64 + c * 8;
@@ -253,15 +256,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int PLANES>
-__global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+template <int PLANES, int NW>
+__global__ __launch_bounds__(NW * 64, (PLANES == 1 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+    constexpr int KBLK = NW * 32;
+    static_assert(16 % NW == 0 && NW >= 2, "pieces per wave; waves 0 and 1 fetch the row terms");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = PLANES * 2 * BKV_TILE + 512;     // Q~ and dO slabs per plane + 64 x (-LSE2, -delta)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
 
-    const int nkb = (p.ntok + 127) / 128;
+    const int nkb = (p.ntok + KBLK - 1) / KBLK;
     const int npairs = p.B * p.heads;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int pair = (slot / nkb) * 8 + xcd, kt = slot % nkb;
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void attn_bwd_dkv_kerne
     const float* ndg = p.neg_delta + (long)pair * npad;
 
     // this wave's 32 keys: K and V fragments as B operands (k = d, column = key)
-    const int krow = kt * 128 + wave * 32 + lr;
+    const int krow = kt * KBLK + wave * 32 + lr;
     const int kc = krow < npad ? krow : npad - 1;
     bf16x8 kf[PLANES][4], vf[PLANES][4];
 #pragma unroll
@@ -293,8 +298,8 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void attn_bwd_dkv_kerne
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int piece = wave * 4 + i;               // 0..7: Q~ rows, 8..15: dO rows
+            for (int i = 0; i < 16 / NW; ++i) {
+                const int piece = wave * (16 / NW) + i;       // 0..7: Q~ rows, 8..15: dO rows
                 const int row = (piece & 7) * 8 + (lane >> 3);
                 const int c = bswz(row, lane & 7);
                 const bf16_t* src;
@@ -437,26 +442,26 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void attn_bwd_dkv_kerne
     }
 }
 
-template <int PLANES>
+template <int PLANES, int NW, int NWK = NW>      // waves per workgroup of the dQ / the dK,dV kernel
 static int launch_bwd(const AttnBwdParams& p, hipStream_t s) {
-    const int nq = (p.ntok + 127) / 128;
+    const int nq = (p.ntok + NW * 32 - 1) / (NW * 32), nkb = (p.ntok + NWK * 32 - 1) / (NWK * 32);
     const int npairs = p.B * p.heads;
-    const int grid = ((npairs + 7) / 8) * 8 * nq;
+    const int grid = ((npairs + 7) / 8) * 8 * nq, grid_k = ((npairs + 7) / 8) * 8 * nkb;
     const size_t lds_dq = (size_t)2 * PLANES * 2 * BKV_TILE;
     const size_t lds_dkv = (size_t)2 * (PLANES * 2 * BKV_TILE + 512);
     static PerDeviceOnce once;
     if (once.first()) {
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<PLANES>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<PLANES, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<PLANES>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<PLANES, NWK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
         once.mark();
     }
     const long row_groups = (long)p.B * p.heads * (p.npad / 8);      // 8 rows per wave, 4 waves per block
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, p.dO, p.O, p.dO_plane, PLANES,
                        p.lse, p.B, p.heads, p.ntok, p.npad, p.neg_lse, p.neg_delta);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<PLANES>), dim3(grid), dim3(256), lds_dq, s, p);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<PLANES>), dim3(grid), dim3(256), lds_dkv, s, p);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<PLANES, NW>), dim3(grid), dim3(NW * 64), lds_dq, s, p);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<PLANES, NWK>), dim3(grid_k), dim3(NWK * 64), lds_dkv, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -466,8 +471,17 @@ int launch_attention_bwd(const AttnBwdParams& p, hipStream_t s) {
         dinoseg_set_error("attention_bwd: npad=%d must be a multiple of 64 and >= ntok=%d", p.npad, p.ntok);
         return -1;
     }
-    if (p.planes == 1) return launch_bwd<1>(p, s);
-    if (p.planes == 2) return launch_bwd<2>(p, s);
+    if (p.planes == 1) {
+        // 256-query workgroups for the dQ kernel once the 128-row grid is a round deep (2 workgroups of 4 waves per CU): half the
+        // LDS-DMA pieces per wave and tile, as in attention_z.hip; same arithmetic per row
+        const int ncu = device_cu_count();
+        const long wgs4 = (long)((p.B * p.heads + 7) / 8) * 8 * ((p.ntok + 127) / 128);
+        // (dQ kernel only: the dK,dV kernel holds three 4-wave workgroups per CU at its 166 registers, an 8-wave one would be alone;
+        //  measured at 8 frames @480: 1509 -> 1515 frames/s with both wide, 1522 with dQ wide only)
+        if (ncu > 0 && wgs4 >= 2L * ncu && !(options().attn_variant & 64)) return launch_bwd<1, 8, 4>(p, s);
+        return launch_bwd<1, 4>(p, s);
+    }
+    if (p.planes == 2) return launch_bwd<2, 4>(p, s);
     dinoseg_set_error("attention_bwd: planes must be 1 or 2");
     return -1;
 }
