@@ -324,13 +324,40 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int ks, lon
         out[(long)r * ldo + c] += a;
     }
 }
+// cols, ld_part, ldo multiples of 4 (every transformer-block weight): 16 bytes per lane and slice, four slices in flight
+__global__ void splitk_reduce4_kernel(const float* __restrict__ part, int ks, long stride, int rows, int ld_part,
+                                      float* __restrict__ out, int ldo, int cols4) {
+    const long total = (long)rows * cols4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols4), c = (int)(i - (long)r * cols4) * 4;
+        const float* src = part + (long)r * ld_part + c;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        int sl = 0;
+        for (; sl + 4 <= ks; sl += 4) {
+            a0 += *reinterpret_cast<const f32x4*>(src + (long)sl * stride);
+            a1 += *reinterpret_cast<const f32x4*>(src + (long)(sl + 1) * stride);
+            a2 += *reinterpret_cast<const f32x4*>(src + (long)(sl + 2) * stride);
+            a3 += *reinterpret_cast<const f32x4*>(src + (long)(sl + 3) * stride);
+        }
+        for (; sl < ks; ++sl) a0 += *reinterpret_cast<const f32x4*>(src + (long)sl * stride);
+        f32x4* dst = reinterpret_cast<f32x4*>(out + (long)r * ldo + c);
+        *dst = *dst + ((a0 + a1) + (a2 + a3));
+    }
+}
 
 int launch_splitk_reduce(const float* part, int ks, long stride, int rows, int ld_part, float* out, int ldo, int cols, hipStream_t s) {
     const long total = (long)rows * cols;
-    int grid = (int)((total + 255) / 256);
-    if (grid > 8192) grid = 8192;
-    if (grid < 1) return 0;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, part, ks, stride, rows, ld_part, out, ldo, cols);
+    if (total < 1) return 0;
+    if (cols % 4 == 0 && ld_part % 4 == 0 && ldo % 4 == 0 && stride % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        int grid = (int)((total / 4 + 255) / 256);
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(grid), dim3(256), 0, s, part, ks, stride, rows, ld_part, out, ldo, cols / 4);
+    } else {
+        int grid = (int)((total + 255) / 256);
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, part, ks, stride, rows, ld_part, out, ldo, cols);
+    }
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
