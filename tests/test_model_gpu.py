@@ -451,6 +451,28 @@ def test_two_stream_split_equals_one_stream(cuda, precision, B):
         dino_amd.set_option("streams", 2)                      # the library default
 
 
+def test_two_stream_split_equals_one_stream_fused_routes(cuda):
+    """The same identity on the large-batch routes of the bf16 mode at 480x480: 9 frames = half-batches of 5 and 4 frames, each above the
+    12 000-row threshold of the fused projection + MLP launch, attention in 256-query workgroups on both sides, the fragment-order
+    weight packs made before the fork.  One stream runs the 9 frames as one batch through the same kernels: bit-identical outputs,
+    every frame equal to its single-frame run up to the route change below the threshold (bounded like the other bf16 checks)."""
+    import dino_amd
+    m, _, _ = build(2, "bf16")
+    frames = torch.from_numpy(synthetic_frames(9, 480, seed=79)).cuda()
+    dino_amd.set_option("streams", 1)
+    try:
+        lp1, am1 = m.forward_frames(frames)
+        lp1, am1 = lp1.clone(), am1.clone()
+        dino_amd.set_option("streams", 2)
+        for _ in range(2):
+            lp2, am2 = m.forward_frames(frames)
+            assert torch.equal(lp2, lp1) and torch.equal(am2, am1)
+        single, _ = m.forward_frames(frames[4:5])            # one frame: unfused route (3601 rows)
+        assert float((single - lp1.reshape(9, 3600, -1)[4]).abs().max()) <= 0.2
+    finally:
+        dino_amd.set_option("streams", 2)
+
+
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-3), ("bf16", 0.35)])
 def test_linear_dispatch_paths_agree(cuda, precision, tol):
     """The LN-fed linears have three routes (option 'gemm_ln': 0 = LayerNorm kernel + GEMM, 2 = fused kernel wherever it is
