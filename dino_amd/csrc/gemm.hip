@@ -278,7 +278,8 @@ int launch_gemm(const GemmParams& p0, hipStream_t s) {
         // (planes == 2: 128-row tiles of three times the work)
         const int bm_big = p.planes == 2 ? 128 : 256;
         const long tiles = (long)((p.M + bm_big - 1) / bm_big) * (p.N / 384);
-        if (options().gemm_big > 1 || p.K % BK != 0 || (tiles >= 128 && (tiles >= 512 || p.K >= 1024))) return launch_gemm_big(p, s);
+        // (K >= 768: ViT-B's attn.proj at 8-16 frames -- 226-450 tiles -- 1.66 -> 1.41 ms per step on the persistent kernel)
+        if (options().gemm_big > 1 || p.K % BK != 0 || (tiles >= 128 && (tiles >= 512 || p.K >= 768))) return launch_gemm_big(p, s);
     }
     return launch_gemm_small(p, s);
 }
