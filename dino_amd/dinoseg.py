@@ -162,6 +162,14 @@ class _ViTParams(nn.Module):
         """vision_transformer.py:273-280; reference call site visualize_attention.py:46."""
         return self._owner().get_last_selfattention(x, cls_mask)
 
+    def get_intermediate_layers(self, x: torch.Tensor, n: int = 1) -> list:
+        """vision_transformer.py:282-290: ``norm(x)`` of all tokens after each of the last ``n`` blocks, oldest first (a list of
+        [B, N, D] tensors; every block when n exceeds the depth).  One ``dinoseg_features`` call per tap: the library keeps one
+        residual stream, so the forward is re-run up to the tapped block (n is 1 in every published use of this method)."""
+        owner = self._owner()
+        L = owner.cfg.n_blocks
+        return [owner.features(x, n_blocks=i + 1) for i in range(L) if L - i <= n]
+
     def forward_mask(self, x, cls_mask):
         """vision_transformer.py:250-271."""
         return self._owner().forward_mask(x, cls_mask)
@@ -275,6 +283,36 @@ class DINOSeg(nn.Module):
     def _param_signature(self):
         return (self._weights_epoch,) + tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items())
 
+    # The full signature walks state_dict() (~0.2 ms for 156 tensors): a 20-40 % tax on a single-frame predict().  The fast check
+    # below sees the same events without building it: every tensor's version counter and address (in-place updates, optimizer
+    # steps, load_state_dict, .to()), the identity of every entry of every module's parameter / buffer / child table (a replaced
+    # Parameter or sub-module), and the tables' sizes (an added one).  Only when it differs is the full signature rebuilt.
+    def _build_fast_index(self):
+        tens, tables = [], []
+        for mod in self.modules():
+            for d in (mod._parameters, mod._buffers, mod._modules):
+                tables.append((d, len(d)))
+                tens.extend((d, k, t) for k, t in d.items() if t is not None)
+        return tens, tables
+
+    def _fast_signature(self):
+        idx = self.__dict__.get("_fast_index")
+        if idx is None:
+            return None
+        tens, tables = idx
+        for d, n in tables:
+            if len(d) != n:
+                return None
+        vers = []
+        for d, k, t in tens:
+            if d.get(k) is not t:
+                return None
+            if isinstance(t, torch.Tensor):
+                vers.append(t._version)
+                vers.append(t.data_ptr())
+        vers.append(self._weights_epoch)
+        return vers
+
     def invalidate_weights(self) -> None:
         """Force a re-pack of the bf16 weight planes on the next call.  In-place edits through ``p.data`` (or any write that
         does not bump the tensor version counter) are invisible to the automatic check; call this after them."""
@@ -290,6 +328,8 @@ class DINOSeg(nn.Module):
         state["_handle"] = None
         state["_bound_sig"] = None
         state["_grad_sig"] = None
+        state.pop("_fast_index", None)
+        state.pop("_fast_sig", None)
         state.pop("_adam_state", None)
         state.pop("_grad_bucket_cache", None)
         return state
@@ -314,8 +354,14 @@ class DINOSeg(nn.Module):
             capi.check(lib.dinoseg_create(C.byref(cfg), C.byref(h)))
             self._handle = h
             self._bound_sig = None
+        if self._bound_sig is not None:
+            fast = self._fast_signature()
+            if fast is not None and fast == self.__dict__.get("_fast_sig"):
+                return
         sig = self._param_signature()
         if sig == self._bound_sig:
+            self._fast_index = self._build_fast_index()
+            self._fast_sig = self._fast_signature()
             return
         for name, t in self.state_dict(keep_vars=True).items():
             if t.dtype != torch.float32 or not t.is_contiguous():
@@ -324,6 +370,8 @@ class DINOSeg(nn.Module):
             capi.check(lib.dinoseg_bind_weight(self._handle, name.encode(), t.data_ptr(), shape, t.dim()))
         capi.check(lib.dinoseg_refresh_weights(self._handle, self._stream()))
         self._bound_sig = sig
+        self._fast_index = self._build_fast_index()
+        self._fast_sig = self._fast_signature()
 
     def set_precision(self, precision: str) -> None:
         if precision not in _PRECISIONS:
@@ -679,31 +727,40 @@ class DINOSeg(nn.Module):
                 grad_scale, self._stream()))
         self.invalidate_weights()      # weights changed in place through raw pointers: re-pack on the next forward
 
-    def fit(self, ck_file_name=None, train_dataloader=None, val_dataloader=None, test_dataloader=None, max_epochs=None):
-        """The reference's ``fit`` (pl_torch_modules.py:367-431) without Lightning: freeze / unfreeze the backbone, train
-        ``max_epochs`` epochs with ``fused_training_step`` + the fused optimizer step, validate after every epoch
-        (``check_val_every_n_epoch=1``), keep the checkpoint with the best ``val_acc`` (``ModelCheckpoint(monitor='val_acc',
-        mode='max')``) at ``write_path/<ck_file_name>.ckpt`` in the PL-1.5 schema, then run the test split and set
-        ``self.best_ck``.  The dataset / augmentation pipeline is out of scope, so the dataloaders are
-        arguments: any iterables of ``(x, y)`` batches with x uint8 [B,r,r,3] or fp32 [B,3,r,r] and y int [B,(r/8)^2].
-        Returns {'history': [per-epoch metrics], 'test': test metrics or None}."""
-        import os
+    def training_epoch_end(self, outputs):
+        """pl_torch_modules.py:343-345: the train-split metrics of an epoch (the reference computes and drops them).  Accepts the
+        reference's step outputs ({'pred', 'gt', ...}) as well as this class's ({'confusion'})."""
+        outs = []
+        for o in outputs:
+            if "confusion" not in o:
+                pred = torch.as_tensor(o["pred"]).to(self.device).reshape(-1).to(torch.int32).contiguous()
+                gt = torch.as_tensor(o["gt"]).to(self.device).reshape(-1).long().contiguous()
+                cm = torch.zeros((self.cfg.n_classes, self.cfg.n_classes), dtype=torch.int64, device=self.device)
+                capi.check(capi.lib().dinoseg_op_confusion(pred.data_ptr(), gt.data_ptr(), gt.numel(), self.cfg.n_classes,
+                                                           cm.data_ptr(), self._stream()))
+                o = {"confusion": cm}
+            outs.append(o)
+        return self.validation_epoch_end(outs, prefix="train")
 
+    def _no_dataset(self, what):
+        raise NotImplementedError(
+            f"DINOSeg.{what}(): the DuckieSegDataset / albumentations pipeline (pl_torch_modules.py:347-365) is not part of "
+            "dino_amd (DESIGN.md section 6); pass dataloaders to fit(), or override this hook in a subclass")
+
+    def train_dataloader(self, sim=False):
+        self._no_dataset("train_dataloader")
+
+    def val_dataloader(self, sim=False):
+        self._no_dataset("val_dataloader")
+
+    def test_dataloader(self):
+        self._no_dataset("test_dataloader")
+
+    def _fit_phase(self, train_dataloader, val_dataloader, ck_path, max_epochs, step):
+        """One ``Trainer.fit`` of the reference: ``max_epochs`` epochs, validation after each, best ``val_acc`` checkpointed."""
         from .ckpt import save_checkpoint
-        if train_dataloader is None or val_dataloader is None:
-            raise ValueError("fit() needs train_dataloader and val_dataloader (the DuckieSegDataset pipeline is not part of dino_amd)")
-        if self.freeze_backbone:
-            self.freeze_bb()
-        else:
-            self.unfreeze_bb()
-        if ck_file_name is None:        # same naming rule as the reference
-            ck_file_name = (str(self.n_blocks) + "_" + self.head + ("_frozen" if self.freeze_backbone else "_finetuned") +
-                            ("_grayscale" if self.grayscale else ""))
-        out_dir = self.write_path if self.write_path is not None else "."
-        os.makedirs(out_dir, exist_ok=True)
-        ck_path = os.path.join(out_dir, ck_file_name + ".ckpt")
-        best, history, step = -1.0, [], 0
-        for epoch in range(self.max_epochs if max_epochs is None else max_epochs):
+        best, history = -1.0, []
+        for epoch in range(max_epochs):
             cms, losses = [], []
             for bi, (x, y) in enumerate(train_dataloader):
                 out = self.fused_training_step((x, y), bi)
@@ -723,13 +780,60 @@ class DINOSeg(nn.Module):
             if metrics["val_acc"] > best:
                 best = metrics["val_acc"]
                 save_checkpoint(self, ck_path, epoch=epoch, global_step=step)
+        return history, step
+
+    def fit(self, ck_file_name=None, train_dataloader=None, val_dataloader=None, test_dataloader=None, max_epochs=None,
+            sim_dataloader=None):
+        """The reference's ``fit`` (pl_torch_modules.py:367-431) without Lightning: freeze / unfreeze the backbone, train
+        ``max_epochs`` epochs with ``fused_training_step`` + the fused optimizer step, validate after every epoch
+        (``check_val_every_n_epoch=1``), keep the checkpoint with the best ``val_acc`` (``ModelCheckpoint(monitor='val_acc',
+        mode='max')``) at ``write_path/<ck_file_name>.ckpt`` in the PL-1.5 schema, then run the test split and set
+        ``self.best_ck``.  With ``pretrain_on_sim=True`` (ctor kwarg, :391-401) a first phase of ``max_epochs`` epochs runs on
+        ``sim_dataloader`` (validated on the REAL validation split, like the reference's ``val_dataloader(sim=False)``) before the
+        main phase; each phase tracks its own best ``val_acc`` (the reference builds a fresh ``ModelCheckpoint`` per phase), the
+        main phase's best is what ``best_ck`` names.  The dataset / augmentation pipeline is out of scope,
+        so the dataloaders are arguments (or the ``train_dataloader() / val_dataloader() / test_dataloader()`` hooks of a
+        subclass): any iterables of ``(x, y)`` batches with x uint8 [B,r,r,3] or fp32 [B,3,r,r] and y int [B,(r/8)^2].
+        Returns {'history': [per-epoch metrics of the main phase], 'sim_history': [...] or None, 'test': test metrics or None}."""
+        import os
+
+        hooks = type(self).train_dataloader is not DINOSeg.train_dataloader
+        if train_dataloader is None and hooks:
+            train_dataloader = self.train_dataloader()
+        if val_dataloader is None and type(self).val_dataloader is not DINOSeg.val_dataloader:
+            val_dataloader = self.val_dataloader()
+        if test_dataloader is None and type(self).test_dataloader is not DINOSeg.test_dataloader:
+            test_dataloader = self.test_dataloader()
+        if train_dataloader is None or val_dataloader is None:
+            raise ValueError("fit() needs train_dataloader and val_dataloader (the DuckieSegDataset pipeline is not part of dino_amd)")
+        if self.pretrain_on_sim and sim_dataloader is None:
+            if hooks:
+                sim_dataloader = self.train_dataloader(sim=True)
+            else:
+                raise ValueError("pretrain_on_sim=True needs fit(sim_dataloader=...): the simulation split's loader "
+                                 "(pl_torch_modules.py:391-401 builds it from train_path_sim, which is not part of dino_amd)")
+        if self.freeze_backbone:
+            self.freeze_bb()
+        else:
+            self.unfreeze_bb()
+        if ck_file_name is None:        # same naming rule as the reference
+            ck_file_name = (str(self.n_blocks) + "_" + self.head + ("_frozen" if self.freeze_backbone else "_finetuned") +
+                            ("_grayscale" if self.grayscale else ""))
+        out_dir = self.write_path if self.write_path is not None else "."
+        os.makedirs(out_dir, exist_ok=True)
+        ck_path = os.path.join(out_dir, ck_file_name + ".ckpt")
+        epochs = self.max_epochs if max_epochs is None else max_epochs
+        sim_history, step = None, 0
+        if self.pretrain_on_sim:
+            sim_history, step = self._fit_phase(sim_dataloader, val_dataloader, ck_path, epochs, 0)
+        history, step = self._fit_phase(train_dataloader, val_dataloader, ck_path, epochs, 0)
         self.best_ck = ck_path if history else None
         test = None
         if test_dataloader is not None:
             test = self.test_epoch_end([self.test_step(b, i) for i, b in enumerate(test_dataloader)])
         if self.comet_logger is not None and self.best_ck is not None:
             self.comet_logger.experiment.log_asset(self.best_ck)
-        return {"history": history, "test": test}
+        return {"history": history, "sim_history": sim_history, "test": test}
 
     def freeze_bb(self):
         for p in self.dino.parameters():

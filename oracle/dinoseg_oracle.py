@@ -182,6 +182,18 @@ def vit_forward(x: Tensor, W: Dict[str, Tensor], num_heads: int, patch: int = 8,
     return layer_norm(t, W["dino.norm.weight"], W["dino.norm.bias"], eps)
 
 
+def intermediate_layers(x: Tensor, W: Dict[str, Tensor], num_heads: int, n: int = 1, patch: int = 8, eps: float = 1e-6) -> list:
+    """norm(x) after each of the last n blocks (VisionTransformer.get_intermediate_layers, vision_transformer.py:282-290)."""
+    t = prepare_tokens(x, W, patch)
+    L = count_blocks(W)
+    out = []
+    for i in range(L):
+        t = block(t, W, i, num_heads, eps)
+        if L - i <= n:
+            out.append(layer_norm(t, W["dino.norm.weight"], W["dino.norm.bias"], eps))
+    return out
+
+
 def last_selfattention(x: Tensor, W: Dict[str, Tensor], num_heads: int, patch: int = 8, eps: float = 1e-6) -> Tensor:
     """[B,3,r,r] -> softmax attention [B,H,N,N] of the last block (VisionTransformer.get_last_selfattention,
     vision_transformer.py:273-280)."""

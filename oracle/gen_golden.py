@@ -396,6 +396,26 @@ def g10():
     save("g10_last_selfattention", **out)
 
 
+# ----------------------------------------------------------------------------- G14 get_intermediate_layers
+def g14():
+    """VisionTransformer.get_intermediate_layers(x, n) (vision_transformer.py:282-290): norm(x) after each of the last n blocks."""
+    out = {}
+    cfg = TINY
+    vit = ref_vit(cfg, procedural_state_dict(cfg))
+    frames = synthetic_frames(2, 64, seed=141)
+    with torch.no_grad():
+        for n in (1, 2, 5):                 # n beyond the depth returns every block's output
+            ys = vit.get_intermediate_layers(preprocess_np(frames), n)
+            out[f"tiny_r64_n{n}"] = np.stack([y.numpy() for y in ys])
+    cfg = ViTConfig(n_blocks=3)
+    vit = ref_vit(cfg, procedural_state_dict(cfg))
+    frames2 = synthetic_frames(1, 96, seed=142)
+    with torch.no_grad():
+        ys = vit.get_intermediate_layers(preprocess_np(frames2), 2)
+    out["vits8_L3_r96_n2"] = np.stack([y.numpy() for y in ys])[:, :, ::6, :].copy()      # every 6th token (CLS included)
+    save("g14_intermediate_layers", frames_tiny=frames, frames_vits=frames2, **out)
+
+
 def g11():
     """forward_mask / get_last_selfattention(x, cls_mask): the masked-CLS path of the last block."""
     out = {}
@@ -446,7 +466,7 @@ def g12():
     save("g12_finetune_r480_ignore", **{k.replace("/", "|"): v for k, v in out.items()})
 
 
-ALL = {"G13": g13, "G12": g12, "G11": g11, "G10": g10, "G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
+ALL = {"G14": g14, "G13": g13, "G12": g12, "G11": g11, "G10": g10, "G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

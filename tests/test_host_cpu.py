@@ -135,3 +135,46 @@ def test_resize_mirror_matches_scalar_restatement():
     assert np.unique(resize_linear_u8(const, 16, 16)).tolist() == [200]
     same = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
     assert resize_linear_u8(same, 8, 8) is not None and np.array_equal(resize_linear_u8(same, 8, 8), same)
+
+
+def test_fast_signature_sees_every_kind_of_weight_change():
+    """The cheap per-call check of DINOSeg._sync_weights (no state_dict walk) must notice everything the full signature does:
+    in-place updates, optimizer steps, load_state_dict, replaced Parameters / sub-modules, added entries, invalidate_weights()."""
+    import copy
+    import pickle
+    m = DINOSeg(head="mlp", n_blocks=2)
+    assert m._fast_signature() is None                       # nothing indexed before the first bind
+    m._fast_index = m._build_fast_index()
+    base = m._fast_signature()
+    assert base is not None and m._fast_signature() == base  # stable while nothing changes
+    with torch.no_grad():
+        m.clf.layer_3.bias.add_(1.0)
+    assert m._fast_signature() != base
+    base = m._fast_signature()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    assert m._fast_signature() != base
+    base = m._fast_signature()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in procedural_state_dict(m.cfg).items()})
+    assert m._fast_signature() != base
+    base = m._fast_signature()
+    m.dino.norm.bias.data = torch.ones_like(m.dino.norm.bias)          # new storage, same Parameter, version unchanged
+    assert m._fast_signature() != base
+    m._fast_index = m._build_fast_index()
+    base = m._fast_signature()
+    m.clf.layer_1.bias = torch.nn.Parameter(torch.zeros(200))          # replaced Parameter object
+    assert m._fast_signature() is None
+    m._fast_index = m._build_fast_index()
+    m.dino.blocks[1] = copy.deepcopy(m.dino.blocks[0])                 # replaced sub-module
+    assert m._fast_signature() is None
+    m._fast_index = m._build_fast_index()
+    m.clf.register_buffer("extra", torch.zeros(1))                     # added entry
+    assert m._fast_signature() is None
+    m._fast_index = m._build_fast_index()
+    base = m._fast_signature()
+    m.invalidate_weights()
+    assert m._fast_signature() != base
+    m2 = pickle.loads(pickle.dumps(m))                                  # the index is process state: not pickled
+    assert "_fast_index" not in m2.__dict__ and m2._fast_signature() is None

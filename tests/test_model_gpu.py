@@ -272,6 +272,24 @@ def test_g10_last_selfattention(cuda, golden_dir):
     assert float((a[0, :, 77] - torch.from_numpy(g["vits8_L3_r96_row77"])).abs().max()) <= 2e-4
 
 
+def test_g14_intermediate_layers(cuda, golden_dir):
+    """model.dino.get_intermediate_layers(x, n) against the reference's own output (vision_transformer.py:282-290)."""
+    g = load(golden_dir, "g14_intermediate_layers")
+    m, _, _ = build(TINY, "bf16x3")
+    x = O.preprocess(g["frames_tiny"]).cuda()
+    for n, want in ((1, 1), (2, 2), (5, 2)):
+        ys = m.dino.get_intermediate_layers(x, n)
+        ref = torch.from_numpy(g[f"tiny_r64_n{n}"])
+        assert isinstance(ys, list) and len(ys) == want
+        assert float((torch.stack([y.cpu() for y in ys]) - ref).abs().max()) <= 3e-4
+    assert m.dino.get_intermediate_layers(x, 0) == []
+    m, _, _ = build(3, "bf16x3")
+    ys = m.dino.get_intermediate_layers(O.preprocess(g["frames_vits"]).cuda())          # default n = 1
+    assert len(ys) == 1
+    ys = m.dino.get_intermediate_layers(O.preprocess(g["frames_vits"]).cuda(), 2)
+    assert float((torch.stack([y.cpu() for y in ys])[:, :, ::6] - torch.from_numpy(g["vits8_L3_r96_n2"])).abs().max()) <= 3e-4
+
+
 def test_validation_metrics_on_device(cuda):
     from sklearn.metrics import balanced_accuracy_score, f1_score, jaccard_score
     m, sd, cfg = build(1, "bf16x3")

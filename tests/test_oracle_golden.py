@@ -155,6 +155,23 @@ def test_g10_last_selfattention(golden_dir):
     assert float((a[0, :, 77] - torch.from_numpy(g["vits8_L3_r96_row77"])).abs().max()) <= 5e-6
 
 
+def test_g14_intermediate_layers(golden_dir):
+    """VisionTransformer.get_intermediate_layers(x, n) of the reference (vision_transformer.py:282-290) vs the oracle."""
+    g = load(golden_dir, "g14_intermediate_layers")
+    W = O.to_torch(procedural_state_dict(TINY))
+    x = O.preprocess(g["frames_tiny"])
+    with torch.no_grad():
+        for n, want in ((1, 1), (2, 2), (5, 2)):
+            ys = O.intermediate_layers(x, W, TINY.num_heads, n)
+            ref = torch.from_numpy(g[f"tiny_r64_n{n}"])
+            assert len(ys) == want == ref.shape[0]
+            assert float((torch.stack(ys) - ref).abs().max()) <= 2e-5
+        assert O.intermediate_layers(x, W, TINY.num_heads, 0) == []
+        cfg = ViTConfig(n_blocks=3)
+        ys = O.intermediate_layers(O.preprocess(g["frames_vits"]), O.to_torch(procedural_state_dict(cfg)), cfg.num_heads, 2)
+        assert float((torch.stack(ys)[:, :, ::6] - torch.from_numpy(g["vits8_L3_r96_n2"])).abs().max()) <= 5e-5
+
+
 def test_metrics_from_confusion_match_sklearn():
     from sklearn.metrics import balanced_accuracy_score, f1_score, jaccard_score
     from dino_amd.dinoseg import metrics_from_confusion

@@ -216,6 +216,30 @@ def test_fit_loop_keeps_best_checkpoint(cuda, tmp_path):
         assert np.array_equal(m2.predict(frames[4].numpy()), m.predict(frames[4].numpy()))
     with pytest.raises(ValueError):
         m.fit()
+    # pretrain_on_sim (pl_torch_modules.py:391-401): a first phase on the simulation loader, or a refusal -- never ignored
+    m.pretrain_on_sim = True
+    with pytest.raises(ValueError, match="sim_dataloader"):
+        m.fit(train_dataloader=train, val_dataloader=val, max_epochs=1)
+    out = m.fit(train_dataloader=train, val_dataloader=val, sim_dataloader=[(frames[4:6], lab[4:6])], max_epochs=2)
+    assert len(out["sim_history"]) == 2 and len(out["history"]) == 2 and out["test"] is None
+    # the Lightning hooks the reference defines on the class: the dataset is out of scope, so they say so (a subclass may supply them)
+    with pytest.raises(NotImplementedError, match="DuckieSegDataset"):
+        m.train_dataloader()
+    tm = m.training_epoch_end([{"pred": torch.tensor([0, 1, 2, 2]), "gt": torch.tensor([0, 1, 1, 2])}])
+    assert abs(tm["train_acc"] - (1 + 0.5 + 1) / 3) <= 1e-12
+
+    class WithLoaders(DINOSeg):
+        def train_dataloader(self, sim=False):
+            return [(frames[4:6], lab[4:6])] if sim else train
+
+        def val_dataloader(self, sim=False):
+            return val
+
+    m3 = WithLoaders(arch=cfg, head="mlp", n_blocks=1, n_classes=7, lr=1e-3, optimizer=torch.optim.Adam, freeze_backbone=True,
+                     max_epochs=1, write_path=str(tmp_path), precision="bf16x3", pretrain_on_sim=True).to("cuda")
+    m3.set_resolution(64)
+    out = m3.fit()
+    assert len(out["sim_history"]) == 1 and len(out["history"]) == 1 and m3.best_ck.endswith("1_mlp_frozen.ckpt")
 
 
 # ------------------------------------------------------------------------------------------------ round 2 additions
