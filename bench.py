@@ -2,11 +2,14 @@
 """Headline benchmark of the DINOSeg hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks 12] [--batch 32] [--res 480]
-                    [--precision bf16|bf16x3] [--no-cpu-baseline] [--dry-run]
+                    [--precision fp16|bf16|bf16x3] [--no-cpu-baseline] [--dry-run]
                     [--config headline|parity|960|vitb|finetune]     (the other BASELINE.json configs, one JSON line each)
 
 Metric (BASELINE.json): frames/sec of DINOSeg inference -- ViT-S/8 (12 blocks) + MLP head, 480x480 frames,
-batch 32 per GPU, bf16 operands / fp32 accumulation -- whole job over all N GPUs.  One "step" = one forward
+batch 32 per GPU, 16-bit MFMA operands / fp32 accumulation -- whole job over all N GPUs.  Default precision (round 4): fp16
+operands for the linears and Q.K^T (v_mfma_f32_32x32x16_f16: the bf16 instruction's rate and the same 2.5 PFLOP/s dense peak),
+bf16 for the probabilities and V -- same speed as the all-bf16 mode, ~6x closer to the fp32 reference; the line carries the all-bf16
+mode's own frames/s and parity as `bf16_mode`, and `--precision bf16` times that mode as the headline.  One "step" = one forward
 of the hot path (uint8 frames resident in HBM -> log-probs + argmax map) over one batch.  Frames are
 independent, so N GPUs run N data-parallel replicas with no data-path collective ("weak" scaling); the
 barrier + max-over-ranks timing follows the driver's contract.  `python bench.py --gpus N` with N > 1 and no
@@ -19,7 +22,7 @@ The JSON line also carries
                  same steps right after the timed loop (no event records inside the timed region).
   parity       : "mask argmax match vs ref": the golden fixture's frame through the timed precision (argmax_match,
                  max_abs_dlogp against the reference's log-probabilities); parity_mode = the same config in bf16x3
-                 (the mode that meets argmax-identical / 1e-3) with its own frames/s and match.
+                 (the mode that meets argmax-identical / 1e-3) with its own frames/s and match; bf16_mode = the same in bf16.
   cpu_baseline : the oracle (oracle/dinoseg_oracle.py = CPU fp32 restatement of the reference path, kind "port")
                  timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -33,7 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0}   # dense bf16 MFMA peak, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp16": 2500.0}   # dense bf16 / fp16 MFMA peak, MI355X_MICROARCH.md
+DTYPE = {"fp16": "fp16 (linears, Q.K^T; P.V bf16; fp32 accumulate)", "bf16": "bf16", "bf16x3": "bf16x3 (bf16 hi+lo split, fp32 acc)"}
 
 
 def flops_per_frame(D, H, L, r, head="mlp", C=7):
@@ -133,8 +137,9 @@ def golden_check(model, arch, blocks, res, batch=1):
 
 def bench_finetune(a, world, rank, dev, rehearsal=False):
     """Fine-tune step throughput: ViT-S/8 truncated to 3 blocks + MLP head, all 48 tensors trainable, Adam lr 1e-3
-    (run_experiment.py:135-136), 480x480 frames, batch 8 per GPU (global 64 at 8 GPUs), parity precision (bf16x3)
-    unless --precision bf16.  One step = forward + backward + gradient all-reduce + fused Adam."""
+    (run_experiment.py:135-136), 480x480 frames, batch 8 per GPU (global 64 at 8 GPUs), bf16 operands unless
+    --precision bf16x3 (the parity mode; fp16 is inference-only).  One step = forward + backward + gradient all-reduce + fused
+    Adam.  The bf16 step's gradients are bounded against the reference in tests/test_train_gpu.py (G6 / G12)."""
     import torch
     import torch.distributed as dist
     from dino_amd import DINOSeg, ViTConfig, procedural_state_dict
@@ -151,7 +156,7 @@ def bench_finetune(a, world, rank, dev, rehearsal=False):
     n = (a.res // 8) ** 2
     frames = torch.from_numpy(synthetic_frames(per_gpu * world, a.res, seed=7)).to(dev)
     labels = torch.from_numpy(synthetic_labels(per_gpu * world, n, 7, seed=8)).to(dev)
-    tuner = DataParallelFineTuner(model, fused_optimizer=True)
+    tuner = DataParallelFineTuner(model, fused_optimizer=True, collective=a.collective)
     for _ in range(a.warmup):
         tuner.step(frames, labels)
     torch.cuda.synchronize()
@@ -184,7 +189,8 @@ def bench_finetune(a, world, rank, dev, rehearsal=False):
             "config": {"workload": f"fine-tune step: ViT-S/8 x{blocks} blocks + MLP head unfrozen (48 tensors), fwd+bwd+"
                                    f"grad all-reduce+fused Adam, {a.res}x{a.res}, batch {per_gpu}/GPU", "blocks": blocks,
                        "batch_per_gpu": per_gpu, "global_batch": per_gpu * world, "resolution": a.res,
-                       "precision": a.precision, "parallelism": f"dp{world} (RCCL gradient all-reduce, 22.1 MiB fp32)"},
+                       "precision": a.precision, "collective": a.collective,
+                       "parallelism": f"dp{world} (RCCL gradient {'all-reduce' if a.collective == 'allreduce' else 'reduce-scatter + all-gather'}, 22.1 MiB fp32)"},
             "model_mfma_frac": round(fps / world * 3 * fl["total"] / 1e12 / MFMA_PEAK_TFLOPS[a.precision], 4),
         }), flush=True)
     if world > 1:
@@ -200,7 +206,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--res", type=int, default=480)
     ap.add_argument("--arch", default="vit_small", choices=["vit_small", "vit_base"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--precision", default=None, choices=["fp16", "bf16", "bf16x3"],
+                    help="default: fp16 for inference (see the module docstring), bf16 for --mode finetune (fp16 is inference-only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="(kept for compatibility: kernel_ms_per_step is always emitted)")
     ap.add_argument("--option", action="append", default=[], help="library tuning knob key=int (dinoseg_set_option)")
@@ -210,10 +217,12 @@ def parse_args(argv=None):
     ap.add_argument("--config", default=None, choices=["headline", "parity", "960", "vitb", "finetune"],
                     help="BASELINE.json configs: headline = [1] ViT-S/8 @480 batch 32 bf16 (default); parity = the same in bf16x3; "
                          "960 = [2] @960 batch 8; vitb = [4] ViT-B/8 @480 batch 16/GPU; finetune = [3] 3-block step, batch 8/GPU")
-    ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 sub-record of the headline line")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 and bf16 sub-records of the headline line")
     ap.add_argument("--no-two-stream", action="store_true", help="skip the one-stream sub-record")
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2],
                     help="0 = the library default (2: a batch of >= 8 frames runs as two half-batches on two streams); 1 / 2 force it")
+    ap.add_argument("--collective", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="--mode finetune: one all-reduce per gradient bucket, or reduce-scatter + all-gather (dino_amd/parallel.py)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check only: no model, no GPU (gloo); prints the JSON line with value 0")
     a = ap.parse_args(argv)
@@ -225,6 +234,10 @@ def parse_args(argv=None):
         a.arch, a.batch = "vit_base", 16
     elif a.config == "finetune":
         a.mode = "finetune"
+    if a.precision is None:
+        a.precision = "bf16" if a.mode == "finetune" else "fp16"
+    if a.mode == "finetune" and a.precision == "fp16":
+        ap.error("--precision fp16 is inference-only (fp16 gradients would need loss scaling): use bf16 or bf16x3")
     return a
 
 
@@ -235,19 +248,40 @@ def free_port():
         return sk.getsockname()[1]
 
 
+def visible_gpus():
+    """GPUs this process would see, WITHOUT loading the HIP runtime: the KFD topology nodes that have SIMDs (CPU nodes have none),
+    cut down by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set; None when sysfs tells nothing."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                props = dict(line.split(None, 1) for line in f if " " in line)
+            n += int(props.get("simd_count", "0").strip()) > 0
+        except (OSError, ValueError):
+            return None
+    if n == 0:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(a):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as a `python -m torch.distributed.run` CHILD process (this
-    process has not touched the GPU and never does: no exec of a GPU-initialised process), forward its exit code.  Rank 0 of the
-    child prints the JSON line on the inherited stdout.  On a box with fewer than N GPUs the ranks rehearse the same code path on
-    device 0 over gloo (DINOSEG_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device) and the line says so."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a `python -m torch.distributed.run` CHILD process and
+    forward its exit code.  This parent never loads the HIP runtime: it counts GPUs from sysfs (`visible_gpus`; a box whose sysfs
+    says nothing is treated as having enough, and the ranks fail loudly if it has not) -- and it is never replaced by exec.  Rank 0
+    of the child prints the JSON line on the inherited stdout.  On a box with fewer than N GPUs the ranks rehearse the same code
+    path on device 0 over gloo (DINOSEG_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device) and the line says so."""
     import subprocess
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not a.dry_run:
-        import torch
-        if torch.cuda.device_count() < a.gpus and env.get("DINOSEG_BENCH_REHEARSAL") != "1":
-            print(f"bench.py: {torch.cuda.device_count()} GPU(s) visible for --gpus {a.gpus}: rehearsal mode (all ranks on device 0, "
-                  f"gloo)", file=sys.stderr)
+        ngpu = visible_gpus()
+        if ngpu is not None and ngpu < a.gpus and env.get("DINOSEG_BENCH_REHEARSAL") != "1":
+            print(f"bench.py: {ngpu} GPU(s) visible for --gpus {a.gpus}: rehearsal mode (all ranks on device 0, gloo)", file=sys.stderr)
             env["DINOSEG_BENCH_REHEARSAL"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -291,7 +325,8 @@ def main():
             print(json.dumps({"metric": "frames/sec (480x480, ViT-S/8) DINOSeg inference", "value": 0.0, "unit": "frames/s",
                               "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": 0.0, "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "none", "dry_run": True,
-                              "ranks_seen": seen, "config": {"workload": "dry run: launcher and rendezvous only"}}), flush=True)
+                              "ranks_seen": seen, "config": {"workload": "dry run: launcher and rendezvous only", "mode": a.mode,
+                                                             "collective": a.collective if a.mode == "finetune" else None}}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -416,7 +451,7 @@ def main():
                 and a.arch == "vit_small":
             traffic = tj["hbm_bytes_per_launch"]
             clock = tj.get("clock_ghz_under_load")
-        measured_peak = (tj.get("measured_mfma_peak_tflops") or {}).get("random_operands") if a.precision == "bf16" else None
+        measured_peak = (tj.get("measured_mfma_peak_tflops") or {}).get("random_operands") if a.precision != "bf16x3" else None
 
     if rank == 0:
         # the instantiation the one-stream roofline pass launches (attention_z.hip's rule: 256-query workgroups from one round of
@@ -424,14 +459,15 @@ def main():
         heads_ = 6 if a.arch == "vit_small" else 12
         wgs4 = (a.batch * heads_ + 7) // 8 * 8 * (((a.res // 8) ** 2 + 1 + 127) // 128)
         nw = 8 if wgs4 >= 4 * torch.cuda.get_device_properties(dev).multi_processor_count else 4
-        attn_symbol = (f"dseg::attn_fwd_z_kernel<1, 4, {nw}> (attention_z.hip: fused QK^T-softmax-PV, head_dim 64, zero-reference softmax)"
-                       if a.precision == "bf16" else
+        attn_symbol = (f"dseg::attn_fwd_z_kernel<1, 4, {nw}, {1 if a.precision == 'fp16' else 0}> (attention_z.hip: fused QK^T-softmax-PV, "
+                       f"head_dim 64, zero-reference softmax{'; fp16 Q.K^T, bf16 P.V' if a.precision == 'fp16' else ''})"
+                       if a.precision != "bf16x3" else
                        "dseg::attn_fwd_kernel<2, 4, false, 3> (attention.hip: fused QK^T-softmax-PV, head_dim 64, hi+lo planes)")
         out = {
             "metric": "frames/sec (480x480, ViT-S/8) DINOSeg inference",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "bf16x3 (bf16 hi+lo split, fp32 acc)",
+            "vs_baseline": None, "dtype": DTYPE[a.precision],
             "data": "synthetic", "ranks_seen": seen, "rehearsal": rehearsal,
             "config": {"workload": f"DINOSeg predict path: ViT-{'S' if a.arch == 'vit_small' else 'B'}/8 x{a.blocks} blocks + MLP "
                                    f"head, {a.res}x{a.res} uint8 frames, batch {a.batch}/GPU, frames resident in HBM",
@@ -448,7 +484,7 @@ def main():
                          "measured_how": "HIP events around every launch on the forward's stream, in an untimed pass of the same steps on "
                                          "ONE stream (exclusive launches) right after the timed loop; `value` above is timed with the "
                                          "library default (two half-batches on two streams from 8 frames on)",
-                         "peak_note": "peak = dense bf16 MFMA at the nominal 2.4 GHz (MI355X_MICROARCH.md).  clock_ghz_under_load = what "
+                         "peak_note": "peak = dense bf16 / fp16 MFMA at the nominal 2.4 GHz (MI355X_MICROARCH.md: one rate).  clock_ghz_under_load = what "
                                       "this kernel was measured to hold (rocprofv3 PMC GRBM_GUI_ACTIVE / 8 / duration, committed in "
                                       "profiles/attention_traffic.json); peak_at_measured_clock scales the peak by it",
                          "clock_ghz_under_load": clock,
@@ -470,9 +506,9 @@ def main():
         if one_stream is not None:
             out["one_stream"] = one_stream
         out["parity"] = golden_check(model, a.arch, a.blocks, a.res, a.batch)      # the timed precision / dispatch against the reference fixture
-        if a.precision == "bf16" and not a.no_parity_mode:
-            # north_star's bar (argmax identical, |dlogp| <= 1e-3) is met by the bf16x3 mode: same config, own timing
-            pm = DINOSeg(head="mlp", n_blocks=a.blocks, precision="bf16x3", arch=cfg)
+        def sub_mode(prec):
+            """the same configuration in another precision: its own short timing (library defaults) and its parity record"""
+            pm = DINOSeg(head="mlp", n_blocks=a.blocks, precision=prec, arch=cfg)
             pm.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
             pm.to(dev)
             pm.set_resolution(a.res)
@@ -486,12 +522,20 @@ def main():
             torch.cuda.synchronize()
             pel = time.perf_counter() - t1
             pfps = a.batch * psteps / pel
-            out["parity_mode"] = {"precision": "bf16x3 (bf16 hi+lo operand planes, 3 MFMAs per product, fp32 accumulate)",
-                                  "value": round(pfps, 2), "unit": "frames/s (this rank)", "steps": psteps,
-                                  "ms_per_step": round(pel / psteps * 1e3, 4), "streams": 2 if split else 1,
-                                  "mfma_issue_frac": round(3 * pfps * fl["total"] / 1e12 / peak, 4),
-                                  "parity": golden_check(pm, a.arch, a.blocks, a.res, a.batch)}
+            rec = {"precision": prec, "value": round(pfps, 2), "unit": "frames/s (this rank)", "steps": psteps,
+                   "ms_per_step": round(pel / psteps * 1e3, 4), "streams": 2 if split else 1,
+                   "parity": golden_check(pm, a.arch, a.blocks, a.res, a.batch)}
             del pm
+            return rec, pfps
+        if a.precision != "bf16x3" and not a.no_parity_mode:
+            # north_star's bar (argmax identical, |dlogp| <= 1e-3) is met by the bf16x3 mode: same config, own timing
+            rec, pfps = sub_mode("bf16x3")
+            rec["precision"] = "bf16x3 (bf16 hi+lo operand planes, 3 MFMAs per product, fp32 accumulate)"
+            rec["mfma_issue_frac"] = round(3 * pfps * fl["total"] / 1e12 / peak, 4)
+            out["parity_mode"] = rec
+        if a.precision == "fp16" and not a.no_parity_mode:
+            # BASELINE.json names bf16: the all-bf16 mode's own numbers next to the fp16-operand headline (same kernels, same rate)
+            out["bf16_mode"] = sub_mode("bf16")[0]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, a.res)
         print(json.dumps(out), flush=True)

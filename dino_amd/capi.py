@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdinoseg_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dinoseg.h")
 
-BF16, BF16X3 = 0, 1
+BF16, BF16X3, FP16 = 0, 1, 2
 HEAD_LINEAR, HEAD_MLP = 0, 1
 INPUT_U8_HWC, INPUT_F32_CHW = 0, 1
 EPI_PLAIN, EPI_RESID, EPI_GELU, EPI_RELU = 0, 1, 2, 3

@@ -90,7 +90,7 @@ extern "C" int dinoseg_create(const dinoseg_config* cfg, dinoseg_handle** out) {
     }
     if (cfg->embed_dim % 128 != 0 || cfg->embed_dim > 1024 || cfg->num_heads * 64 != cfg->embed_dim || cfg->patch != 8 ||
         cfg->n_blocks < 0 || cfg->n_classes < 1 || cfg->n_classes > 32 || cfg->mlp_ratio < 1 || cfg->pos_grid < 1 ||
-        (cfg->precision != DINOSEG_BF16 && cfg->precision != DINOSEG_BF16X3) ||
+        (cfg->precision != DINOSEG_BF16 && cfg->precision != DINOSEG_BF16X3 && cfg->precision != DINOSEG_FP16) ||
         (cfg->head_kind != DINOSEG_HEAD_MLP && cfg->head_kind != DINOSEG_HEAD_LINEAR)) {
         dinoseg_set_error("dinoseg_create: unsupported config (embed_dim=%d heads=%d patch=%d blocks=%d classes=%d)",
                           cfg->embed_dim, cfg->num_heads, cfg->patch, cfg->n_blocks, cfg->n_classes);
@@ -99,6 +99,7 @@ extern "C" int dinoseg_create(const dinoseg_config* cfg, dinoseg_handle** out) {
     dinoseg_handle* h = new dinoseg_handle();
     h->cfg = *cfg;
     h->planes = cfg->precision == DINOSEG_BF16X3 ? 2 : 1;
+    h->fmt = cfg->precision == DINOSEG_FP16 ? FMT_FP16 : FMT_BF16;
     add_expected(h);
     *out = h;
     return 0;
@@ -216,25 +217,26 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
 // names of every nn.Linear-shaped weight that feeds gemm.hip, with its logical [N, K] and padded [n_pad, k_pad]
 struct LinSpec {
     std::string wname, bname;
-    int N, K, n_pad, k_pad, planes;
+    int N, K, n_pad, k_pad, planes, fmt;
 };
 
 static std::vector<LinSpec> linear_specs(const dinoseg_handle* h) {
     const dinoseg_config& c = h->cfg;
-    const int D = c.embed_dim, F = c.embed_dim * c.mlp_ratio, P = h->planes;
+    const int D = c.embed_dim, F = c.embed_dim * c.mlp_ratio, P = h->planes, FM = h->fmt;
     std::vector<LinSpec> v;
-    v.push_back({"dino.patch_embed.proj.weight", "dino.patch_embed.proj.bias", D, 3 * c.patch * c.patch, D, 192, P});
+    // (fp16 mode: the patch embedding runs split like the head -- 0.13 % of the FLOPs, and its operands are raw pixels)
+    v.push_back({"dino.patch_embed.proj.weight", "dino.patch_embed.proj.bias", D, 3 * c.patch * c.patch, D, 192, patch_planes(h), FMT_BF16});
     bool qkv_ready = false;      // Q / K / V of block i were written by block i-1's fused launch (mlp_fused2.hip, QKV tail)
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
-        v.push_back({b + "attn.qkv.weight", b + "attn.qkv.bias", 3 * D, D, 3 * D, D, P});
-        v.push_back({b + "attn.proj.weight", b + "attn.proj.bias", D, D, D, D, P});
-        v.push_back({b + "mlp.fc1.weight", b + "mlp.fc1.bias", F, D, F, D, P});
-        v.push_back({b + "mlp.fc2.weight", b + "mlp.fc2.bias", D, F, D, F, P});
+        v.push_back({b + "attn.qkv.weight", b + "attn.qkv.bias", 3 * D, D, 3 * D, D, P, FM});
+        v.push_back({b + "attn.proj.weight", b + "attn.proj.bias", D, D, D, D, P, FM});
+        v.push_back({b + "mlp.fc1.weight", b + "mlp.fc1.bias", F, D, F, D, P, FM});
+        v.push_back({b + "mlp.fc2.weight", b + "mlp.fc2.bias", D, F, D, F, P, FM});
     }
     if (c.head_kind == DINOSEG_HEAD_MLP) {
-        v.push_back({"clf.layer_1.weight", "clf.layer_1.bias", 200, D, 256, D, head_planes()});
-        v.push_back({"clf.layer_2.weight", "clf.layer_2.bias", 100, 200, 128, 256, head_planes()});
+        v.push_back({"clf.layer_1.weight", "clf.layer_1.bias", 200, D, 256, D, head_planes(), FMT_BF16});
+        v.push_back({"clf.layer_2.weight", "clf.layer_2.bias", 100, 200, 128, 256, head_planes(), FMT_BF16});
     }
     return v;
 }
@@ -284,7 +286,7 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
         pk.n_pad = sp.n_pad;
         pk.k_pad = sp.k_pad;
         off += align_up((size_t)sp.planes * sp.n_pad * sp.k_pad * sizeof(bf16_t), 256);
-        jobs.push_back({W(h, sp.wname), pk.w, pk.plane, sp.N, sp.K, sp.n_pad, sp.k_pad, sp.planes, 0});
+        jobs.push_back({W(h, sp.wname), pk.w, pk.plane, sp.N, sp.K, sp.n_pad, sp.k_pad, sp.planes, 0, sp.fmt});
         if (sp.n_pad != sp.N) {
             pk.bias_pad = reinterpret_cast<float*>(h->wbuf + off);
             off += align_up((size_t)sp.n_pad * sizeof(float), 256);
@@ -296,7 +298,7 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
         if (ln_fed(sp)) {
             bf16_t* slab = reinterpret_cast<bf16_t*>(h->wbuf + off);
             off += align_up((size_t)gemm_ln_slab_elems(sp.N, sp.K, sp.planes) * sizeof(bf16_t), 256);
-            DSEG_TRY(launch_pack_slabs(W(h, sp.wname), sp.N, sp.K, sp.planes, slab, s));
+            DSEG_TRY(launch_pack_slabs(W(h, sp.wname), sp.N, sp.K, sp.planes, slab, s, sp.fmt));
             h->packed_slab[sp.wname] = slab;
         }
     }
@@ -319,10 +321,11 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
                 off += align_up((size_t)mlp_fused_qkv_pack_elems(Dm) * sizeof(bf16_t), 256);
             }
         }
-    // Packed now, except while gradient buffers are bound (a fine-tune in progress refreshes after every optimiser step and its
-    // forward never runs the fused kernel): then the first inference forward that wants them packs them (ensure_mlp_packs).
+    // Always packed here, in stream order with the other packs: a forward captured in a graph contains no pack kernels, so a
+    // deferred pack (round 3 skipped these while gradient buffers were bound) would let a replay after a fine-tune step read stale
+    // fused-kernel weights next to fresh ones.  Three small launches per block.
     h->packed_mlp_stale = true;
-    if (h->grads.empty()) DSEG_TRY(ensure_mlp_packs(h, s));
+    DSEG_TRY(ensure_mlp_packs(h, s));
     h->weights_ready = true;
     h->pos_r = -1;   // pos_embed may have changed (fine-tune)
     return 0;
@@ -377,8 +380,11 @@ static WsLayout make_layout(const dinoseg_handle* h, int B, int r) {
         return o;
     };
     L.X = take((size_t)L.M * D * 4);
-    L.a_plane = (long)L.M * D;                 // LN output; also hosts the patch-gather matrix [Mp,192] (smaller)
-    L.A = take((size_t)P * L.a_plane * 2);
+    L.a_plane = (long)L.M * D;                 // LN output; also hosts the patch-gather matrix: patch_planes x [Mp, 192]
+    {
+        const size_t ln_bytes = (size_t)P * L.a_plane * 2, pg_bytes = (size_t)patch_planes(h) * L.Mp * 192 * 2;
+        L.A = take(ln_bytes > pg_bytes ? ln_bytes : pg_bytes);
+    }
     L.qkv_plane = (long)B * c.num_heads * L.npad * 64;
     L.Q = take((size_t)P * L.qkv_plane * 2);
     L.K = take((size_t)P * L.qkv_plane * 2);
@@ -447,16 +453,16 @@ static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s) {
     if (!h->packed_mlp_stale) return 0;
     const int Dm = h->cfg.embed_dim, Fh = h->cfg.embed_dim * h->cfg.mlp_ratio;
     for (auto& kv : h->packed_mlp)
-        DSEG_TRY(launch_pack_mlp(W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc2.weight"), Dm, Fh, kv.second, s));
-    for (auto& kv : h->packed_proj) DSEG_TRY(launch_pack_proj(W(h, kv.first + "attn.proj.weight"), Dm, kv.second, s));
-    for (auto& kv : h->packed_qkvf) DSEG_TRY(launch_pack_qkv(W(h, kv.first + "attn.qkv.weight"), Dm, kv.second, s));
+        DSEG_TRY(launch_pack_mlp(W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc2.weight"), Dm, Fh, kv.second, s, h->fmt));
+    for (auto& kv : h->packed_proj) DSEG_TRY(launch_pack_proj(W(h, kv.first + "attn.proj.weight"), Dm, kv.second, s, h->fmt));
+    for (auto& kv : h->packed_qkvf) DSEG_TRY(launch_pack_qkv(W(h, kv.first + "attn.qkv.weight"), Dm, kv.second, s, h->fmt));
     h->packed_mlp_stale = false;
     return 0;
 }
 
 static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r, float* logp_out,
                         int32_t* argmax_out, int32_t tap_block, float* tap_out, float* attn_out, void* stream,
-                        const MaskRequest* mreq = nullptr, int slot = 0) {
+                        const MaskRequest* mreq = nullptr, int slot = 0, int disp_B = 0) {
     if (!h || !x || B <= 0) {
         dinoseg_set_error("dinoseg_forward: bad argument");
         return -1;
@@ -479,9 +485,13 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     DSEG_TRY(dinoseg_prepare_resolution(h, r, stream));
 
     const dinoseg_config& c = h->cfg;
-    const int D = c.embed_dim, F = D * c.mlp_ratio, P = h->planes, HP = head_planes(), H = c.num_heads;
+    const int D = c.embed_dim, F = D * c.mlp_ratio, P = h->planes, HP = head_planes(), H = c.num_heads, FM = h->fmt;
     const WsLayout L = make_layout(h, B, r);
     DSEG_TRY(ensure_workspace(h, slot, L, B, r, s));
+    // every size-dependent kernel choice below is made for the rows of the WHOLE call: the half-batches of a split forward (disp_B =
+    // the call's batch) then take the routes -- and the summation order -- the unsplit batch takes, so the split changes no bit
+    const int dB = disp_B > 0 ? disp_B : B;
+    const int disp_M = dB * L.ntok, disp_Mp = dB * L.n;
     char* ws = slot ? h->ws2 : h->ws;
     float* X = reinterpret_cast<float*>(ws + L.X);
     bf16_t* A = reinterpret_cast<bf16_t*>(ws + L.A);
@@ -498,13 +508,14 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     float mean255[3], inv255[3];
     norm_consts(mean255, inv255);
     const long pg_plane = (long)L.Mp * 192;
-    DSEG_PROF(DINOSEG_PROF_PATCH, DSEG_TRY(launch_patch_gather(x, x_kind, B, r, mean255, inv255, A, pg_plane, P, s)));
+    const int PP = patch_planes(h);
+    DSEG_PROF(DINOSEG_PROF_PATCH, DSEG_TRY(launch_patch_gather(x, x_kind, B, r, mean255, inv255, A, pg_plane, PP, s)));
     {
         const PackedLinear& pk = h->packed.at("dino.patch_embed.proj.weight");
         GemmParams g = {};
         g.A = A; g.a_plane = pg_plane; g.lda = 192;
         g.W = pk.w; g.w_plane = pk.plane;
-        g.M = L.Mp; g.N = D; g.K = 192; g.planes = P; g.epi = EPI_PATCH;
+        g.M = L.Mp; g.N = D; g.K = 192; g.planes = PP; g.epi = EPI_PATCH; g.dispatch_rows = disp_Mp;
         g.bias = W(h, "dino.patch_embed.proj.bias");
         g.out_f32 = X; g.ldo_f32 = D;
         g.pos = h->pos_cache; g.n_patches = L.n;
@@ -523,7 +534,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
         // gemm_ln: 0 never fused, 2 always, 1 (default) by measurement: bf16 fused; bf16x3 fused only for small batches -- with
         // >= 512 tiles of 128 x 384 the separate LayerNorm + the hi+lo configuration of the persistent GEMM is faster
         // (B = 32: fc1 30 + 534 us against 670 fused; the fused kernel's 64-row panels run one wave per SIMD)
-        const bool big_x3 = P == 2 && options().gemm_big && (long)((L.M + 127) / 128) * 3 >= 512;
+        const bool big_x3 = P == 2 && options().gemm_big && (long)((disp_M + 127) / 128) * 3 >= 512;
         const bool fuse_ln = options().gemm_ln == 2 || (options().gemm_ln == 1 && !big_x3);
         // (the fused kernel keeps 32-bit output row offsets)
         if (qkv_ready) {
@@ -535,17 +546,17 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.W = h->packed_slab.at(b + "attn.qkv.weight"); g.bias = W(h, b + "attn.qkv.bias");
             g.M = L.M; g.N = 3 * D; g.epi = EPI_QKV;
             g.q = Q; g.k = Kb; g.v = V; g.qkv_plane = L.qkv_plane;
-            g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
+            g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale; g.fmt = FM;
             DSEG_PROF(DINOSEG_PROF_QKV, DSEG_TRY(launch_gemm_ln(g, D, P, s)));
         } else {
         DSEG_PROF(DINOSEG_PROF_LN, DSEG_TRY(launch_layernorm(X, W(h, b + "norm1.weight"), W(h, b + "norm1.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
-                                  nullptr, 0, L.ntok, s)));
+                                  nullptr, 0, L.ntok, s, FM)));
         {
             const PackedLinear& pk = h->packed.at(b + "attn.qkv.weight");
             GemmParams g = {};
             g.A = A; g.a_plane = L.a_plane; g.lda = D;
             g.W = pk.w; g.w_plane = pk.plane;
-            g.M = L.M; g.N = 3 * D; g.K = D; g.planes = P; g.epi = EPI_QKV;
+            g.M = L.M; g.N = 3 * D; g.K = D; g.planes = P; g.fmt = FM; g.epi = EPI_QKV; g.dispatch_rows = disp_M;
             g.bias = W(h, b + "attn.qkv.bias");
             g.q = Q; g.k = Kb; g.v = V; g.qkv_plane = L.qkv_plane;
             g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
@@ -553,14 +564,14 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
         }
         }
         if (attn_out && i == c.n_blocks - 1)      // get_last_selfattention: probabilities of the last block, then stop
-            return launch_attn_probs(Q, Kb, L.qkv_plane, P, B, H, L.ntok, L.npad, attn_out, s);
+            return launch_attn_probs(Q, Kb, L.qkv_plane, P, B, H, L.ntok, L.npad, attn_out, s, FM);
         if (mreq && mreq->cls_mask && i == c.n_blocks - 1) {
             // last block with cls_mask (Block.forward, vision_transformer.py:127-140): the CLS token attends through each mask;
             // its residual is repeated once per mask; MLP and the final norm run on those n_masks rows only.  The patch-token
             // rows of X / A / CTX / HB are dead from here on and host the n_masks rows (checked: n_masks < ntok).
             const int Nm = mreq->n_masks;
             DSEG_TRY(launch_cls_mask_attn(Q, Kb, V, L.qkv_plane, P, H, L.ntok, L.npad, mreq->cls_mask, Nm, CTX, L.ctx_plane,
-                                          mreq->attn_out, s));
+                                          mreq->attn_out, s, FM));
             if (!mreq->emb_out) return 0;
             float* Xm = X + D;                        // rows 1 .. Nm
             DSEG_TRY(launch_broadcast_row0(X, D, Nm, s));
@@ -570,7 +581,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
                 GemmParams g = {};
                 g.A = Ain; g.a_plane = a_plane; g.lda = lda;
                 g.W = pk.w; g.w_plane = pk.plane;
-                g.M = Nm; g.N = N; g.K = K; g.planes = P; g.epi = epi;
+                g.M = Nm; g.N = N; g.K = K; g.planes = P; g.fmt = FM; g.epi = epi;
                 g.bias = W(h, name + ".bias");
                 g.out_f32 = Xm; g.ldo_f32 = D;
                 g.out_bf16 = ob; g.out_plane = o_plane; g.ldo = N;
@@ -578,29 +589,30 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             };
             DSEG_TRY(lin(b + "attn.proj", CTX, L.ctx_plane, D, D, D, EPI_RESID, nullptr, 0));
             DSEG_TRY(launch_layernorm(Xm, W(h, b + "norm2.weight"), W(h, b + "norm2.bias"), c.ln_eps, Nm, D, A, L.a_plane, P, nullptr, 0,
-                                      L.ntok, s));
+                                      L.ntok, s, FM));
             DSEG_TRY(lin(b + "mlp.fc1", A, L.a_plane, D, F, D, EPI_GELU, HB, L.hb_plane));
             DSEG_TRY(lin(b + "mlp.fc2", HB, L.hb_plane, F, D, F, EPI_RESID, nullptr, 0));
             return launch_layernorm(Xm, W(h, "dino.norm.weight"), W(h, "dino.norm.bias"), c.ln_eps, Nm, D, A, L.a_plane, P,
-                                    mreq->emb_out, 0, L.ntok, s);
+                                    mreq->emb_out, 0, L.ntok, s, FM);
         }
         {
             AttnParams a = {};
             a.q = Q; a.k = Kb; a.v = V; a.qkv_plane = L.qkv_plane;
             a.ctx = CTX; a.ctx_plane = L.ctx_plane; a.lse = nullptr;
-            a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P;
+            a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P; a.fmt = FM;
             a.shared_gpu = h->in_split ? 1 : 0;
             DSEG_PROF(DINOSEG_PROF_ATTN, DSEG_TRY(launch_attention(a, s)));
         }
-        const bool fuse_mlp = h->packed_mlp.count(b) && mlp_fuse_wanted(h, L.M);
+        const bool fuse_mlp = h->packed_mlp.count(b) && mlp_fuse_wanted(h, disp_M);
         // (the role-split fused MLP kernel takes the attention output projection along: x += proj(ctx) + b, then the MLP, one launch)
-        const bool fuse_proj = fuse_mlp && options().proj_fused && options().mlp_variant != 1 && P == 1 && h->packed_proj.count(b);
+        const bool variant1 = options().mlp_variant == 1 && FM == FMT_BF16;      // (mlp_fused.hip knows bf16 only)
+        const bool fuse_proj = fuse_mlp && options().proj_fused && !variant1 && P == 1 && h->packed_proj.count(b);
         if (!fuse_proj) {
             const PackedLinear& pk = h->packed.at(b + "attn.proj.weight");
             GemmParams g = {};
             g.A = CTX; g.a_plane = L.ctx_plane; g.lda = D;
             g.W = pk.w; g.w_plane = pk.plane;
-            g.M = L.M; g.N = D; g.K = D; g.planes = P; g.epi = EPI_RESID;
+            g.M = L.M; g.N = D; g.K = D; g.planes = P; g.fmt = FM; g.epi = EPI_RESID; g.dispatch_rows = disp_M;
             g.bias = W(h, b + "attn.proj.bias");
             g.out_f32 = X; g.ldo_f32 = D;
             DSEG_PROF(DINOSEG_PROF_PROJ, DSEG_TRY(launch_gemm(g, s)));
@@ -611,7 +623,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             MlpFusedParams g = {};
             g.X = X; g.ldx = D; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
             g.Wp = h->packed_mlp.at(b); g.b1 = W(h, b + "mlp.fc1.bias"); g.b2 = W(h, b + "mlp.fc2.bias");
-            g.M = L.M;
+            g.M = L.M; g.fmt = FM;
             if (fuse_proj) {
                 g.ctx = CTX; g.Wproj = h->packed_proj.at(b); g.bproj = W(h, b + "attn.proj.bias");
                 const std::string nb = "dino.blocks." + std::to_string(i + 1) + ".";
@@ -623,24 +635,24 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
                     qkv_ready = true;
                 }
             }
-            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(options().mlp_variant == 1 ? launch_mlp_fused(g, s) : launch_mlp_fused2(g, s)));
+            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(variant1 ? launch_mlp_fused(g, s) : launch_mlp_fused2(g, s)));
         } else {
         if (fuse_ln && h->packed_slab.count(b + "mlp.fc1.weight") && L.hb_plane < (1L << 31)) {
             LnGemmParams g = {};
             g.X = X; g.ldx = D; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
             g.W = h->packed_slab.at(b + "mlp.fc1.weight"); g.bias = W(h, b + "mlp.fc1.bias");
-            g.M = L.M; g.N = F; g.epi = EPI_GELU;
+            g.M = L.M; g.N = F; g.epi = EPI_GELU; g.fmt = FM;
             g.out_bf16 = HB; g.out_plane = L.hb_plane; g.ldo = F;
             DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_gemm_ln(g, D, P, s)));
         } else {
         DSEG_PROF(DINOSEG_PROF_LN, DSEG_TRY(launch_layernorm(X, W(h, b + "norm2.weight"), W(h, b + "norm2.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
-                                  nullptr, 0, L.ntok, s)));
+                                  nullptr, 0, L.ntok, s, FM)));
         {
             const PackedLinear& pk = h->packed.at(b + "mlp.fc1.weight");
             GemmParams g = {};
             g.A = A; g.a_plane = L.a_plane; g.lda = D;
             g.W = pk.w; g.w_plane = pk.plane;
-            g.M = L.M; g.N = F; g.K = D; g.planes = P; g.epi = EPI_GELU;
+            g.M = L.M; g.N = F; g.K = D; g.planes = P; g.fmt = FM; g.epi = EPI_GELU; g.dispatch_rows = disp_M;
             g.bias = W(h, b + "mlp.fc1.bias");
             g.out_bf16 = HB; g.out_plane = L.hb_plane; g.ldo = F;
             DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_gemm(g, s)));
@@ -651,7 +663,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             GemmParams g = {};
             g.A = HB; g.a_plane = L.hb_plane; g.lda = F;
             g.W = pk.w; g.w_plane = pk.plane;
-            g.M = L.M; g.N = D; g.K = F; g.planes = P; g.epi = EPI_RESID;
+            g.M = L.M; g.N = D; g.K = F; g.planes = P; g.fmt = FM; g.epi = EPI_RESID; g.dispatch_rows = disp_M;
             g.bias = W(h, b + "mlp.fc2.bias");
             g.out_f32 = X; g.ldo_f32 = D;
             DSEG_PROF(DINOSEG_PROF_FC2, DSEG_TRY(launch_gemm(g, s)));
@@ -730,13 +742,13 @@ extern "C" int dinoseg_forward(dinoseg_handle* h, const void* x, int32_t x_kind,
     const size_t frame_bytes = x_kind == DINOSEG_INPUT_U8_HWC ? (size_t)r * r * 3 : (size_t)r * r * 3 * sizeof(float);
     const void* x1 = reinterpret_cast<const char*>(x) + (size_t)B0 * frame_bytes;
     const long ntok_ = n + 1;
-    if (mlp_fuse_wanted(h, B0 * ntok_) || mlp_fuse_wanted(h, B1 * ntok_)) DSEG_TRY(ensure_mlp_packs(h, s));   // before the fork: both halves read them
+    if (mlp_fuse_wanted(h, B * ntok_)) DSEG_TRY(ensure_mlp_packs(h, s));   // before the fork: both halves read them
     DSEG_CHECK_HIP(hipEventRecord(h->ev_fork, s));
     DSEG_CHECK_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
     h->in_split = true;
-    const int rc0 = forward_impl(h, x, x_kind, B0, r, logp_out, argmax_out, -1, nullptr, nullptr, stream);
+    const int rc0 = forward_impl(h, x, x_kind, B0, r, logp_out, argmax_out, -1, nullptr, nullptr, stream, nullptr, 0, B);
     const int rc1 = forward_impl(h, x1, x_kind, B1, r, logp_out ? logp_out + (size_t)B0 * n * h->cfg.n_classes : nullptr,
-                                 argmax_out ? argmax_out + (size_t)B0 * n : nullptr, -1, nullptr, nullptr, h->aux_stream, nullptr, 1);
+                                 argmax_out ? argmax_out + (size_t)B0 * n : nullptr, -1, nullptr, nullptr, h->aux_stream, nullptr, 1, B);
     h->in_split = false;
     // join even after an error: the caller's stream must not run ahead of work already queued on the internal one
     DSEG_CHECK_HIP(hipEventRecord(h->ev_join, h->aux_stream));
@@ -805,6 +817,14 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
     }
     if (strcmp(key, "gemm_big") == 0) {
         dseg::options().gemm_big = value;
+        return 0;
+    }
+    if (strcmp(key, "op_fmt") == 0) {      // operand format of the single-plane stand-alone ops (dinoseg_op_*): 0 bf16, 1 fp16
+        if (value != FMT_BF16 && value != FMT_FP16) {
+            dinoseg_set_error("dinoseg_set_option: op_fmt must be 0 (bf16) or 1 (fp16)");
+            return -1;
+        }
+        dseg::options().op_fmt = value;
         return 0;
     }
     if (strcmp(key, "streams") == 0) {
@@ -908,7 +928,7 @@ extern "C" int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* c
 extern "C" int dinoseg_op_pack(const float* src, int32_t rows, int32_t cols, void* dst, int64_t plane_stride,
                                int32_t rows_pad, int32_t cols_pad, int32_t planes, void* stream) {
     return launch_pack_planes(src, rows, cols, reinterpret_cast<bf16_t*>(dst), plane_stride, rows_pad, cols_pad, planes,
-                              reinterpret_cast<hipStream_t>(stream));
+                              reinterpret_cast<hipStream_t>(stream), planes == 1 ? options().op_fmt : FMT_BF16);
 }
 
 extern "C" int dinoseg_op_gemm(const void* A, int64_t a_plane, int32_t lda, const void* Wp, int64_t w_plane, int32_t M,
@@ -922,6 +942,7 @@ extern "C" int dinoseg_op_gemm(const void* A, int64_t a_plane, int32_t lda, cons
     g.A = reinterpret_cast<const bf16_t*>(A); g.a_plane = a_plane; g.lda = lda;
     g.W = reinterpret_cast<const bf16_t*>(Wp); g.w_plane = w_plane;
     g.M = M; g.N = N; g.K = K; g.planes = planes; g.epi = epi; g.bias = bias;
+    g.fmt = planes == 1 ? options().op_fmt : FMT_BF16;
     g.out_f32 = out_f32; g.ldo_f32 = N;
     g.out_bf16 = reinterpret_cast<bf16_t*>(out_bf16); g.out_plane = out_plane; g.ldo = ldo;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
@@ -935,6 +956,7 @@ extern "C" int dinoseg_op_qkv_gemm(const void* A, int64_t a_plane, const void* W
     g.A = reinterpret_cast<const bf16_t*>(A); g.a_plane = a_plane; g.lda = D;
     g.W = reinterpret_cast<const bf16_t*>(Wp); g.w_plane = w_plane;
     g.M = B * ntok; g.N = 3 * D; g.K = D; g.planes = planes; g.epi = EPI_QKV; g.bias = bias;
+    g.fmt = planes == 1 ? options().op_fmt : FMT_BF16;
     g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
     g.qkv_plane = qkv_plane; g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = D; g.qscale = qscale;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
@@ -947,7 +969,7 @@ extern "C" int dinoseg_op_pack_mlp(const float* W1, const float* W2, int32_t D, 
         dinoseg_set_error("dinoseg_op_pack_mlp: null pointer");
         return -1;
     }
-    return launch_pack_mlp(W1, W2, D, F, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream));
+    return launch_pack_mlp(W1, W2, D, F, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), options().op_fmt);
 }
 
 extern "C" int dinoseg_op_mlp_fused(float* X, const float* gamma, const float* beta, float eps, const void* Wp, const float* b1,
@@ -958,9 +980,9 @@ extern "C" int dinoseg_op_mlp_fused(float* X, const float* gamma, const float* b
     }
     MlpFusedParams g = {};
     g.X = X; g.ldx = D; g.gamma = gamma; g.beta = beta; g.eps = eps;
-    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
-    return options().mlp_variant == 1 ? launch_mlp_fused(g, reinterpret_cast<hipStream_t>(stream))
-                                      : launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
+    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M; g.fmt = options().op_fmt;
+    return options().mlp_variant == 1 && g.fmt == FMT_BF16 ? launch_mlp_fused(g, reinterpret_cast<hipStream_t>(stream))
+                                                           : launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t dinoseg_op_proj_pack_elems(int32_t D) { return mlp_fused_proj_pack_elems(D); }
@@ -970,7 +992,7 @@ extern "C" int dinoseg_op_pack_proj(const float* Wsrc, int32_t D, void* dst, voi
         dinoseg_set_error("dinoseg_op_pack_proj: null pointer or unsupported width D=%d", D);
         return -1;
     }
-    return launch_pack_proj(Wsrc, D, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream));
+    return launch_pack_proj(Wsrc, D, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), options().op_fmt);
 }
 
 extern "C" int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* Wproj, const float* bproj, const float* gamma,
@@ -985,6 +1007,7 @@ extern "C" int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* 
     g.X = X; g.ldx = D; g.gamma = gamma; g.beta = beta; g.eps = eps;
     g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
     g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.Wproj = reinterpret_cast<const bf16_t*>(Wproj); g.bproj = bproj;
+    g.fmt = options().op_fmt;
     return launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -995,7 +1018,7 @@ extern "C" int dinoseg_op_pack_qkv(const float* Wsrc, int32_t D, void* dst, void
         dinoseg_set_error("dinoseg_op_pack_qkv: null pointer or unsupported width D=%d", D);
         return -1;
     }
-    return launch_pack_qkv(Wsrc, D, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream));
+    return launch_pack_qkv(Wsrc, D, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), options().op_fmt);
 }
 
 extern "C" int dinoseg_op_block_tail_fused(float* X, const void* ctx, const void* Wproj, const float* bproj, const float* gamma2,
@@ -1015,7 +1038,7 @@ extern "C" int dinoseg_op_block_tail_fused(float* X, const void* ctx, const void
     g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.Wproj = reinterpret_cast<const bf16_t*>(Wproj); g.bproj = bproj;
     g.Wqkv = reinterpret_cast<const bf16_t*>(Wqkv); g.bqkv = bqkv; g.gamma1 = gamma1; g.beta1 = beta1;
     g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
-    g.ntok = ntok; g.npad = npad; g.heads = heads; g.qscale = qscale;
+    g.ntok = ntok; g.npad = npad; g.heads = heads; g.qscale = qscale; g.fmt = options().op_fmt;
     return launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1028,7 +1051,8 @@ extern "C" int dinoseg_op_pack_slabs(const float* Wsrc, int32_t N, int32_t K, in
         dinoseg_set_error("dinoseg_op_pack_slabs: unsupported shape N=%d K=%d planes=%d", N, K, planes);
         return -1;
     }
-    return launch_pack_slabs(Wsrc, N, K, planes, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream));
+    return launch_pack_slabs(Wsrc, N, K, planes, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream),
+                             planes == 1 ? options().op_fmt : FMT_BF16);
 }
 
 extern "C" int dinoseg_op_ln_gemm(const float* X, const float* gamma, const float* beta, float eps, const void* Wp, int64_t w_plane,
@@ -1044,6 +1068,7 @@ extern "C" int dinoseg_op_ln_gemm(const float* X, const float* gamma, const floa
     g.qkv_plane = qkv_plane; g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = heads * 64; g.qscale = qscale;
     g.a_out = reinterpret_cast<bf16_t*>(a_out); g.a_plane = (long)M * K;
     g.aux_out = reinterpret_cast<bf16_t*>(aux_out); g.aux_plane = out_plane;
+    g.fmt = planes == 1 ? options().op_fmt : FMT_BF16;
     return launch_gemm_ln(g, K, planes, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1055,6 +1080,7 @@ extern "C" int dinoseg_op_attention(const void* q, const void* k, const void* v,
     a.v = reinterpret_cast<const bf16_t*>(v); a.qkv_plane = qkv_plane;
     a.ctx = reinterpret_cast<bf16_t*>(ctx); a.ctx_plane = ctx_plane; a.lse = lse;
     a.B = B; a.heads = heads; a.ntok = ntok; a.npad = npad; a.planes = planes;
+    a.fmt = planes == 1 ? options().op_fmt : FMT_BF16;
     return launch_attention(a, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1062,7 +1088,7 @@ extern "C" int dinoseg_op_layernorm(const float* x, const float* gamma, const fl
                                     void* out_bf16, int64_t out_plane, int32_t planes, float* out_f32, int32_t drop_cls,
                                     int32_t ntok, void* stream) {
     return launch_layernorm(x, gamma, beta, eps, M, D, reinterpret_cast<bf16_t*>(out_bf16), out_plane, planes, out_f32,
-                            drop_cls, ntok, reinterpret_cast<hipStream_t>(stream));
+                            drop_cls, ntok, reinterpret_cast<hipStream_t>(stream), planes == 1 ? options().op_fmt : FMT_BF16);
 }
 
 extern "C" int dinoseg_op_pos_resample(const float* pos_embed, int32_t g, int32_t D, int32_t o, float* out, void* stream) {

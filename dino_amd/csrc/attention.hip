@@ -377,6 +377,13 @@ int launch_attention(const AttnParams& p0, hipStream_t s) {
         dinoseg_set_error("attention: npad=%d must be a multiple of 64 and >= ntok=%d", p.npad, p.ntok);
         return -1;
     }
+    if (p.fmt == FMT_FP16) {      // fp16 Q / K / ctx (inference): the zero-reference kernel only; no log-sum-exp for a backward
+        if (p.planes != 1 || p.lse != nullptr) {
+            dinoseg_set_error("attention: the fp16 operand format is single-plane and inference-only");
+            return -1;
+        }
+        return launch_attention_z(p, s);
+    }
     if (p.dbg != 0 && p.planes == 1) return launch_attn<1, 4, true, 0>(p, s);      // ablation build (tools/bench_ops.py)
     if (p.planes == 1 && (options().attn_variant & 8)) return launch_attention_z(p, s);      // zero-reference, 4 waves / SIMD
     if (p.planes == 2 && (options().attn_variant & 16)) return launch_attention_z(p, s);     // (hi + lo planes: experiment)

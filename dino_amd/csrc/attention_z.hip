@@ -29,8 +29,11 @@ constexpr int KV_TILE = attn::KV_TILE_BYTES;
 // NW waves per workgroup (32 query rows each); WPS = resident waves per SIMD the register budget is cut for.  The hi+lo
 // instantiation (experiment, attn_variant bit 4) uses ONE 12-wave workgroup per CU around its 64 KiB K/V ring = three waves per
 // SIMD (two 6-wave workgroups do not work: the dispatcher deals a workgroup's waves 2,2,1,1 over the SIMDs, twice).
-template <int PLANES, int WPS, int NW>
+// FMT (PLANES == 1 only): FMT_FP16 = Q, K (the QK^T product) and the ctx output are fp16; the probabilities and V -- the P.V product --
+// stay bf16 (2^S against the fixed reference 0 lives on bf16's exponent range).
+template <int PLANES, int WPS, int NW, int FMT = FMT_BF16>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_z_kernel(AttnParams p) {
+    static_assert(FMT == FMT_BF16 || PLANES == 1, "the fp16 operand format is single-plane");
     using namespace az;
     constexpr int QB = NW * QW;
     using attn::sigma23;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_z_kernel(AttnParams p) 
                     z = mfma32(kf[PLANES - 1][s], qf[0][s], z);
                     z = mfma32(kf[0][s], qf[PLANES - 1][s], z);
                 }
-                z = mfma32(kf[0][s], qf[0][s], z);
+                z = mfma32f<FMT>(kf[0][s], qf[0][s], z);
             }
             sacc[kb] = z;
         }
@@ -280,8 +283,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_z_kernel(AttnParams p) 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint2 hi, lo;
-                    split_bf16x2(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv, hi.x, lo.x);
-                    split_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv, hi.y, lo.y);
+                    if constexpr (FMT == FMT_FP16) {
+                        hi.x = pack2<FMT>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
+                        hi.y = pack2<FMT>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                        lo = hi;
+                    } else {
+                        split_bf16x2(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv, hi.x, lo.x);
+                        split_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv, hi.y, lo.y);
+                    }
                     *reinterpret_cast<uint2*>(patch + lr * 128 + (((db * 4 + g) ^ (lr & 7)) << 4) + lh * 8) = pl == 0 ? hi : lo;
                 }
             asm volatile("" ::: "memory");
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_z_kernel(AttnParams p) 
     }
 }
 
-template <int PLANES, int WPS, int NW>
+template <int PLANES, int WPS, int NW, int FMT = FMT_BF16>
 static int launch_z(const AttnParams& p, hipStream_t s) {
     using namespace az;
     constexpr int QB = NW * QW;
@@ -306,7 +315,7 @@ static int launch_z(const AttnParams& p, hipStream_t s) {
     const int npairs = p.B * p.heads;
     const int grid = ((npairs + 7) / 8) * 8 * nq;
     const size_t lds = (size_t)2 * PLANES * 2 * KV_TILE + 16;
-    hipLaunchKernelGGL((attn_fwd_z_kernel<PLANES, WPS, NW>), dim3(grid), dim3(NW * 64), lds, s, p);
+    hipLaunchKernelGGL((attn_fwd_z_kernel<PLANES, WPS, NW, FMT>), dim3(grid), dim3(NW * 64), lds, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -321,8 +330,16 @@ int launch_attention_z(const AttnParams& p, hipStream_t s) {
         const int ncu = device_cu_count();
         const long wgs4 = (long)((p.B * p.heads + 7) / 8) * 8 * ((p.ntok + 127) / 128);
         const bool wide = ncu > 0 && (wgs4 >= 4L * ncu || (p.shared_gpu && wgs4 >= 2L * ncu));
+        if (p.fmt == FMT_FP16) {
+            if (wide && !(options().attn_variant & 64)) return launch_z<1, 4, 8, FMT_FP16>(p, s);
+            return launch_z<1, 4, 4, FMT_FP16>(p, s);
+        }
         if (wide && !(options().attn_variant & 64)) return launch_z<1, 4, 8>(p, s);
         return launch_z<1, 4, 4>(p, s);
+    }
+    if (p.fmt != FMT_BF16) {
+        dinoseg_set_error("attention: the fp16 operand format is single-plane");
+        return -1;
     }
     return launch_z<2, 3, 12>(p, s);      // hi + lo planes: 168 registers, three waves per SIMD (the reference-based kernel: 213, two)
 }

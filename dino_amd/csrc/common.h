@@ -25,6 +25,41 @@ __device__ __forceinline__ float bf16_lo_to_f32(uint32_t packed) { return __buil
 __device__ __forceinline__ float bf16_hi_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed & 0xFFFF0000u); }
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
 
+// ---- operand format of the single-plane modes: bf16 (8 significand bits, fp32's exponent range) or fp16 (11 bits, |x| < 65504).
+// Both are 16-bit storage (bf16_t) and ride in the same registers (bf16x8 = four VGPRs); what differs is the conversion
+// (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32), the way back to fp32, and the MFMA opcode (same rate).  Kernels take it as a template
+// parameter; the pack / gather kernels that run once per weight refresh take it at run time.
+enum OperandFmt { FMT_BF16 = 0, FMT_FP16 = 1 };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+template <int FMT>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    if constexpr (FMT == FMT_FP16) return pack_f16x2(a, b);
+    else return pack_bf16x2(a, b);
+}
+template <int FMT>
+__device__ __forceinline__ float lo_to_f32(uint32_t packed) {
+    if constexpr (FMT == FMT_FP16) return (float)__builtin_bit_cast(f16x2, packed)[0];
+    else return bf16_lo_to_f32(packed);
+}
+template <int FMT>
+__device__ __forceinline__ float hi_to_f32(uint32_t packed) {
+    if constexpr (FMT == FMT_FP16) return (float)__builtin_bit_cast(f16x2, packed)[1];
+    else return bf16_hi_to_f32(packed);
+}
+// run-time forms (pack kernels, the small gather kernels of the visualisation paths)
+__device__ __forceinline__ bf16_t pack1(float v, int fmt) {
+    return (bf16_t)((fmt == FMT_FP16 ? pack_f16x2(v, 0.f) : pack_bf16x2(v, 0.f)) & 0xFFFFu);
+}
+__device__ __forceinline__ float unpack1(bf16_t v, int fmt) {
+    return fmt == FMT_FP16 ? (float)__builtin_bit_cast(f16x2, (uint32_t)v)[0] : bf16_to_f32(v);
+}
+
 // hi/lo split of two floats: hi = bf16(x), lo = bf16(x - hi).  hi + lo carries ~16 mantissa bits.
 __device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
     hi = pack_bf16x2(a, b);
@@ -51,6 +86,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// the same product on operands of either format (the registers carry bit patterns: bf16x8 is just "eight 16-bit elements")
+template <int FMT>
+__device__ __forceinline__ f32x16 mfma32f(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (FMT == FMT_FP16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) {

@@ -10,11 +10,15 @@ namespace dseg {
 // fp32 [rows, cols] -> bf16 hi(/lo) planes [planes][rows_pad][cols_pad], zero padded.
 // Used once per weight refresh (nn.Linear weights are [out, in] = the W[N,K] operand of gemm.hip).
 __global__ void pack_planes_kernel(const float* __restrict__ src, int rows, int cols, bf16_t* __restrict__ dst,
-                                   long plane, int rows_pad, int cols_pad, int planes) {
+                                   long plane, int rows_pad, int cols_pad, int planes, int fmt) {
     const long total = (long)rows_pad * cols_pad;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int r = (int)(i / cols_pad), c = (int)(i - (long)r * cols_pad);
         const float v = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+        if (fmt == FMT_FP16) {      // (single plane)
+            dst[i] = pack1(v, fmt);
+            continue;
+        }
         const uint32_t hi = pack_bf16x2(v, 0.f);
         dst[i] = (bf16_t)(hi & 0xFFFF);
         if (planes == 2) dst[plane + i] = (bf16_t)(pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
@@ -22,11 +26,15 @@ __global__ void pack_planes_kernel(const float* __restrict__ src, int rows, int 
 }
 
 int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,
-                       int planes, hipStream_t s) {
+                       int planes, hipStream_t s, int fmt) {
+    if (fmt != FMT_BF16 && planes != 1) {
+        dinoseg_set_error("pack_planes: the fp16 operand format is single-plane");
+        return -1;
+    }
     const long total = (long)rows_pad * cols_pad;
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(pack_planes_kernel, dim3(grid), dim3(256), 0, s, src, rows, cols, dst, plane, rows_pad, cols_pad, planes);
+    hipLaunchKernelGGL(pack_planes_kernel, dim3(grid), dim3(256), 0, s, src, rows, cols, dst, plane, rows_pad, cols_pad, planes, fmt);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -89,6 +97,10 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(MultiPackTable T) {
         }
         if (r0 + r >= j.rows_pad || c0 + c >= j.cols_pad) continue;
         const float v = tile[r][c];
+        if (j.fmt == FMT_FP16) {      // (single plane)
+            j.dst[d] = pack1(v, j.fmt);
+            continue;
+        }
         const uint32_t hi = pack_bf16x2(v, 0.f);
         j.dst[d] = (bf16_t)(hi & 0xFFFF);
         if (j.planes == 2) j.dst[j.plane + d] = (bf16_t)(pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
@@ -121,7 +133,7 @@ template <int NV>   // D = 128 * NV
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int M,
                                                         bf16_t* __restrict__ out, long out_plane, int planes,
-                                                        float* __restrict__ out_f32, int drop_cls, int ntok) {
+                                                        float* __restrict__ out_f32, int drop_cls, int ntok, int fmt) {
     constexpr int D = 128 * NV;
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -167,7 +179,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             }
             if (out) {
                 uint32_t hi, lo;
-                split_bf16x2(y0, y1, hi, lo);
+                if (fmt == FMT_FP16) hi = lo = pack_f16x2(y0, y1);      // (single plane; wave-uniform)
+                else split_bf16x2(y0, y1, hi, lo);
                 *reinterpret_cast<uint32_t*>(out + o) = hi;
                 if (planes == 2) *reinterpret_cast<uint32_t*>(out + out_plane + o) = lo;
             }
@@ -176,8 +189,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, int M, int D, bf16_t* out,
-                     long out_plane, int planes, float* out_f32, int drop_cls, int ntok, hipStream_t s) {
+                     long out_plane, int planes, float* out_f32, int drop_cls, int ntok, hipStream_t s, int fmt) {
     if (M <= 0) return 0;
+    if (fmt != FMT_BF16 && planes != 1) {
+        dinoseg_set_error("layernorm: the fp16 operand format is single-plane");
+        return -1;
+    }
     if (D % 128 != 0 || D > 1024) {
         dinoseg_set_error("layernorm: D=%d must be a multiple of 128 and <= 1024", D);
         return -1;
@@ -187,7 +204,7 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, floa
 #define DSEG_LN(NV)                                                                                              \
     case NV:                                                                                                     \
         hipLaunchKernelGGL((layernorm_kernel<NV>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, M, out,    \
-                           out_plane, planes, out_f32, drop_cls, ntok);                                          \
+                           out_plane, planes, out_f32, drop_cls, ntok, fmt);                                     \
         break;
     switch (D / 128) {
         DSEG_LN(1) DSEG_LN(2) DSEG_LN(3) DSEG_LN(4) DSEG_LN(5) DSEG_LN(6) DSEG_LN(7) DSEG_LN(8)
@@ -421,7 +438,7 @@ int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, con
 // grid (ceil(ntok/16), B*H): scores of 16 queries against all keys (Q~ is pre-scaled by scale*log2e, so the
 // softmax is exp2-based), then the same workgroup normalises its 16 rows in place.
 __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, long plane,
-                                                         int planes, int ntok, int npad, float* __restrict__ out) {
+                                                         int planes, int ntok, int npad, float* __restrict__ out, int fmt) {
     __shared__ float qs[16][64];
     const int pair = blockIdx.y, q0 = blockIdx.x * 16, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bf16_t* Qg = q + (long)pair * npad * 64;
@@ -429,7 +446,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restric
     for (int i = tid; i < 16 * 64; i += 256) {
         const int r = i >> 6, d = i & 63;
         const int qr = q0 + r < ntok ? q0 + r : ntok - 1;
-        float v = bf16_to_f32(Qg[(long)qr * 64 + d]);
+        float v = unpack1(Qg[(long)qr * 64 + d], fmt);
         if (planes == 2) v += bf16_to_f32(Qg[plane + (long)qr * 64 + d]);
         qs[r][d] = v;
     }
@@ -443,8 +460,8 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restric
             const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                kv[c * 8 + 2 * e] = bf16_lo_to_f32(hw[e]);
-                kv[c * 8 + 2 * e + 1] = bf16_hi_to_f32(hw[e]);
+                kv[c * 8 + 2 * e] = fmt == FMT_FP16 ? lo_to_f32<FMT_FP16>(hw[e]) : bf16_lo_to_f32(hw[e]);
+                kv[c * 8 + 2 * e + 1] = fmt == FMT_FP16 ? hi_to_f32<FMT_FP16>(hw[e]) : bf16_hi_to_f32(hw[e]);
             }
             if (planes == 2) {
                 const uint4 l = *reinterpret_cast<const uint4*>(Kg + plane + (long)key * 64 + c * 8);
@@ -484,8 +501,8 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restric
 }
 
 int launch_attn_probs(const bf16_t* q, const bf16_t* k, long plane, int planes, int B, int heads, int ntok, int npad, float* out,
-                      hipStream_t s) {
-    hipLaunchKernelGGL(attn_probs_kernel, dim3((ntok + 15) / 16, B * heads), dim3(256), 0, s, q, k, plane, planes, ntok, npad, out);
+                      hipStream_t s, int fmt) {
+    hipLaunchKernelGGL(attn_probs_kernel, dim3((ntok + 15) / 16, B * heads), dim3(256), 0, s, q, k, plane, planes, ntok, npad, out, fmt);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -500,24 +517,26 @@ int launch_attn_probs(const bf16_t* q, const bf16_t* k, long plane, int planes, 
 __global__ __launch_bounds__(256) void cls_mask_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                             const bf16_t* __restrict__ v, long plane, int planes, int heads, int ntok,
                                                             int npad, const float* __restrict__ mask, int n_masks,
-                                                            bf16_t* __restrict__ ctx, long ctx_plane, float* __restrict__ probs) {
+                                                            bf16_t* __restrict__ ctx, long ctx_plane, float* __restrict__ probs,
+                                                            int fmt) {
     extern __shared__ float sc[];           // [ntok] scores -> probabilities, then [4][64] partial contexts
     __shared__ float qs[64];
     __shared__ float red[8];
     const int m = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long po = (long)hd * npad * 64;
-    auto ld = [&](const bf16_t* base, long idx) {
-        float x = bf16_to_f32(base[idx]);
+    // (fp16 mode: Q, K and the ctx output are fp16, V is bf16 -- as the fused attention kernel has them)
+    auto ld = [&](const bf16_t* base, long idx, int f = FMT_BF16) {
+        float x = unpack1(base[idx], f);
         if (planes == 2) x += bf16_to_f32(base[plane + idx]);
         return x;
     };
-    if (tid < 64) qs[tid] = ld(q, po + tid);                      // CLS row = token 0
+    if (tid < 64) qs[tid] = ld(q, po + tid, fmt);                 // CLS row = token 0
     __syncthreads();
     const float* mrow = mask + (long)m * (ntok - 1);
     float mx = -INFINITY;
     for (int n = tid; n < ntok; n += 256) {
         float s = 0.f;
-        for (int d = 0; d < 64; ++d) s = fmaf(qs[d], ld(k, po + (long)n * 64 + d), s);
+        for (int d = 0; d < 64; ++d) s = fmaf(qs[d], ld(k, po + (long)n * 64 + d, fmt), s);
         s *= (n == 0) ? 0.f : mrow[n - 1];
         sc[n] = s;
         mx = fmaxf(mx, s);
@@ -549,7 +568,7 @@ __global__ __launch_bounds__(256) void cls_mask_attn_kernel(const bf16_t* __rest
     __syncthreads();
     if (tid < 64) {
         const float o = (sc[tid] + sc[64 + tid] + sc[128 + tid] + sc[192 + tid]) * inv;
-        const uint32_t hi = pack_bf16x2(o, 0.f);
+        const uint32_t hi = fmt == FMT_FP16 ? pack_f16x2(o, 0.f) : pack_bf16x2(o, 0.f);
         const long idx = (long)m * heads * 64 + hd * 64 + tid;
         ctx[idx] = (bf16_t)(hi & 0xFFFF);
         if (planes == 2) ctx[ctx_plane + idx] = (bf16_t)(pack_bf16x2(o - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
@@ -557,14 +576,14 @@ __global__ __launch_bounds__(256) void cls_mask_attn_kernel(const bf16_t* __rest
 }
 
 int launch_cls_mask_attn(const bf16_t* q, const bf16_t* k, const bf16_t* v, long plane, int planes, int heads, int ntok, int npad,
-                         const float* mask, int n_masks, bf16_t* ctx, long ctx_plane, float* probs, hipStream_t s) {
+                         const float* mask, int n_masks, bf16_t* ctx, long ctx_plane, float* probs, hipStream_t s, int fmt) {
     const size_t lds = (size_t)(ntok > 256 ? ntok : 256) * sizeof(float);
     if (lds > 60 * 1024) {
         dinoseg_set_error("cls_mask_attn: %d tokens exceed the LDS score buffer", ntok);
         return -1;
     }
     hipLaunchKernelGGL(cls_mask_attn_kernel, dim3(n_masks, heads), dim3(256), lds, s, q, k, v, plane, planes, heads, ntok, npad, mask,
-                       n_masks, ctx, ctx_plane, probs);
+                       n_masks, ctx, ctx_plane, probs, fmt);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -19,8 +19,10 @@ namespace dseg {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 128;   // one [128][64] bf16 slab
 
-template <int PLANES, int EPI>
+// FMT (PLANES == 1, inference epilogues only): FMT_FP16 = A, W and the 16-bit outputs are fp16 (EPI_QKV: V stays bf16)
+template <int PLANES, int EPI, int FMT = FMT_BF16>
 __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(GemmParams p) {
+    static_assert(FMT == FMT_BF16 || (PLANES == 1 && (EPI == EPI_RESID || EPI == EPI_GELU || EPI == EPI_QKV)), "fp16: single plane, inference");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = PLANES * 2 * TILE_BYTES;
 
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
                         acc[i][j] = mfma32(a[1][i], b[0][j], acc[i][j]);
                         acc[i][j] = mfma32(a[0][i], b[1][j], acc[i][j]);
                     }
-                    acc[i][j] = mfma32(a[0][i], b[0][j], acc[i][j]);
+                    acc[i][j] = mfma32f<FMT>(a[0][i], b[0][j], acc[i][j]);
                 }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -180,10 +182,18 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
                 if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
             }
             uint4 hi, lo;
-            split_bf16x2(v[0], v[1], hi.x, lo.x);
-            split_bf16x2(v[2], v[3], hi.y, lo.y);
-            split_bf16x2(v[4], v[5], hi.z, lo.z);
-            split_bf16x2(v[6], v[7], hi.w, lo.w);
+            if (FMT == FMT_FP16 && !(EPI == EPI_QKV && which == 2)) {      // (which is workgroup-uniform)
+                hi.x = pack2<FMT>(v[0], v[1]);
+                hi.y = pack2<FMT>(v[2], v[3]);
+                hi.z = pack2<FMT>(v[4], v[5]);
+                hi.w = pack2<FMT>(v[6], v[7]);
+                lo = hi;
+            } else {
+                split_bf16x2(v[0], v[1], hi.x, lo.x);
+                split_bf16x2(v[2], v[3], hi.y, lo.y);
+                split_bf16x2(v[4], v[5], hi.z, lo.z);
+                split_bf16x2(v[6], v[7], hi.w, lo.w);
+            }
             bf16_t* dst;
             long plane_stride;
             if (EPI == EPI_QKV) {
@@ -250,18 +260,18 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
     }
 }
 
-template <int PLANES, int EPI>
+template <int PLANES, int EPI, int FMT = FMT_BF16>
 static int launch_one(const GemmParams& p, hipStream_t s) {
     const int nbn = p.N / BN, nbm = (p.M + BM - 1) / BM;
     const int grid = ((nbm + 7) / 8) * 8 * nbn;
     const size_t lds = (size_t)PLANES * 2 * 2 * TILE_BYTES;
     static PerDeviceOnce once;
     if (once.first()) {
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<PLANES, EPI>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<PLANES, EPI, FMT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.mark();
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<PLANES, EPI>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<PLANES, EPI, FMT>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3(256), lds, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -277,7 +287,8 @@ int launch_gemm(const GemmParams& p0, hipStream_t s) {
         // below 128 tiles the 128x128 kernel has 3-6x more workgroups to spread (fc2 at B = 1: 60 -> 40 us).
         // (planes == 2: 128-row tiles of three times the work)
         const int bm_big = p.planes == 2 ? 128 : 256;
-        const long tiles = (long)((p.M + bm_big - 1) / bm_big) * (p.N / 384);
+        const int m_disp = p.dispatch_rows > 0 ? p.dispatch_rows : p.M;
+        const long tiles = (long)((m_disp + bm_big - 1) / bm_big) * (p.N / 384);
         // (K >= 768: ViT-B's attn.proj at 8-16 frames -- 226-450 tiles -- 1.66 -> 1.41 ms per step on the persistent kernel)
         if (options().gemm_big > 1 || p.K % BK != 0 || (tiles >= 128 && (tiles >= 512 || p.K >= 768))) return launch_gemm_big(p, s);
     }
@@ -292,6 +303,13 @@ int launch_gemm_small(const GemmParams& p, hipStream_t s) {
     }
     if (p.epi == EPI_QKV && (p.dmodel % 128 != 0 || p.N != 3 * p.dmodel)) {
         dinoseg_set_error("gemm: QKV epilogue needs dmodel%%128==0 and N==3*dmodel");
+        return -1;
+    }
+    if (p.fmt == FMT_FP16) {
+        if (p.planes == 1 && p.epi == EPI_RESID) return launch_one<1, EPI_RESID, FMT_FP16>(p, s);
+        if (p.planes == 1 && p.epi == EPI_GELU && p.aux_out == nullptr) return launch_one<1, EPI_GELU, FMT_FP16>(p, s);
+        if (p.planes == 1 && p.epi == EPI_QKV) return launch_one<1, EPI_QKV, FMT_FP16>(p, s);
+        dinoseg_set_error("gemm: the fp16 operand format covers the single-plane inference epilogues only (planes=%d epi=%d)", p.planes, p.epi);
         return -1;
     }
 #define DSEG_CASE(PL, E) \

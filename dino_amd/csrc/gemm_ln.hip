@@ -96,8 +96,12 @@ long gemm_ln_slab_elems(int N, int K, int planes) {
     return (long)((N + bn - 1) / bn) * bn * K * planes;
 }
 
-int launch_pack_slabs(const float* src, int N, int K, int planes, bf16_t* dst, hipStream_t s) {
-    if (planes == 1) return launch_pack_slabs12(src, N, K, dst, s);
+int launch_pack_slabs(const float* src, int N, int K, int planes, bf16_t* dst, hipStream_t s, int fmt) {
+    if (planes == 1) return launch_pack_slabs12(src, N, K, dst, s, fmt);
+    if (fmt != FMT_BF16) {
+        dinoseg_set_error("pack_slabs: the fp16 operand format is single-plane only");
+        return -1;
+    }
     const long total = gemm_ln_slab_elems(N, K, planes);
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;

@@ -34,7 +34,7 @@ constexpr int PASSES = BM / 4, PPW = (PASSES + NW - 1) / NW;     // LayerNorm: 4
 }  // namespace ln12
 
 __global__ __launch_bounds__(256) void pack_slabs12_kernel(const float* __restrict__ src, int N, int K, bf16_t* __restrict__ dst,
-                                                           long total) {
+                                                           long total, int fmt) {
     const int nh = K / 16;
     const long nstages = (long)((N + ln12::BN - 1) / ln12::BN) * nh;      // + RING more: the first RING stages again (see the kernel)
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void pack_slabs12_kernel(const float* __restri
         const int tile = (int)(t / nh);
         const int n = tile * ln12::BN + rb * 32 + r, k = h * 16 + ((phys ^ ((r >> 3) & 1)) << 3) + e;
         const float v = n < N ? src[(long)n * K + k] : 0.f;
-        dst[idx] = (bf16_t)(pack_bf16x2(v, 0.f) & 0xFFFF);
+        dst[idx] = pack1(v, fmt);
     }
 }
 
@@ -59,20 +59,23 @@ long gemm_ln12_slab_elems(int N, int K) {
     return (long)((N + ln12::BN - 1) / ln12::BN) * ln12::BN * K + (long)ln12::RING * ln12::HSTAGE / 2;
 }
 
-int launch_pack_slabs12(const float* src, int N, int K, bf16_t* dst, hipStream_t s) {
+int launch_pack_slabs12(const float* src, int N, int K, bf16_t* dst, hipStream_t s, int fmt) {
     const long total = gemm_ln12_slab_elems(N, K);
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pack_slabs12_kernel, dim3(grid), dim3(256), 0, s, src, N, K, dst, total);
+    hipLaunchKernelGGL(pack_slabs12_kernel, dim3(grid), dim3(256), 0, s, src, N, K, dst, total, fmt);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
+#ifndef LN12_NT
+#define LN12_NT 0           // experiment: 1 = the residual rows are loaded, 2 = the outputs stored with the non-temporal hint
+#endif
 #ifndef ALN_ABL
 #define ALN_ABL 0           // compile-time ablation bits for A/B builds (tools/build_variant.sh): 1 skip epilogue, 2 skip W DMA,
 #endif                      // 4 skip LayerNorm, 8 skip MFMAs, 32 skip fragment reads
 
-template <int EPI, bool DBG>
+template <int EPI, bool DBG, int FMT>
 __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParams p) {
     using namespace ln12;
     using aln::off64;
@@ -115,7 +118,8 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
     f32x16 acc[MI];
     uint32_t row_off[MI];       // element offset of this lane's output row in each row block of the current panel
     float bias_cur, bias_nxt;   // lane = column; loaded by asm (the compiler must not wait for them with the ring in flight)
-    const uint4 ones_u = {lh == 0 ? 0x3F803F80u : 0u, lh == 0 ? 0x00003F80u : 0u, 0u, 0u};     // k = 0, 1, 2 are 1.0
+    constexpr uint32_t ONE = FMT == FMT_FP16 ? 0x3C00u : 0x3F80u;
+    const uint4 ones_u = {lh == 0 ? (ONE << 16 | ONE) : 0u, lh == 0 ? ONE : 0u, 0u, 0u};     // k = 0, 1, 2 are 1.0
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
     auto load_bias = [&](int bn, float& dst) {
         int n = bn * BN + wave * 32 + lr;
@@ -127,10 +131,10 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
     auto init_acc = [&](float& b) {
         asm volatile("" : "+v"(b));
         const float bj = b;
-        const uint32_t hi = pack_bf16x2(bj, 0.f);
-        const float r1 = bj - bf16_lo_to_f32(hi);
-        const uint32_t mid = pack_bf16x2(r1, 0.f);
-        const uint32_t lo = pack_bf16x2(r1 - bf16_lo_to_f32(mid), 0.f);
+        const uint32_t hi = pack2<FMT>(bj, 0.f);
+        const float r1 = bj - lo_to_f32<FMT>(hi);
+        const uint32_t mid = pack2<FMT>(r1, 0.f);
+        const uint32_t lo = pack2<FMT>(r1 - lo_to_f32<FMT>(mid), 0.f);
         const uint4 fu = {lh == 0 ? ((hi & 0xFFFFu) | (mid << 16)) : 0u, lh == 0 ? (lo & 0xFFFFu) : 0u, 0u, 0u};
         f32x16 z;
 #pragma unroll
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             asm volatile("" : "+v"(one_frag));      // opaque: MI separate MFMAs, not one result copied MI times
-            acc[i] = mfma32(__builtin_bit_cast(bf16x8, fu), one_frag, z);
+            acc[i] = mfma32f<FMT>(__builtin_bit_cast(bf16x8, fu), one_frag, z);
         }
     };
 
@@ -162,12 +166,17 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
         } else {
             base = p.out_bf16 + row_off[i] + n0;
         }
-        auto store_block = [&](const float* val, bf16_t* dst) {
+        auto store_block = [&](const float* val, bf16_t* dst, bool as_bf16 = false) {
             uint2 w[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                w[q].x = pack_bf16x2(val[4 * q], val[4 * q + 1]);
-                w[q].y = pack_bf16x2(val[4 * q + 2], val[4 * q + 3]);
+                if (FMT == FMT_BF16 || as_bf16) {        // (as_bf16 is wave-uniform: V of the fp16 mode)
+                    w[q].x = pack_bf16x2(val[4 * q], val[4 * q + 1]);
+                    w[q].y = pack_bf16x2(val[4 * q + 2], val[4 * q + 3]);
+                } else {
+                    w[q].x = pack2<FMT>(val[4 * q], val[4 * q + 1]);
+                    w[q].y = pack2<FMT>(val[4 * q + 2], val[4 * q + 3]);
+                }
             }
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
@@ -176,6 +185,10 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
                 const auto sy = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
                 const uint4 o = {sx[0], sy[0], sx[1], sy[1]};
                 if ((DBG || ALN_ABL) && (dbg & 64)) asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));      // ablation: stores issued from the k-loop instead
+                else if (LN12_NT & 2) {
+                    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(dst + qq * 16 + lh * 8));
+                }
                 else *reinterpret_cast<uint4*>(dst + qq * 16 + lh * 8) = o;
             }
         };
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
             if (EPI == EPI_GELU) v[r] = gelu_fast(v[r]);
             if (EPI == EPI_QKV && which == 0) v[r] *= p.qscale;
         }
-        store_block(v, base);
+        store_block(v, base, EPI == EPI_QKV && which == 2);
     };
 
     // ---- fragment pipeline: two register sets, the reads of half-step U+1 are issued during half-step U (inline asm: the
@@ -237,17 +250,17 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
         const Half& f = hs[KK];
         await_set(Cur{});
         const bool mm = VALID && !((DBG || ALN_ABL) && (dbg & 8));
-        if (mm) acc[0] = mfma32(f.w, f.a[0], acc[0]);
+        if (mm) acc[0] = mfma32f<FMT>(f.w, f.a[0], acc[0]);
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t ring_next = ring_off + UNIT == RING * UNIT ? 0 : ring_off + UNIT;
         issue_reads(Nxt{}, a_off_next, KK ^ 1, ring_next);
         __builtin_amdgcn_sched_barrier(0);
-        if (mm) acc[1] = mfma32(f.w, f.a[1], acc[1]);
+        if (mm) acc[1] = mfma32f<FMT>(f.w, f.a[1], acc[1]);
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 2)) issue_next(ring_off);      // this unit's fragments are in registers: its slot takes unit + RING
         __builtin_amdgcn_sched_barrier(0);
-        if (mm) acc[2] = mfma32(f.w, f.a[2], acc[2]);
-        if (mm) acc[3] = mfma32(f.w, f.a[3], acc[3]);
+        if (mm) acc[2] = mfma32f<FMT>(f.w, f.a[2], acc[2]);
+        if (mm) acc[3] = mfma32f<FMT>(f.w, f.a[3], acc[3]);
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 2)) {
             if (LAX && prev_stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 2 + TILE_STORES) : "memory");
@@ -335,7 +348,9 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
                 gm = gm < M ? gm : M - 1;
                 const float* xr = p.X + (long)gm * p.ldx + l * 4;
 #pragma unroll
-                for (int it = 0; it < NT; ++it) x[ps][it] = *reinterpret_cast<const f32x4*>(xr + it * 64);
+                for (int it = 0; it < NT; ++it)
+                    x[ps][it] = (LN12_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + it * 64))
+                                              : *reinterpret_cast<const f32x4*>(xr + it * 64);
             }
 #pragma unroll
             for (int ps = 0; ps < PPW; ++ps) {
@@ -366,8 +381,8 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y[e] = x[ps][it][e] * rstd * gam[e] + bet[e];
                         uint2 hi;
-                        hi.x = pack_bf16x2(y[0], y[1]);
-                        hi.y = pack_bf16x2(y[2], y[3]);
+                        hi.x = pack2<FMT>(y[0], y[1]);
+                        hi.y = pack2<FMT>(y[2], y[3]);
                         // column c = it*64 + l*4: k-slab c >> 5, 16-byte chunk (c & 31) >> 3, byte (c & 7) * 2
                         char* dst = sA + (it * 2 + (l >> 3)) * A_SLAB + off64(row, (l >> 1) & 3) + (l & 1) * 8;
                         *reinterpret_cast<uint2*>(dst) = hi;
@@ -418,13 +433,13 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the RING units issued past the end (and the last stores)
 }
 
-template <int EPI>
+template <int EPI, int FMT>
 static int launch_ln12(const LnGemmParams& p, hipStream_t s) {
     static PerDeviceOnce once;
     if (once.first()) {
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln12_kernel<EPI, false>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln12_kernel<EPI, false, FMT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ln12::LDS_BYTES));
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln12_kernel<EPI, true>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln12_kernel<EPI, true, FMT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ln12::LDS_BYTES));
         once.mark();
     }
@@ -439,16 +454,24 @@ static int launch_ln12(const LnGemmParams& p, hipStream_t s) {
     const int rounds = (npanels + ncu - 1) / ncu;
     const int grid = (npanels + rounds - 1) / rounds;
 #endif
-    if (p.dbg) hipLaunchKernelGGL((gemm_ln12_kernel<EPI, true>), dim3(grid), dim3(ln12::THREADS), ln12::LDS_BYTES, s, p);
-    else hipLaunchKernelGGL((gemm_ln12_kernel<EPI, false>), dim3(grid), dim3(ln12::THREADS), ln12::LDS_BYTES, s, p);
+    if (p.dbg) hipLaunchKernelGGL((gemm_ln12_kernel<EPI, true, FMT>), dim3(grid), dim3(ln12::THREADS), ln12::LDS_BYTES, s, p);
+    else hipLaunchKernelGGL((gemm_ln12_kernel<EPI, false, FMT>), dim3(grid), dim3(ln12::THREADS), ln12::LDS_BYTES, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 // (shape checks: launch_gemm_ln in gemm_ln.hip)
 int launch_gemm_ln12(const LnGemmParams& p, hipStream_t s) {
-    if (p.epi == EPI_QKV) return launch_ln12<EPI_QKV>(p, s);
-    return launch_ln12<EPI_GELU>(p, s);
+    if (p.fmt == FMT_FP16) {
+        if (p.a_out != nullptr || p.aux_out != nullptr) {
+            dinoseg_set_error("gemm_ln12: the fp16 operand format is inference-only (no a_out / aux_out)");
+            return -1;
+        }
+        if (p.epi == EPI_QKV) return launch_ln12<EPI_QKV, FMT_FP16>(p, s);
+        return launch_ln12<EPI_GELU, FMT_FP16>(p, s);
+    }
+    if (p.epi == EPI_QKV) return launch_ln12<EPI_QKV, FMT_BF16>(p, s);
+    return launch_ln12<EPI_GELU, FMT_BF16>(p, s);
 }
 
 }  // namespace dseg

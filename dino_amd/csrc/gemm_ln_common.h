@@ -28,7 +28,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // gemm_ln12.hip: the bf16 (one plane) configuration -- 12 waves, 128 x 384 tile
 constexpr int LN12_BN = 384;
 long gemm_ln12_slab_elems(int N, int K);
-int launch_pack_slabs12(const float* src, int N, int K, bf16_t* dst, hipStream_t s);
+int launch_pack_slabs12(const float* src, int N, int K, bf16_t* dst, hipStream_t s, int fmt = 0);
 struct LnGemmParams;
 int launch_gemm_ln12(const LnGemmParams& p, hipStream_t s);
 

@@ -30,6 +30,8 @@ struct GemmParams {
     int n_valid;                                // ATOMIC: only columns < n_valid are written (0 = all N)
     int dbg;                                    // timing-only ablations: bit0 skip epilogue stores, bit1 skip steady-state loads
     int planes;                                 // 1: bf16 ; 2: bf16 hi+lo split (3 MFMAs per product)
+    int fmt;                                    // planes == 1 only: 0 = bf16 operands, 1 = fp16 (FMT_FP16: A, W and the bf16_t outputs of
+                                                // GELU / QKV; EPI_QKV still writes V as bf16 -- the P.V product of the attention stays bf16)
     int epi;
     const float* bias;                          // [N] or null
     float* out_f32; int ldo_f32;                // PLAIN / RESID / PATCH
@@ -40,6 +42,8 @@ struct GemmParams {
     const float* resid;                         // RESID: out = resid + acc + bias (null: in place on out_f32)
     bf16_t* aux_out;                            // GELU: also save the pre-activation planes here (training), ld = ldo
     const bf16_t* aux_in; long aux_plane;       // DGELU / DRELU operand planes [planes][M][ldo]; also plane stride of aux_out
+    int dispatch_rows;                          // launch_gemm's kernel choice is made for this many rows instead of M when > 0: the two
+                                                // half-batches of a split forward take the route of the whole batch (same summation order)
     int ksplit;                                 // >1: split the K loop over grid.y (EPI_ATOMIC, or EPI_PLAIN partial tiles)
     long split_stride;                          // EPI_PLAIN with ksplit > 1: slice y writes out_f32 + y * split_stride (floats)
 };
@@ -61,10 +65,11 @@ struct LnGemmParams {
     bf16_t* a_out; long a_plane;                // optional: the normalised planes [planes][M][K] (training: weight gradients)
     bf16_t* aux_out; long aux_plane;            // optional (GELU): pre-activation planes [planes][M][ldo] (training: gelu')
     int dbg;                                    // timing-only ablations (wrong results): 1 skip epilogue, 2 skip W DMA, 4 skip LN prologue
+    int fmt;                                    // planes == 1 only: operand format (FMT_BF16 / FMT_FP16), as GemmParams::fmt
 };
 bool gemm_ln_supported(int K, int N, int planes, int epi, int dmodel);
 long gemm_ln_slab_elems(int N, int K, int planes);      // bf16 elements of the slab-major copy of W [N][K]
-int launch_pack_slabs(const float* src, int N, int K, int planes, bf16_t* dst, hipStream_t s);
+int launch_pack_slabs(const float* src, int N, int K, int planes, bf16_t* dst, hipStream_t s, int fmt = 0);
 int launch_gemm_ln(const LnGemmParams& p, int K, int planes, hipStream_t s);
 
 // Fused MLP of one transformer block, bf16 mode, D = 384 (mlp_fused.hip): X += fc2(gelu(fc1(LayerNorm(X))))   in place
@@ -85,14 +90,16 @@ struct MlpFusedParams {
     const float* bqkv; const float* gamma1; const float* beta1;
     bf16_t* q; bf16_t* k; bf16_t* v;            // each [B, heads, npad, 64] bf16 (rows >= ntok are never written)
     int ntok, npad, heads; float qscale;
+    int fmt;                                    // mlp_fused2 only: operand format of ctx, the packed weights and everything in between
+                                                // (FMT_BF16 / FMT_FP16); the qkv tail writes V as bf16 either way
 };
 long mlp_fused_qkv_pack_elems(int D);           // bf16 elements of the packed qkv weight (0: unsupported width)
-int launch_pack_qkv(const float* W, int D, bf16_t* dst, hipStream_t s);
+int launch_pack_qkv(const float* W, int D, bf16_t* dst, hipStream_t s, int fmt = 0);
 long mlp_fused_proj_pack_elems(int D);          // bf16 elements of the packed projection weight (0: unsupported width)
-int launch_pack_proj(const float* W, int D, bf16_t* dst, hipStream_t s);
+int launch_pack_proj(const float* W, int D, bf16_t* dst, hipStream_t s, int fmt = 0);
 bool mlp_fused_supported(int D, int F, int planes);
 long mlp_fused_pack_elems(int D, int F);        // bf16 elements of the packed copy (0: unsupported shape)
-int launch_pack_mlp(const float* W1, const float* W2, int D, int F, bf16_t* dst, hipStream_t s);
+int launch_pack_mlp(const float* W1, const float* W2, int D, int F, bf16_t* dst, hipStream_t s, int fmt = 0);
 int launch_mlp_fused(const MlpFusedParams& p, hipStream_t s);      // one wave per SIMD (mlp_fused.hip)
 int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s);     // role-split wave pairs, two waves per SIMD (mlp_fused2.hip)
 
@@ -112,6 +119,8 @@ struct Options {
     int mlp_variant = 2;     // 1: mlp_fused.hip (one wave per SIMD), 2: mlp_fused2.hip (role-split wave pairs)
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 8;       // (8 frames @480: +6 %, 12: +16 %, 16: +12 %; 6 frames and fewer: slower split)
+    int op_fmt = 0;          // operand format (FMT_BF16 / FMT_FP16) of the single-plane stand-alone ops (dinoseg_op_*: tests, tools); a
+                             // handle's forward follows its own precision instead
     int train_streams = 2;   // 2: backward runs the weight-gradient GEMMs of the blocks on the handle's side stream (train_api.hip)
     int splitk_tiles = 512;  // weight-gradient GEMMs: partial 128x128 tiles per launch (<= 768, the workspace holds that many)
     int attn_variant = 11;   // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
@@ -128,6 +137,8 @@ struct AttnParams {
     int B, heads, ntok, npad, planes;
     int dbg;                           // timing-only ablations: bit0 skip max/exp, bit1 skip steady-state loads, bit2 skip PV
     int shared_gpu;                    // hint: another stream's kernels run beside this launch (the split forward): prefer wide workgroups
+    int fmt;                           // planes == 1 only: FMT_FP16 = Q, K and ctx are fp16 (V and the probabilities stay bf16: 2^S against the
+                                       // fixed reference 0 needs bf16's exponent range); attention_z.hip only
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
 int launch_attention_z(const AttnParams& p, hipStream_t s);    // zero-reference softmax, <= 128 registers: 4 waves per SIMD (attention_z.hip)
@@ -135,12 +146,12 @@ int launch_attention_pipe(const AttnParams& p, hipStream_t s); // bf16 only: sof
 
 // fp32 [rows, cols] -> bf16 planes [planes][rows_pad][cols_pad], zero padded
 int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,
-                       int planes, hipStream_t s);
+                       int planes, hipStream_t s, int fmt = 0);
 
 // LayerNorm over the last dim (D % 128 == 0, D <= 1024). rows of x: [M, D] fp32.
 // drop_cls != 0: input row m = b*ntok + t is skipped for t == 0 and written to output row b*(ntok-1) + t-1.
 int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, int M, int D,
-                     bf16_t* out, long out_plane, int planes, float* out_f32, int drop_cls, int ntok, hipStream_t s);
+                     bf16_t* out, long out_plane, int planes, float* out_f32, int drop_cls, int ntok, hipStream_t s, int fmt = 0);
 
 // Patch gather ("im2col") for the 8x8/stride-8 patch embedding. k index = c*64 + ky*8 + kx.
 // kind 0: uint8 HWC frames [B,r,r,3] with the ImageNet normalisation fused; kind 1: fp32 CHW [B,3,r,r] as is.
@@ -159,10 +170,10 @@ int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, con
 
 // materialised softmax(q k^T) of one block, fp32 [B,H,ntok,ntok] (get_last_selfattention; visualisation only)
 int launch_attn_probs(const bf16_t* q, const bf16_t* k, long plane, int planes, int B, int heads, int ntok, int npad, float* out,
-                      hipStream_t s);
+                      hipStream_t s, int fmt = 0);
 // cm[gt][pred] += 1 over n patches (int64 [C,C], accumulates)
 int launch_cls_mask_attn(const bf16_t* q, const bf16_t* k, const bf16_t* v, long plane, int planes, int heads, int ntok, int npad,
-                         const float* mask, int n_masks, bf16_t* ctx, long ctx_plane, float* probs, hipStream_t s);
+                         const float* mask, int n_masks, bf16_t* ctx, long ctx_plane, float* probs, hipStream_t s, int fmt = 0);
 int launch_broadcast_row0(float* X, int D, int n, hipStream_t s);
 int launch_resize_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, hipStream_t s);
 int launch_confusion(const int32_t* pred, const int64_t* gt, long n, int C, int64_t* cm, hipStream_t s);
@@ -211,6 +222,7 @@ int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, 
 struct PackJob {
     const float* src; bf16_t* dst; long plane;
     int rows, cols, rows_pad, cols_pad, planes, transposed;
+    int fmt = 0;                    // planes == 1 only: FMT_BF16 / FMT_FP16
 };
 int launch_multi_pack(const PackJob* jobs, int count, hipStream_t s);
 // fp32 [rows, cols] -> TRANSPOSED bf16 planes [planes][cols_pad][rows_pad] (zero padded): W^T operands for dgrad

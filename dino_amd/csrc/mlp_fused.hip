@@ -54,7 +54,7 @@ static_assert(PIECES == 12, "three groups of four pieces");
 #endif                // 16 no fragment reads, 32 no prologue loads / epilogue stores, 64 no epilogue stores, 128 no prologue loads
 
 __global__ __launch_bounds__(256) void pack_mlp_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
-                                                       bf16_t* __restrict__ dst, long total) {
+                                                       bf16_t* __restrict__ dst, long total, int fmt) {
     using namespace mf;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         long t = idx;
@@ -70,19 +70,19 @@ __global__ __launch_bounds__(256) void pack_mlp_kernel(const float* __restrict__
             const int f2 = frag - NKS, db = f2 >> 1, s2 = f2 & 1;
             v = W2[(long)(db * 32 + i) * F + tile * HT + s2 * 16 + h * 8 + e];
         }
-        dst[idx] = (bf16_t)(pack_bf16x2(v, 0.f) & 0xFFFF);
+        dst[idx] = pack1(v, fmt);
     }
 }
 
 long mlp_fused_pack_elems(int Dm, int Fh) { return Dm == mf::D && Fh == mf::F ? (long)mf::NT * mf::TILE_BYTES / 2 : 0; }
 
-int launch_pack_mlp(const float* W1, const float* W2, int Dm, int Fh, bf16_t* dst, hipStream_t s) {
+int launch_pack_mlp(const float* W1, const float* W2, int Dm, int Fh, bf16_t* dst, hipStream_t s, int fmt) {
     const long total = mlp_fused_pack_elems(Dm, Fh);
     if (total <= 0) {
         dinoseg_set_error("pack_mlp: unsupported shape D=%d F=%d", Dm, Fh);
         return -1;
     }
-    hipLaunchKernelGGL(pack_mlp_kernel, dim3(2048), dim3(256), 0, s, W1, W2, dst, total);
+    hipLaunchKernelGGL(pack_mlp_kernel, dim3(2048), dim3(256), 0, s, W1, W2, dst, total, fmt);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -69,6 +69,21 @@ constexpr int RA = MF2_RA, NFR = RA + 1;            // fragment read-ahead (gaps
                        // 32 no row loads / stores, 64 no LDS-DMA in the qkv tail, 128 no MFMAs in the qkv tail
 #endif
 
+#ifndef MF2_NT
+#define MF2_NT 0       // experiment: 1 = the residual rows are loaded, 2 = stored with the non-temporal hint (streamed once: keep the packed
+                       // weights, which every item re-streams, in the XCD's L2 instead)
+#endif
+template <class T>
+__device__ __forceinline__ T mf2_ld(const T* p) {
+    if (MF2_NT & 1) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <class T>
+__device__ __forceinline__ void mf2_st(T* p, const T& v) {
+    if (MF2_NT & 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 #ifndef MF2_STAMP
 #define MF2_STAMP 0      // diagnostic build only: lane 0 of waves 0 (A) and 4 (B) stamps s_memrealtime / s_memtime into p.queue
 #endif
@@ -87,7 +102,7 @@ constexpr int RA = MF2_RA, NFR = RA + 1;            // fragment read-ahead (gaps
 // One projection k-tile for one wave: acc^T[384][32] += Wproj(kt) . ctx(kt)^T -- the 24 MFMA gaps of an fc2 step, the weight
 // fragments from a_w (W1-ring slot), the two ctx fragments from ap0 / ap1; piece(j), j = 0..11, is called in every other gap
 // (wave B issues its LDS-DMA pieces there, wave A nothing).
-template <class PieceFn>
+template <int FMT, class PieceFn>
 __device__ __forceinline__ void mf2_proj_tile(f32x16 (&acc)[mfc::NDB], uint32_t a_w, uint32_t ap0, uint32_t ap1, PieceFn&& piece) {
     using namespace mf2;
     bf16x8 p0, p1, fr[NFR];
@@ -103,14 +118,14 @@ __device__ __forceinline__ void mf2_proj_tile(f32x16 (&acc)[mfc::NDB], uint32_t 
         constexpr int G = decltype(g_tag)::value;
         if constexpr (G + RA < 24) issue_read(std::integral_constant<int, G + RA>{});
         mf_wait<(23 - G < RA ? 23 - G : RA)>();
-        acc[G % 12] = mfma32(fr[G % NFR], G < 12 ? p0 : p1, acc[G % 12]);
+        acc[G % 12] = mfma32f<FMT>(fr[G % NFR], G < 12 ? p0 : p1, acc[G % 12]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr ((G & 1) == 0) piece(std::integral_constant<int, G / 2>{});
         __builtin_amdgcn_sched_barrier(0);
     });
 }
 
-template <bool PROJ, bool QKV>
+template <bool PROJ, bool QKV, int FMT>
 __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedParams p) {
     static_assert(PROJ || !QKV, "the qkv tail needs the hand-off machinery of the projection build");
     using namespace mf2;
@@ -224,8 +239,8 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                 for (int k = 0; k < NKS; ++k) {
                     f32x4 a = {1.f, 2.f, 3.f, (float)k}, b = a;
                     if (!(MF2_ABL & 32)) {
-                        a = *reinterpret_cast<const f32x4*>(xr + k * 16);
-                        b = *reinterpret_cast<const f32x4*>(xr + k * 16 + 4);
+                        a = mf2_ld(reinterpret_cast<const f32x4*>(xr + k * 16));
+                        b = mf2_ld(reinterpret_cast<const f32x4*>(xr + k * 16 + 4));
                     }
                     const f32x4 c0 = *reinterpret_cast<const f32x4*>(sB2 + k * 16 + lh_i * 8);
                     const f32x4 c1 = *reinterpret_cast<const f32x4*>(sB2 + k * 16 + lh_i * 8 + 4);
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
             };
             auto load_rows_k = [&](const float* xr, auto k_tag) __attribute__((always_inline)) {
                 constexpr int k = decltype(k_tag)::value;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k * 16), b = *reinterpret_cast<const f32x4*>(xr + k * 16 + 4);
+                const f32x4 a = mf2_ld(reinterpret_cast<const f32x4*>(xr + k * 16)), b = mf2_ld(reinterpret_cast<const f32x4*>(xr + k * 16 + 4));
                 const f32x4 c0 = *reinterpret_cast<const f32x4*>(sB2 + k * 16 + lh_i * 8);
                 const f32x4 c1 = *reinterpret_cast<const f32x4*>(sB2 + k * 16 + lh_i * 8 + 4);
 #pragma unroll
@@ -325,7 +340,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                         if constexpr (G + RA < 24) issue_read(std::integral_constant<int, G + RA>{});
                         if (MF2_ABL & 16) fr[G % NFR] = p0;
                         else mf_wait<(23 - G < RA ? 23 - G : RA)>();
-                        if (!(MF2_ABL & 8)) o[G % 12] = mfma32(fr[G % NFR], G < 12 ? p0 : p1, o[G % 12]);
+                        if (!(MF2_ABL & 8)) o[G % 12] = mfma32f<FMT>(fr[G % NFR], G < 12 ? p0 : p1, o[G % 12]);
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr ((G & 1) == 0) piece(std::integral_constant<int, G / 2>{});
                         __builtin_amdgcn_sched_barrier(0);
@@ -388,10 +403,10 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                             y[4 + e] = (o[k >> 1][(k & 1) * 8 + 4 + e] - mean_n) * rstd * g1[e] + e1[e];
                         }
                         uint4 u;
-                        u.x = pack_bf16x2(y[0], y[1]);
-                        u.y = pack_bf16x2(y[2], y[3]);
-                        u.z = pack_bf16x2(y[4], y[5]);
-                        u.w = pack_bf16x2(y[6], y[7]);
+                        u.x = pack2<FMT>(y[0], y[1]);
+                        u.y = pack2<FMT>(y[2], y[3]);
+                        u.z = pack2<FMT>(y[4], y[5]);
+                        u.w = pack2<FMT>(y[6], y[7]);
                         *reinterpret_cast<uint4*>(hw + kk * 1024) = u;
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                         else if constexpr (J == 7) mf_dma1<0>(cv[1], cb, cl1);
                     };
                     const uint32_t cs = (uint32_t)(kt % 6) * CTX_SLOT;
-                    mf2_proj_tile(o, frag_rd_i + W1_OFF + (uint32_t)(kt % 3) * W_TILE, cp0 + cs, (cp0 ^ 32u) + cs, piece);
+                    mf2_proj_tile<FMT>(o, frag_rd_i + W1_OFF + (uint32_t)(kt % 3) * W_TILE, cp0 + cs, (cp0 ^ 32u) + cs, piece);
                     // k-tile kt + 1 (issued one step ago) has landed; the eight pieces of this step may stay in flight
                     if (issue) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -514,8 +529,8 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                                 a[e] = o[k >> 1][(k & 1) * 8 + e];
                                 b[e] = o[k >> 1][(k & 1) * 8 + 4 + e];
                             }
-                            *reinterpret_cast<f32x4*>(xrow + k * 16) = a;
-                            *reinterpret_cast<f32x4*>(xrow + k * 16 + 4) = b;
+                            mf2_st(reinterpret_cast<f32x4*>(xrow + k * 16), a);
+                            mf2_st(reinterpret_cast<f32x4*>(xrow + k * 16 + 4), b);
                         }
                     }
                     if constexpr (T > NKS) {      // the next item's rows: two k-steps per step
@@ -559,8 +574,8 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                         a += *reinterpret_cast<const f32x4*>(fp);
                         b += *reinterpret_cast<const f32x4*>(fp + 4);
                     }
-                    *reinterpret_cast<f32x4*>(xrow + k * 16) = a;
-                    *reinterpret_cast<f32x4*>(xrow + k * 16 + 4) = b;
+                    mf2_st(reinterpret_cast<f32x4*>(xrow + k * 16), a);
+                    mf2_st(reinterpret_cast<f32x4*>(xrow + k * 16 + 4), b);
                 }
             }
             if (wave == 4) MF2_ST(1, item_k, 7);
@@ -618,10 +633,10 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                 y[4 + e] = (x[2 * k + 1][e] - mean_n) * rstd * g1[e] + e1[e];
             }
             uint4 u;
-            u.x = pack_bf16x2(y[0], y[1]);
-            u.y = pack_bf16x2(y[2], y[3]);
-            u.z = pack_bf16x2(y[4], y[5]);
-            u.w = pack_bf16x2(y[6], y[7]);
+            u.x = pack2<FMT>(y[0], y[1]);
+            u.y = pack2<FMT>(y[2], y[3]);
+            u.z = pack2<FMT>(y[4], y[5]);
+            u.w = pack2<FMT>(y[6], y[7]);
             xn[k] = __builtin_bit_cast(bf16x8, u);
         }
     };
@@ -640,7 +655,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         }
         const char* w = smem + W1_OFF + lane_p * 16;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) s = mfma32(lds_frag(w + ks * 1024), xn[ks], s);
+        for (int ks = 0; ks < NKS; ++ks) s = mfma32f<FMT>(lds_frag(w + ks * 1024), xn[ks], s);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         return s;
     };
@@ -659,8 +674,8 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                 x[2 * k] = f32x4{1.f, 2.f, (float)k, (float)lane_p};
                 x[2 * k + 1] = x[2 * k];
             } else {
-                x[2 * k] = *reinterpret_cast<const f32x4*>(xrow + k * 16);
-                x[2 * k + 1] = *reinterpret_cast<const f32x4*>(xrow + k * 16 + 4);
+                x[2 * k] = mf2_ld(reinterpret_cast<const f32x4*>(xrow + k * 16));
+                x[2 * k + 1] = mf2_ld(reinterpret_cast<const f32x4*>(xrow + k * 16 + 4));
             }
         }
         layernorm(x, lh);
@@ -674,7 +689,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         constexpr int N = decltype(n_tag)::value, I = decltype(i_tag)::value;
         if constexpr (I == 0) ex[N] = s[N];
         if (MF2_ABL & 1) {
-            if constexpr (I == 10 && (N & 1)) pd[N >> 1] = pack_bf16x2(ex[N - 1], ex[N]);
+            if constexpr (I == 10 && (N & 1)) pd[N >> 1] = pack2<FMT>(ex[N - 1], ex[N]);
             return;
         }
         if constexpr (I == 1) ea[N] = __builtin_amdgcn_fmed3f(ex[N], -8.0f, 8.0f);
@@ -686,7 +701,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         if constexpr (I == 7) ec[N] = 1.0f + ec[N];
         if constexpr (I == 8) ec[N] = __builtin_amdgcn_rcpf(ec[N]);
         if constexpr (I == 9) ex[N] = ex[N] * ec[N];
-        if constexpr (I == 10 && (N & 1)) pd[N >> 1] = pack_bf16x2(ex[N - 1], ex[N]);
+        if constexpr (I == 10 && (N & 1)) pd[N >> 1] = pack2<FMT>(ex[N - 1], ex[N]);
     };
     auto valu_slot = [&](auto g_tag, const f32x16& s) __attribute__((always_inline)) {
         constexpr int G = decltype(g_tag)::value;
@@ -709,7 +724,8 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         const uint32_t frag_rd_i = lds_base + lane16_i;
         char* const p_wr = smem + P_OFF + pair * 4096 + lane16_i;
         const float* const b1_lane_p = sB1 + attn::sigma23((int)(lane_i & 31));     // + HT * tile: b1 of MFMA A row lr
-        const uint4 ones_u = {lh_i == 0 ? 0x3F803F80u : 0u, lh_i == 0 ? 0x00003F80u : 0u, 0u, 0u};     // k = 0, 1, 2 are 1.0
+        constexpr uint32_t ONE = FMT == FMT_FP16 ? 0x3C00u : 0x3F80u;
+        const uint4 ones_u = {lh_i == 0 ? (ONE << 16 | ONE) : 0u, lh_i == 0 ? ONE : 0u, 0u, 0u};     // k = 0, 1, 2 are 1.0
         // normalised rows from wave B: three rounds of eight fragments through the pair's window (5 barriers)
         auto receive_xn = [&]() __attribute__((always_inline)) {
             const char* const hr = smem + H_OFF + pair * 8192 + lane16_i;
@@ -737,10 +753,10 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
             bf16x8 bias_frag;
             if (!LAST) {      // b1 of tile s+1 as an A fragment (hi + mid + lo = the fp32 value exactly) times a ones fragment
                 const float bj = b1_lane_p[(s + 1) * HT];
-                const uint32_t hi = pack_bf16x2(bj, 0.f);
-                const float r1f = bj - bf16_lo_to_f32(hi);
-                const uint32_t mid = pack_bf16x2(r1f, 0.f);
-                const uint32_t lo = pack_bf16x2(r1f - bf16_lo_to_f32(mid), 0.f);
+                const uint32_t hi = pack2<FMT>(bj, 0.f);
+                const float r1f = bj - lo_to_f32<FMT>(hi);
+                const uint32_t mid = pack2<FMT>(r1f, 0.f);
+                const uint32_t lo = pack2<FMT>(r1f - lo_to_f32<FMT>(mid), 0.f);
                 const uint4 fu = {lh_i == 0 ? ((hi & 0xFFFFu) | (mid << 16)) : 0u, lh_i == 0 ? (lo & 0xFFFFu) : 0u, 0u, 0u};
                 bias_frag = __builtin_bit_cast(bf16x8, fu);
             }
@@ -759,7 +775,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                     f32x16 z;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                    s_nxt = mfma32(bias_frag, __builtin_bit_cast(bf16x8, ones_u), z);
+                    s_nxt = mfma32f<FMT>(bias_frag, __builtin_bit_cast(bf16x8, ones_u), z);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 mf_for(std::make_integer_sequence<int, 24>{}, [&](auto g_tag) __attribute__((always_inline)) {
@@ -767,7 +783,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                     if constexpr (G + RA < 24) issue_read(std::integral_constant<int, G + RA>{});
                     if (MF2_ABL & 16) fr[G % NFR] = xn[(G + 1) % NKS];
                     else mf_wait<(23 - G < RA ? 23 - G : RA)>();
-                    if (!(MF2_ABL & 4)) s_nxt = mfma32(fr[G % NFR], xn[G], s_nxt);
+                    if (!(MF2_ABL & 4)) s_nxt = mfma32f<FMT>(fr[G % NFR], xn[G], s_nxt);
                     __builtin_amdgcn_sched_barrier(0);
                     valu_slot(g_tag, s_cur);
                     __builtin_amdgcn_sched_barrier(0);
@@ -811,10 +827,10 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                 bf16x8 bias_frag;
                 if (!LAST) {
                     const float bj = bq_lane_p[(t + 1) * 32];
-                    const uint32_t hi = pack_bf16x2(bj, 0.f);
-                    const float r1f = bj - bf16_lo_to_f32(hi);
-                    const uint32_t mid = pack_bf16x2(r1f, 0.f);
-                    const uint32_t lo = pack_bf16x2(r1f - bf16_lo_to_f32(mid), 0.f);
+                    const uint32_t hi = pack2<FMT>(bj, 0.f);
+                    const float r1f = bj - lo_to_f32<FMT>(hi);
+                    const uint32_t mid = pack2<FMT>(r1f, 0.f);
+                    const uint32_t lo = pack2<FMT>(r1f - lo_to_f32<FMT>(mid), 0.f);
                     const uint4 fu = {lh_i == 0 ? ((hi & 0xFFFFu) | (mid << 16)) : 0u, lh_i == 0 ? (lo & 0xFFFFu) : 0u, 0u, 0u};
                     bias_frag = __builtin_bit_cast(bf16x8, fu);
                 }
@@ -833,7 +849,10 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                 auto q_slot = [&](auto g_tag) __attribute__((always_inline)) {
                     constexpr int G = decltype(g_tag)::value;
                     if constexpr (G < 16) ex[G] = s_cur[G] * sc;
-                    else if constexpr (G < 24) pd[G - 16] = pack_bf16x2(ex[2 * (G - 16)], ex[2 * (G - 16) + 1]);
+                    else if constexpr (G < 24) {      // (V stays bf16 in the fp16 mode: kernels.h, AttnParams::fmt; t is wave-uniform)
+                        if (FMT == FMT_BF16 || t >= 2 * NDB) pd[G - 16] = pack_bf16x2(ex[2 * (G - 16)], ex[2 * (G - 16) + 1]);
+                        else pd[G - 16] = pack2<FMT>(ex[2 * (G - 16)], ex[2 * (G - 16) + 1]);
+                    }
                 };
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -849,14 +868,14 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                         f32x16 z;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                        s_nxt = mfma32(bias_frag, __builtin_bit_cast(bf16x8, ones_u), z);
+                        s_nxt = mfma32f<FMT>(bias_frag, __builtin_bit_cast(bf16x8, ones_u), z);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     mf_for(std::make_integer_sequence<int, 24>{}, [&](auto g_tag) __attribute__((always_inline)) {
                         constexpr int G = decltype(g_tag)::value;
                         if constexpr (G + RA < 24) issue_read(std::integral_constant<int, G + RA>{});
                         mf_wait<(23 - G < RA ? 23 - G : RA)>();
-                        if (!(MF2_ABL & 128)) s_nxt = mfma32(fr[G % NFR], xn[G], s_nxt);
+                        if (!(MF2_ABL & 128)) s_nxt = mfma32f<FMT>(fr[G % NFR], xn[G], s_nxt);
                         __builtin_amdgcn_sched_barrier(0);
                         q_slot(g_tag);
                         if constexpr ((G & 1) == 0 && G < 12) piece(std::integral_constant<int, G / 2>{});
@@ -890,7 +909,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
 
 // Wproj [384 out][384 in] fp32 -> bf16 fragments [k-tile kt][fragment db * 2 + s2][lane][8]: the fc2 fragment format of pack_mlp with
 // the 32 input features of k-tile kt in the place of a hidden tile (A row = output feature 32 db + sigma23(lane & 31))
-__global__ __launch_bounds__(256) void pack_proj_kernel(const float* __restrict__ W, bf16_t* __restrict__ dst) {
+__global__ __launch_bounds__(256) void pack_proj_kernel(const float* __restrict__ W, bf16_t* __restrict__ dst, int fmt) {
     using namespace mf2;
     const int total = NPT * NKS * 512;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -899,11 +918,11 @@ __global__ __launch_bounds__(256) void pack_proj_kernel(const float* __restrict_
         const int lane = t & 63; t >>= 6;
         const int frag = t % NKS, kt = t / NKS;
         const int i = attn::sigma23(lane & 31), h = lane >> 5, db = frag >> 1, s2 = frag & 1;
-        dst[idx] = (bf16_t)(pack_bf16x2(W[(long)(db * 32 + i) * D + kt * 32 + s2 * 16 + h * 8 + e], 0.f) & 0xFFFF);
+        dst[idx] = pack1(W[(long)(db * 32 + i) * D + kt * 32 + s2 * 16 + h * 8 + e], fmt);
     }
 }
 // Wqkv [1152 out][384 in] fp32 -> bf16 fragments [tile of 32 outputs][k-step][lane][8]: the fc1 fragment format of pack_mlp
-__global__ __launch_bounds__(256) void pack_qkv_kernel(const float* __restrict__ W, bf16_t* __restrict__ dst) {
+__global__ __launch_bounds__(256) void pack_qkv_kernel(const float* __restrict__ W, bf16_t* __restrict__ dst, int fmt) {
     using namespace mf2;
     const int total = NQT * NKS * 512;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -912,39 +931,47 @@ __global__ __launch_bounds__(256) void pack_qkv_kernel(const float* __restrict__
         const int lane = t & 63; t >>= 6;
         const int frag = t % NKS, tile = t / NKS;
         const int i = attn::sigma23(lane & 31), h = lane >> 5;
-        dst[idx] = (bf16_t)(pack_bf16x2(W[(long)(tile * 32 + i) * D + frag * 16 + h * 8 + e], 0.f) & 0xFFFF);
+        dst[idx] = pack1(W[(long)(tile * 32 + i) * D + frag * 16 + h * 8 + e], fmt);
     }
 }
 long mlp_fused_qkv_pack_elems(int Dm) { return Dm == mf2::D ? (long)mf2::NQT * mf2::W_TILE / 2 : 0; }
-int launch_pack_qkv(const float* W, int Dm, bf16_t* dst, hipStream_t s) {
+int launch_pack_qkv(const float* W, int Dm, bf16_t* dst, hipStream_t s, int fmt) {
     if (Dm != mf2::D) {
         dinoseg_set_error("pack_qkv: unsupported width %d", Dm);
         return -1;
     }
-    hipLaunchKernelGGL(pack_qkv_kernel, dim3(432), dim3(256), 0, s, W, dst);
+    hipLaunchKernelGGL(pack_qkv_kernel, dim3(432), dim3(256), 0, s, W, dst, fmt);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 long mlp_fused_proj_pack_elems(int Dm) { return Dm == mf2::D ? (long)mf2::NPT * mf2::W_TILE / 2 : 0; }
-int launch_pack_proj(const float* W, int Dm, bf16_t* dst, hipStream_t s) {
+int launch_pack_proj(const float* W, int Dm, bf16_t* dst, hipStream_t s, int fmt) {
     if (Dm != mf2::D) {
         dinoseg_set_error("pack_proj: unsupported width %d", Dm);
         return -1;
     }
-    hipLaunchKernelGGL(pack_proj_kernel, dim3(144), dim3(256), 0, s, W, dst);
+    hipLaunchKernelGGL(pack_proj_kernel, dim3(144), dim3(256), 0, s, W, dst, fmt);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
+template <int FMT>
+static int launch_mlp_fused2_fmt(const MlpFusedParams& p, hipStream_t s);
+
 int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s) {
+    return p.fmt == FMT_FP16 ? launch_mlp_fused2_fmt<FMT_FP16>(p, s) : launch_mlp_fused2_fmt<FMT_BF16>(p, s);
+}
+
+template <int FMT>
+static int launch_mlp_fused2_fmt(const MlpFusedParams& p, hipStream_t s) {
     static PerDeviceOnce once;
     if (once.first()) {
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<false, false>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<false, false, FMT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, mf2::LDS_BYTES));
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<true, false>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<true, false, FMT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, mf2::LDS_BYTES));
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<true, true>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused2_kernel<true, true, FMT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, mf2::LDS_BYTES));
         once.mark();
     }
@@ -988,16 +1015,16 @@ int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s) {
                 dinoseg_set_error("mlp_fused2: incomplete qkv tail (bias / norm1 / q / k / v / geometry)");
                 return -1;
             }
-            hipLaunchKernelGGL((mlp_fused2_kernel<true, true>), dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
+            hipLaunchKernelGGL((mlp_fused2_kernel<true, true, FMT>), dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
         } else {
-            hipLaunchKernelGGL((mlp_fused2_kernel<true, false>), dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
+            hipLaunchKernelGGL((mlp_fused2_kernel<true, false, FMT>), dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
         }
     } else {
         if (p.Wqkv) {
             dinoseg_set_error("mlp_fused2: the qkv tail needs the projection in the same launch (ctx)");
             return -1;
         }
-        hipLaunchKernelGGL((mlp_fused2_kernel<false, false>), dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
+        hipLaunchKernelGGL((mlp_fused2_kernel<false, false, FMT>), dim3(grid), dim3(mf2::THREADS), mf2::LDS_BYTES, s, q);
     }
     DSEG_CHECK_HIP(hipGetLastError());
 #if MF2_STAMP

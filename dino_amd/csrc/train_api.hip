@@ -232,6 +232,10 @@ static int train_forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, 
         dinoseg_set_error("dinoseg_train_forward: weights not packed (call dinoseg_refresh_weights after binding)");
         return -3;
     }
+    if (h->fmt != FMT_BF16) {
+        dinoseg_set_error("dinoseg_train_forward: precision fp16 is inference-only (fp16 gradients would need loss scaling); use bf16 or bf16x3");
+        return -1;
+    }
     h->tr_B = -1;       // no valid saved forward until this one has been enqueued completely
     DSEG_TRY(check_stream_device(h, s));
     DSEG_TRY(dinoseg_prepare_resolution(h, r, reinterpret_cast<void*>(s)));
@@ -754,7 +758,8 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
         DSEG_CHECK_HIP(hipMemcpyAsync(grad("dino.cls_token"), dpos, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
     // (scratch: the T2 transpose buffer, idle until the patch-embed gradient below; [pos_grid][r/8][D] floats fit its >= Mppad x 256 bf16)
     if (grad("dino.pos_embed")) {
-        if ((size_t)c.pos_grid * (r / 8) * D * sizeof(float) > (size_t)L.t_plane * P * sizeof(bf16_t)) {
+        // (T2 is allocated with two planes whatever the precision: make_train_layout)
+        if ((size_t)c.pos_grid * (r / 8) * D * sizeof(float) > (size_t)2 * L.t_plane * sizeof(bf16_t)) {
             dinoseg_set_error("dinoseg_backward: pos-embed scratch does not fit (pos_grid %d, grid %d)", c.pos_grid, r / 8);
             return -1;
         }
@@ -775,9 +780,21 @@ extern "C" int dinoseg_train_forward(dinoseg_handle* h, const void* x, int32_t x
     return train_forward_impl(h, x, x_kind, B, r, logp_out, reinterpret_cast<hipStream_t>(stream));
 }
 
+// The backward forks weight-gradient kernels onto the handle's side stream (option train_streams = 2) and joins them before it
+// returns.  An error in between returns early: join here too, so that the caller's stream never runs ahead of side-stream kernels
+// that still read / write the gradient buffers, the split-K workspace or the activations (as dinoseg_forward does for its halves).
+static int backward_joined(dinoseg_handle* h, const int64_t* labels, const float* dlogp, float* loss_out, hipStream_t s) {
+    const int rc = train_backward_impl(h, labels, dlogp, loss_out, s);
+    if (rc != 0 && h && h->aux_stream && h->ev_join) {
+        (void)hipEventRecord(h->ev_join, h->aux_stream);
+        (void)hipStreamWaitEvent(s, h->ev_join, 0);
+    }
+    return rc;
+}
+
 extern "C" int dinoseg_backward(dinoseg_handle* h, const float* dlogp, void* stream) {
     DeviceGuard guard(h);
-    return train_backward_impl(h, nullptr, dlogp, nullptr, reinterpret_cast<hipStream_t>(stream));
+    return backward_joined(h, nullptr, dlogp, nullptr, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_kind, int32_t B, int32_t r,
@@ -789,7 +806,7 @@ extern "C" int dinoseg_train_step(dinoseg_handle* h, const void* x, int32_t x_ki
     DeviceGuard guard(h);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DSEG_TRY(train_forward_impl(h, x, x_kind, B, r, logp_out, s));
-    return train_backward_impl(h, labels, nullptr, loss_out, s);
+    return backward_joined(h, labels, nullptr, loss_out, s);
 }
 
 extern "C" int dinoseg_grad_stages(const dinoseg_handle* h) { return h ? h->cfg.n_blocks + 2 : -1; }

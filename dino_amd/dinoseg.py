@@ -22,7 +22,7 @@ from .weights import VIT_B8, VIT_S8, ViTConfig
 
 _IMAGENET_MEAN = (0.485, 0.456, 0.406)
 _IMAGENET_STD = (0.229, 0.224, 0.225)
-_PRECISIONS = {"bf16": capi.BF16, "bf16x3": capi.BF16X3}
+_PRECISIONS = {"bf16": capi.BF16, "bf16x3": capi.BF16X3, "fp16": capi.FP16}
 
 
 # --------------------------------------------------------------------------- preprocessing mirror

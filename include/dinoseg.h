@@ -28,8 +28,13 @@ typedef struct dinoseg_handle dinoseg_handle;
 /* Precision of the GEMM / attention operands (accumulation is always fp32):
  *   DINOSEG_BF16   : bf16 operands, 1 MFMA per product  (benchmark mode, BASELINE.json "bf16")
  *   DINOSEG_BF16X3 : bf16 hi+lo operand pairs, 3 MFMAs per product (~16 mantissa bits): the parity mode
- *                    that meets "argmax identical, |dlogp| <= 1e-3" against the fp32 reference. */
-enum { DINOSEG_BF16 = 0, DINOSEG_BF16X3 = 1 };
+ *                    that meets "argmax identical, |dlogp| <= 1e-3" against the fp32 reference.
+ *   DINOSEG_FP16   : fp16 operands (11 significand bits), 1 MFMA per product at the bf16 rate: the linears and Q.K^T on
+ *                    v_mfma_f32_32x32x16_f16; the probabilities and V (the P.V product) stay bf16 -- 2^S against the fixed
+ *                    reference 0 needs bf16's exponent range; the patch embedding and the head run split (bf16 hi+lo).
+ *                    ~6x closer to the reference than DINOSEG_BF16 at the same speed; inference only (the fine-tune
+ *                    entry points refuse it: fp16 gradients would need loss scaling). */
+enum { DINOSEG_BF16 = 0, DINOSEG_BF16X3 = 1, DINOSEG_FP16 = 2 };
 enum { DINOSEG_HEAD_LINEAR = 0, DINOSEG_HEAD_MLP = 1 };
 enum { DINOSEG_INPUT_U8_HWC = 0,      /* uint8 [B,r,r,3] frames; ImageNet normalisation fused on device   */
        DINOSEG_INPUT_F32_CHW = 1 };   /* fp32  [B,3,r,r] already-normalised tensor (DINOSeg.forward input) */
@@ -47,7 +52,7 @@ typedef struct dinoseg_config {
     int32_t head_kind;    /* DINOSEG_HEAD_*  (pl_torch_modules.py:219-222)                       */
     int32_t pos_grid;     /* 28: stored pos_embed is [1, 28*28+1, D]                             */
     float   ln_eps;       /* 1e-6 (vision_transformer.py:303)                                    */
-    int32_t precision;    /* DINOSEG_BF16 / DINOSEG_BF16X3                                       */
+    int32_t precision;    /* DINOSEG_BF16 / DINOSEG_BF16X3 / DINOSEG_FP16                        */
 } dinoseg_config;
 
 const char* dinoseg_last_error(void);
@@ -172,8 +177,11 @@ int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
 /* Process-wide switches.  Keys:
  *   "streams"    2 [default] / 1: with 2, dinoseg_forward runs a batch of >= "split_min" (default 8) frames as two half-batches,
  *                the first on the caller's stream, the second on an internal stream forked from / joined to it by events (the
- *                call stays stream-ordered and capturable; outputs identical; +6 to +9 % frames/s at B = 32 on MI355X: one
- *                half's attention fills the CUs the other half's GEMM tails and memory phases leave idle); 1 = one stream;
+ *                call stays stream-ordered and capturable; outputs bit-identical to the one-stream run in every precision -- each
+ *                half takes the kernel routes of the whole batch: tests/test_model_gpu.py::test_two_stream_split_equals_one_stream*;
+ *                +6 to +9 % frames/s at B = 32 on MI355X: one half's attention fills the CUs the other half's GEMM tails and
+ *                memory phases leave idle); 1 = one stream;
+ *   "op_fmt"     0 [default] / 1: operand format of the single-plane stand-alone ops (dinoseg_op_*: tests, tools): bf16 / fp16;
  *   "gemm_big"   1 [default] = the persistent 256x384 (bf16) / 128x384 (bf16x3) GEMM where it applies, 0 = always the 128x128
  *                kernel, 2 = wherever its shape rules allow;
  *   "gemm_ln"    1 [default] = qkv / fc1 through the LayerNorm-fused kernels where measured faster, 0 never, 2 wherever supported;

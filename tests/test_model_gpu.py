@@ -491,6 +491,27 @@ def test_two_stream_split_equals_one_stream_fused_routes(cuda):
         dino_amd.set_option("streams", 2)
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
+def test_two_stream_split_equals_one_stream_at_the_benchmark_batch(cuda, precision):
+    """32 frames @480 (the headline shape): a whole batch of 901 row panels takes the persistent GEMMs in the split mode where a
+    16-frame half on its own (451 panels) would take the 128x128 kernel -- another summation order (the r03 parity line
+    read outputs_identical_to_two_streams = false).  Every size-dependent kernel choice of a half-batch is now made for the rows of
+    the whole call (GemmParams::dispatch_rows, forward_impl's disp_M), so the split changes no bit in any precision."""
+    import dino_amd
+    m, _, _ = build(2, precision)
+    frames = torch.from_numpy(synthetic_frames(32, 480, seed=91)).cuda()
+    dino_amd.set_option("streams", 1)
+    try:
+        lp1, am1 = m.forward_frames(frames)
+        lp1, am1 = lp1.clone(), am1.clone()
+        dino_amd.set_option("streams", 2)
+        lp2, am2 = m.forward_frames(frames)
+        assert torch.isfinite(lp1).all()
+        assert torch.equal(lp2, lp1) and torch.equal(am2, am1)
+    finally:
+        dino_amd.set_option("streams", 2)
+
+
 def test_fused_routes_agree_on_random_shapes(cuda):
     """Sixteen random (resolution, batch) shapes -- 65 to 27 511 token rows: fewer rows than one 128-row item, items that straddle
     frames, ragged last items, more items than CUs -- through every route of a block's second half in bf16 mode: separate kernels,

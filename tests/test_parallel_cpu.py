@@ -190,6 +190,26 @@ def test_bench_self_launch_dry_run():
     assert r.returncode != 0
 
 
+def test_scale_script_dry_run(tmp_path):
+    """tools/scale.sh --dry-run: the one command that yields the 1 -> 8 GPU curve on an 8-GPU lease (headline replicas; the fine-tune
+    step with both collective forms), here with N = 1, 2 through the real launcher on gloo -- one tagged JSON line per run."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "scale.jsonl"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SCALE_GPUS"] = "1 2"
+    r = subprocess.run(["bash", os.path.join(root, "tools", "scale.sh"), "--dry-run", str(out)], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    rows = [json.loads(ln) for ln in open(out)]
+    assert [x["scale_label"] for x in rows] == ["headline N=1", "headline N=2", "finetune allreduce N=1", "finetune allreduce N=2",
+                                                "finetune rs_ag N=1", "finetune rs_ag N=2"]
+    for x in rows:
+        assert x["dry_run"] is True and x["ranks_seen"] == x["n_gpus"]
+    assert [x["config"]["collective"] for x in rows] == [None, None, "allreduce", "allreduce", "rs_ag", "rs_ag"]
+
+
 def test_finetuner_fixes_the_bucket_size_before_the_first_step():
     """with a non-default bucket_bytes the tuner must make the model build (and bind) buckets of THAT size before the
     first step, and refuse to reduce buckets the step did not write into."""
