@@ -69,8 +69,9 @@ int launch_pack_slabs12(const float* src, int N, int K, bf16_t* dst, hipStream_t
 }
 
 #ifndef LN12_NT
-#define LN12_NT 0           // experiment: 1 = the residual rows are loaded, 2 = the outputs stored with the non-temporal hint
-#endif
+#define LN12_NT 1           // 1 = the residual rows (read once per launch) are loaded with the non-temporal hint: the packed W, which every
+#endif                      // panel re-streams, keeps its place in the XCD's L2 (qkv 1.83 -> 1.76 ms per 32-frame step, two boxes); 2 = the
+                            // outputs stored non-temporal too: 2.9 ms (attention reads them next: they should stay in the Infinity Cache)
 #ifndef ALN_ABL
 #define ALN_ABL 0           // compile-time ablation bits for A/B builds (tools/build_variant.sh): 1 skip epilogue, 2 skip W DMA,
 #endif                      // 4 skip LayerNorm, 8 skip MFMAs, 32 skip fragment reads

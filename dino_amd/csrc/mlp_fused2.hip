@@ -70,8 +70,9 @@ constexpr int RA = MF2_RA, NFR = RA + 1;            // fragment read-ahead (gaps
 #endif
 
 #ifndef MF2_NT
-#define MF2_NT 0       // experiment: 1 = the residual rows are loaded, 2 = stored with the non-temporal hint (streamed once: keep the packed
-                       // weights, which every item re-streams, in the XCD's L2 instead)
+#define MF2_NT 0       // experiment (measured, off): 1 = the residual rows are loaded, 2 = stored with the non-temporal hint.  Both SLOWER here:
+                       // 4.38 -> 4.74 / 4.59 / 5.30 ms per 32-frame step for 1 / 2 / 3 (profiles/r04_nt_experiments.md) -- the rows this
+                       // launch stores are the rows the next launch (LayerNorm1 + qkv) loads: they should stay cached
 #endif
 template <class T>
 __device__ __forceinline__ T mf2_ld(const T* p) {
