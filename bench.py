@@ -36,8 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp16": 2500.0}   # dense bf16 / fp16 MFMA peak, MI355X_MICROARCH.md
-DTYPE = {"fp16": "fp16 (linears, Q.K^T; P.V bf16; fp32 accumulate)", "bf16": "bf16", "bf16x3": "bf16x3 (bf16 hi+lo split, fp32 acc)"}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp16": 2500.0, "fp16x3": 2500.0}   # dense bf16 / fp16 MFMA peak, MI355X_MICROARCH.md
+DTYPE = {"fp16": "fp16 (linears, Q.K^T; P.V bf16; fp32 accumulate)", "bf16": "bf16", "bf16x3": "bf16x3 (bf16 hi+lo split, fp32 acc)",
+         "fp16x3": "fp16x3 (fp16 hi+lo split, fp32 acc)"}
 
 
 def flops_per_frame(D, H, L, r, head="mlp", C=7):
@@ -206,7 +207,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--res", type=int, default=480)
     ap.add_argument("--arch", default="vit_small", choices=["vit_small", "vit_base"])
-    ap.add_argument("--precision", default=None, choices=["fp16", "bf16", "bf16x3"],
+    ap.add_argument("--precision", default=None, choices=["fp16", "bf16", "bf16x3", "fp16x3"],
                     help="default: fp16 for inference (see the module docstring), bf16 for --mode finetune (fp16 is inference-only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="(kept for compatibility: kernel_ms_per_step is always emitted)")
@@ -215,7 +216,7 @@ def parse_args(argv=None):
                     help="infer: the headline metric; finetune: BASELINE configs[3] (3-block unfrozen step, batch 8/GPU, "
                          "gradient all-reduce over RCCL, fused Adam)")
     ap.add_argument("--config", default=None, choices=["headline", "parity", "960", "vitb", "finetune"],
-                    help="BASELINE.json configs: headline = [1] ViT-S/8 @480 batch 32 bf16 (default); parity = the same in bf16x3; "
+                    help="BASELINE.json configs: headline = [1] ViT-S/8 @480 batch 32 (default); parity = the same in a hi+lo mode (fp16x3 unless --precision bf16x3); "
                          "960 = [2] @960 batch 8; vitb = [4] ViT-B/8 @480 batch 16/GPU; finetune = [3] 3-block step, batch 8/GPU")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 and bf16 sub-records of the headline line")
     ap.add_argument("--no-two-stream", action="store_true", help="skip the one-stream sub-record")
@@ -227,7 +228,7 @@ def parse_args(argv=None):
                     help="launcher / rendezvous check only: no model, no GPU (gloo); prints the JSON line with value 0")
     a = ap.parse_args(argv)
     if a.config == "parity":
-        a.precision = "bf16x3"
+        a.precision = a.precision or "fp16x3"
     elif a.config == "960":
         a.res, a.batch = 960, 8
     elif a.config == "vitb":
@@ -236,8 +237,8 @@ def parse_args(argv=None):
         a.mode = "finetune"
     if a.precision is None:
         a.precision = "bf16" if a.mode == "finetune" else "fp16"
-    if a.mode == "finetune" and a.precision == "fp16":
-        ap.error("--precision fp16 is inference-only (fp16 gradients would need loss scaling): use bf16 or bf16x3")
+    if a.mode == "finetune" and a.precision in ("fp16", "fp16x3"):
+        ap.error("the fp16 precisions are inference-only (fp16 gradients would need loss scaling): use bf16 or bf16x3")
     return a
 
 
@@ -451,7 +452,7 @@ def main():
                 and a.arch == "vit_small":
             traffic = tj["hbm_bytes_per_launch"]
             clock = tj.get("clock_ghz_under_load")
-        measured_peak = (tj.get("measured_mfma_peak_tflops") or {}).get("random_operands") if a.precision != "bf16x3" else None
+        measured_peak = (tj.get("measured_mfma_peak_tflops") or {}).get("random_operands") if a.precision in ("bf16", "fp16") else None
 
     if rank == 0:
         # the instantiation the one-stream roofline pass launches (attention_z.hip's rule: 256-query workgroups from one round of
@@ -461,8 +462,9 @@ def main():
         nw = 8 if wgs4 >= 4 * torch.cuda.get_device_properties(dev).multi_processor_count else 4
         attn_symbol = (f"dseg::attn_fwd_z_kernel<1, 4, {nw}, {1 if a.precision == 'fp16' else 0}> (attention_z.hip: fused QK^T-softmax-PV, "
                        f"head_dim 64, zero-reference softmax{'; fp16 Q.K^T, bf16 P.V' if a.precision == 'fp16' else ''})"
-                       if a.precision != "bf16x3" else
-                       "dseg::attn_fwd_kernel<2, 4, false, 3> (attention.hip: fused QK^T-softmax-PV, head_dim 64, hi+lo planes)")
+                       if a.precision in ("bf16", "fp16") else
+                       f"dseg::attn_fwd_kernel<2, 4, false, 3, {1 if a.precision == 'fp16x3' else 0}> (attention.hip: fused QK^T-softmax-PV, "
+                       f"head_dim 64, hi+lo planes)")
         out = {
             "metric": "frames/sec (480x480, ViT-S/8) DINOSeg inference",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -497,7 +499,7 @@ def main():
                          "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/attention_traffic.json)",
                          "algorithmic_bytes_per_launch": 4 * a.batch * cfg.num_heads * ((a.res // 8) ** 2 + 1) * 64 * 2
-                         * (2 if a.precision == "bf16x3" else 1),
+                         * (2 if a.precision in ("bf16x3", "fp16x3") else 1),
                          "launches_timed": att_n, "avg_launch_ms": round(att_avg_ms, 4),
                          "gflop_per_launch": round(att_flops / 1e9, 1)},
             # every kernel class of one forward, same untimed one-stream pass (fc1_gemm holds the fused MLP launch when it applies)
@@ -527,12 +529,15 @@ def main():
                    "parity": golden_check(pm, a.arch, a.blocks, a.res, a.batch)}
             del pm
             return rec, pfps
-        if a.precision != "bf16x3" and not a.no_parity_mode:
-            # north_star's bar (argmax identical, |dlogp| <= 1e-3) is met by the bf16x3 mode: same config, own timing
-            rec, pfps = sub_mode("bf16x3")
-            rec["precision"] = "bf16x3 (bf16 hi+lo operand planes, 3 MFMAs per product, fp32 accumulate)"
-            rec["mfma_issue_frac"] = round(3 * pfps * fl["total"] / 1e12 / peak, 4)
-            out["parity_mode"] = rec
+        if a.precision in ("bf16", "fp16") and not a.no_parity_mode:
+            # north_star's bar (argmax identical, |dlogp| <= 1e-3) is met by the hi+lo modes: same config, own timing.  fp16x3 =
+            # fp16 hi+lo planes (~22 bits, round 4): the parity mode with margin; bf16x3 = rounds 1-3's (~16 bits)
+            for key, prec, text in (("parity_mode", "fp16x3", "fp16x3 (fp16 hi+lo operand planes, 3 MFMAs per product, fp32 accumulate)"),
+                                    ("parity_mode_bf16x3", "bf16x3", "bf16x3 (bf16 hi+lo operand planes, 3 MFMAs per product, fp32 accumulate)")):
+                rec, pfps = sub_mode(prec)
+                rec["precision"] = text
+                rec["mfma_issue_frac"] = round(3 * pfps * fl["total"] / 1e12 / peak, 4)
+                out[key] = rec
         if a.precision == "fp16" and not a.no_parity_mode:
             # BASELINE.json names bf16: the all-bf16 mode's own numbers next to the fp16-operand headline (same kernels, same rate)
             out["bf16_mode"] = sub_mode("bf16")[0]

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdinoseg_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dinoseg.h")
 
-BF16, BF16X3, FP16 = 0, 1, 2
+BF16, BF16X3, FP16, FP16X3 = 0, 1, 2, 3
 HEAD_LINEAR, HEAD_MLP = 0, 1
 INPUT_U8_HWC, INPUT_F32_CHW = 0, 1
 EPI_PLAIN, EPI_RESID, EPI_GELU, EPI_RELU = 0, 1, 2, 3
@@ -51,6 +51,7 @@ SIGNATURES = {
     "dinoseg_prepare_resolution": (C.c_int, [_vp, _i32, _vp]),
     "dinoseg_forward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _fp, _i32, _fp, _vp]),
     "dinoseg_workspace_bytes": (_i64, [_vp, _i32, _i32]),
+    "dinoseg_state_generation": (_i64, [_vp]),
     "dinoseg_last_selfattention": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _vp]),
     "dinoseg_op_confusion": (C.c_int, [_fp, _fp, _i64, _i32, _fp, _vp]),
     "dinoseg_forward_mask": (C.c_int, [_vp, _vp, _i32, _i32, _fp, _i32, _fp, _fp, _vp]),

@@ -90,7 +90,8 @@ extern "C" int dinoseg_create(const dinoseg_config* cfg, dinoseg_handle** out) {
     }
     if (cfg->embed_dim % 128 != 0 || cfg->embed_dim > 1024 || cfg->num_heads * 64 != cfg->embed_dim || cfg->patch != 8 ||
         cfg->n_blocks < 0 || cfg->n_classes < 1 || cfg->n_classes > 32 || cfg->mlp_ratio < 1 || cfg->pos_grid < 1 ||
-        (cfg->precision != DINOSEG_BF16 && cfg->precision != DINOSEG_BF16X3 && cfg->precision != DINOSEG_FP16) ||
+        (cfg->precision != DINOSEG_BF16 && cfg->precision != DINOSEG_BF16X3 && cfg->precision != DINOSEG_FP16 &&
+         cfg->precision != DINOSEG_FP16X3) ||
         (cfg->head_kind != DINOSEG_HEAD_MLP && cfg->head_kind != DINOSEG_HEAD_LINEAR)) {
         dinoseg_set_error("dinoseg_create: unsupported config (embed_dim=%d heads=%d patch=%d blocks=%d classes=%d)",
                           cfg->embed_dim, cfg->num_heads, cfg->patch, cfg->n_blocks, cfg->n_classes);
@@ -98,8 +99,8 @@ extern "C" int dinoseg_create(const dinoseg_config* cfg, dinoseg_handle** out) {
     }
     dinoseg_handle* h = new dinoseg_handle();
     h->cfg = *cfg;
-    h->planes = cfg->precision == DINOSEG_BF16X3 ? 2 : 1;
-    h->fmt = cfg->precision == DINOSEG_FP16 ? FMT_FP16 : FMT_BF16;
+    h->planes = (cfg->precision == DINOSEG_BF16X3 || cfg->precision == DINOSEG_FP16X3) ? 2 : 1;
+    h->fmt = (cfg->precision == DINOSEG_FP16 || cfg->precision == DINOSEG_FP16X3) ? FMT_FP16 : FMT_BF16;
     add_expected(h);
     *out = h;
     return 0;
@@ -225,7 +226,7 @@ static std::vector<LinSpec> linear_specs(const dinoseg_handle* h) {
     const int D = c.embed_dim, F = c.embed_dim * c.mlp_ratio, P = h->planes, FM = h->fmt;
     std::vector<LinSpec> v;
     // (fp16 mode: the patch embedding runs split like the head -- 0.13 % of the FLOPs, and its operands are raw pixels)
-    v.push_back({"dino.patch_embed.proj.weight", "dino.patch_embed.proj.bias", D, 3 * c.patch * c.patch, D, 192, patch_planes(h), FMT_BF16});
+    v.push_back({"dino.patch_embed.proj.weight", "dino.patch_embed.proj.bias", D, 3 * c.patch * c.patch, D, 192, patch_planes(h), split_fmt(h)});
     bool qkv_ready = false;      // Q / K / V of block i were written by block i-1's fused launch (mlp_fused2.hip, QKV tail)
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
@@ -235,8 +236,8 @@ static std::vector<LinSpec> linear_specs(const dinoseg_handle* h) {
         v.push_back({b + "mlp.fc2.weight", b + "mlp.fc2.bias", D, F, D, F, P, FM});
     }
     if (c.head_kind == DINOSEG_HEAD_MLP) {
-        v.push_back({"clf.layer_1.weight", "clf.layer_1.bias", 200, D, 256, D, head_planes(), FMT_BF16});
-        v.push_back({"clf.layer_2.weight", "clf.layer_2.bias", 100, 200, 128, 256, head_planes(), FMT_BF16});
+        v.push_back({"clf.layer_1.weight", "clf.layer_1.bias", 200, D, 256, D, head_planes(), split_fmt(h)});
+        v.push_back({"clf.layer_2.weight", "clf.layer_2.bias", 100, 200, 128, 256, head_planes(), split_fmt(h)});
     }
     return v;
 }
@@ -257,6 +258,7 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     auto ln_fed = [&](const LinSpec& sp) {        // qkv / fc1: also kept slab-major for the LayerNorm-fused kernel
         const bool qkv = sp.wname.find("attn.qkv.weight") != std::string::npos;
         const bool fc1 = sp.wname.find("mlp.fc1.weight") != std::string::npos;
+        if (sp.planes == 2 && sp.fmt != FMT_BF16) return false;      // (the hi+lo LayerNorm-fused kernel is bf16 only: gemm_ln.hip)
         return (qkv || fc1) && gemm_ln_supported(sp.K, sp.N, sp.planes, qkv ? EPI_QKV : EPI_GELU, h->cfg.embed_dim);
     };
     size_t total = 0;
@@ -272,6 +274,7 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
                                             align_up((size_t)mlp_fused_proj_pack_elems(Dm) * sizeof(bf16_t), 256) +
                                             align_up((size_t)mlp_fused_qkv_pack_elems(Dm) * sizeof(bf16_t), 256));
     if (total > h->wbuf_bytes) {
+        ++h->generation;
         if (h->wbuf) DSEG_CHECK_HIP(hipFree(h->wbuf));
         h->wbuf = nullptr;
         DSEG_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&h->wbuf), total));
@@ -345,6 +348,7 @@ extern "C" int dinoseg_prepare_resolution(dinoseg_handle* h, int32_t r, void* st
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DeviceGuard guard(h);
     const int o = r / 8, D = h->cfg.embed_dim;
+    ++h->generation;        // (the cache holds ONE resolution: a captured forward of another one would read this one's rows)
     const size_t need = ((size_t)o * o + 1) * D * sizeof(float);
     if (need > h->pos_cap) {
         if (h->pos_cache) DSEG_CHECK_HIP(hipFree(h->pos_cache));
@@ -403,6 +407,8 @@ static WsLayout make_layout(const dinoseg_handle* h, int B, int r) {
     return L;
 }
 
+extern "C" int64_t dinoseg_state_generation(const dinoseg_handle* h) { return h ? h->generation : -1; }
+
 extern "C" int64_t dinoseg_workspace_bytes(const dinoseg_handle* h, int32_t B, int32_t r) {
     if (!h || B <= 0 || r <= 0 || r % 8 != 0) return -1;
     return (int64_t)(make_layout(h, B, r).total + h->wbuf_bytes);
@@ -415,6 +421,7 @@ static int ensure_workspace(dinoseg_handle* h, int slot, const WsLayout& L, int 
     int& wB = slot ? h->ws2_B : h->ws_B;
     int& wr = slot ? h->ws2_r : h->ws_r;
     if (L.total > bytes) {
+        ++h->generation;
         if (ws) {
             DSEG_CHECK_HIP(hipStreamSynchronize(s));
             DSEG_CHECK_HIP(hipFree(ws));
@@ -485,7 +492,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     DSEG_TRY(dinoseg_prepare_resolution(h, r, stream));
 
     const dinoseg_config& c = h->cfg;
-    const int D = c.embed_dim, F = D * c.mlp_ratio, P = h->planes, HP = head_planes(), H = c.num_heads, FM = h->fmt;
+    const int D = c.embed_dim, F = D * c.mlp_ratio, P = h->planes, HP = head_planes(), H = c.num_heads, FM = h->fmt, SF = split_fmt(h);
     const WsLayout L = make_layout(h, B, r);
     DSEG_TRY(ensure_workspace(h, slot, L, B, r, s));
     // every size-dependent kernel choice below is made for the rows of the WHOLE call: the half-batches of a split forward (disp_B =
@@ -509,13 +516,13 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     norm_consts(mean255, inv255);
     const long pg_plane = (long)L.Mp * 192;
     const int PP = patch_planes(h);
-    DSEG_PROF(DINOSEG_PROF_PATCH, DSEG_TRY(launch_patch_gather(x, x_kind, B, r, mean255, inv255, A, pg_plane, PP, s)));
+    DSEG_PROF(DINOSEG_PROF_PATCH, DSEG_TRY(launch_patch_gather(x, x_kind, B, r, mean255, inv255, A, pg_plane, PP, s, SF)));
     {
         const PackedLinear& pk = h->packed.at("dino.patch_embed.proj.weight");
         GemmParams g = {};
         g.A = A; g.a_plane = pg_plane; g.lda = 192;
         g.W = pk.w; g.w_plane = pk.plane;
-        g.M = L.Mp; g.N = D; g.K = 192; g.planes = PP; g.epi = EPI_PATCH; g.dispatch_rows = disp_Mp;
+        g.M = L.Mp; g.N = D; g.K = 192; g.planes = PP; g.fmt = SF; g.epi = EPI_PATCH; g.dispatch_rows = disp_Mp;
         g.bias = W(h, "dino.patch_embed.proj.bias");
         g.out_f32 = X; g.ldo_f32 = D;
         g.pos = h->pos_cache; g.n_patches = L.n;
@@ -531,11 +538,17 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     bool qkv_ready = false;      // Q / K / V of block i were written by block i-1's fused launch (mlp_fused2.hip, QKV tail)
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
-        // gemm_ln: 0 never fused, 2 always, 1 (default) by measurement: bf16 fused; bf16x3 fused only for small batches -- with
-        // >= 512 tiles of 128 x 384 the separate LayerNorm + the hi+lo configuration of the persistent GEMM is faster
-        // (B = 32: fc1 30 + 534 us against 670 fused; the fused kernel's 64-row panels run one wave per SIMD)
+        // gemm_ln: 0 never fused, 2 always, 1 (default) by measurement (round 4, tools/r4_fourth.sh, 1..6 frames @480):
+        //  * single plane (bf16 / fp16): fused from 80 row panels of 128 on -- below that its persistent 128 x 384 panels leave most
+        //    CUs idle (one frame = 29 panels: qkv 31 against 21 us with LayerNorm + the 128x128 kernel, fc1 40 against 23; the
+        //    whole single-frame forward 1.72 -> 1.33 ms at 12 blocks; crossover between 2 and 3 frames);
+        //  * hi+lo planes: its 64-row panels run one workgroup per CU, so it wins only while they fill about one round of the chip
+        //    (9 600 .. 16 384 rows = 3-4 frames: fc1 1.15 against 1.24 ms; 1 frame 1.01 against 0.48, 6 frames 2.13 against 1.33);
+        //    from 512 tiles of 128 x 384 on, LayerNorm + the hi+lo configuration of the persistent GEMM (B = 32: fc1 30 + 534 us
+        //    against 670 fused).
         const bool big_x3 = P == 2 && options().gemm_big && (long)((disp_M + 127) / 128) * 3 >= 512;
-        const bool fuse_ln = options().gemm_ln == 2 || (options().gemm_ln == 1 && !big_x3);
+        const bool ln_small = P == 1 ? (disp_M + 127) / 128 < 80 : (disp_M < 9600 || disp_M > 16384);
+        const bool fuse_ln = options().gemm_ln == 2 || (options().gemm_ln == 1 && !big_x3 && !ln_small);
         // (the fused kernel keeps 32-bit output row offsets)
         if (qkv_ready) {
             qkv_ready = false;
@@ -680,7 +693,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
 
     // ---- final norm, drop CLS (vision_transformer.py:243; pl_torch_modules.py:243,253) ----
     DSEG_PROF(DINOSEG_PROF_LN, DSEG_TRY(launch_layernorm(X, W(h, "dino.norm.weight"), W(h, "dino.norm.bias"), c.ln_eps, L.M, D, FEAT, L.feat_plane,
-                              HP, nullptr, 1, L.ntok, s)));
+                              HP, nullptr, 1, L.ntok, s, SF)));
 
     // ---- segmentation head (pl_torch_modules.py:108-138), always in split precision ----
     if (c.head_kind == DINOSEG_HEAD_MLP) {
@@ -689,7 +702,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             GemmParams g = {};
             g.A = FEAT; g.a_plane = L.feat_plane; g.lda = D;
             g.W = pk.w; g.w_plane = pk.plane;
-            g.M = L.Mp; g.N = 256; g.K = D; g.planes = HP; g.epi = EPI_RELU;
+            g.M = L.Mp; g.N = 256; g.K = D; g.planes = HP; g.fmt = SF; g.epi = EPI_RELU;
             g.bias = pk.bias_pad;
             g.out_bf16 = H1; g.out_plane = L.h1_plane; g.ldo = 256;
             DSEG_PROF(DINOSEG_PROF_HEAD, DSEG_TRY(launch_gemm(g, s)));
@@ -699,16 +712,16 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             GemmParams g = {};
             g.A = H1; g.a_plane = L.h1_plane; g.lda = 256;
             g.W = pk.w; g.w_plane = pk.plane;
-            g.M = L.Mp; g.N = 128; g.K = 256; g.planes = HP; g.epi = EPI_RELU;
+            g.M = L.Mp; g.N = 128; g.K = 256; g.planes = HP; g.fmt = SF; g.epi = EPI_RELU;
             g.bias = pk.bias_pad;
             g.out_bf16 = H2; g.out_plane = L.h2_plane; g.ldo = 128;
             DSEG_PROF(DINOSEG_PROF_HEAD, DSEG_TRY(launch_gemm(g, s)));
         }
         DSEG_PROF(DINOSEG_PROF_HEAD, DSEG_TRY(launch_head_final(H2, L.h2_plane, 128, L.Mp, 100, W(h, "clf.layer_3.weight"), W(h, "clf.layer_3.bias"),
-                                   c.n_classes, logp_out ? logp_out : reinterpret_cast<float*>(ws + L.HB), argmax_out, s)));
+                                   c.n_classes, logp_out ? logp_out : reinterpret_cast<float*>(ws + L.HB), argmax_out, s, SF)));
     } else {
         DSEG_PROF(DINOSEG_PROF_HEAD, DSEG_TRY(launch_head_final(FEAT, L.feat_plane, D, L.Mp, D, W(h, "clf.layer_1.weight"), W(h, "clf.layer_1.bias"),
-                                   c.n_classes, logp_out ? logp_out : reinterpret_cast<float*>(ws + L.HB), argmax_out, s)));
+                                   c.n_classes, logp_out ? logp_out : reinterpret_cast<float*>(ws + L.HB), argmax_out, s, SF)));
     }
     return 0;
 }
@@ -928,7 +941,7 @@ extern "C" int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* c
 extern "C" int dinoseg_op_pack(const float* src, int32_t rows, int32_t cols, void* dst, int64_t plane_stride,
                                int32_t rows_pad, int32_t cols_pad, int32_t planes, void* stream) {
     return launch_pack_planes(src, rows, cols, reinterpret_cast<bf16_t*>(dst), plane_stride, rows_pad, cols_pad, planes,
-                              reinterpret_cast<hipStream_t>(stream), planes == 1 ? options().op_fmt : FMT_BF16);
+                              reinterpret_cast<hipStream_t>(stream), options().op_fmt);
 }
 
 extern "C" int dinoseg_op_gemm(const void* A, int64_t a_plane, int32_t lda, const void* Wp, int64_t w_plane, int32_t M,
@@ -942,7 +955,7 @@ extern "C" int dinoseg_op_gemm(const void* A, int64_t a_plane, int32_t lda, cons
     g.A = reinterpret_cast<const bf16_t*>(A); g.a_plane = a_plane; g.lda = lda;
     g.W = reinterpret_cast<const bf16_t*>(Wp); g.w_plane = w_plane;
     g.M = M; g.N = N; g.K = K; g.planes = planes; g.epi = epi; g.bias = bias;
-    g.fmt = planes == 1 ? options().op_fmt : FMT_BF16;
+    g.fmt = options().op_fmt;
     g.out_f32 = out_f32; g.ldo_f32 = N;
     g.out_bf16 = reinterpret_cast<bf16_t*>(out_bf16); g.out_plane = out_plane; g.ldo = ldo;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
@@ -956,7 +969,7 @@ extern "C" int dinoseg_op_qkv_gemm(const void* A, int64_t a_plane, const void* W
     g.A = reinterpret_cast<const bf16_t*>(A); g.a_plane = a_plane; g.lda = D;
     g.W = reinterpret_cast<const bf16_t*>(Wp); g.w_plane = w_plane;
     g.M = B * ntok; g.N = 3 * D; g.K = D; g.planes = planes; g.epi = EPI_QKV; g.bias = bias;
-    g.fmt = planes == 1 ? options().op_fmt : FMT_BF16;
+    g.fmt = options().op_fmt;
     g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
     g.qkv_plane = qkv_plane; g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = D; g.qscale = qscale;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(stream));
@@ -1080,7 +1093,7 @@ extern "C" int dinoseg_op_attention(const void* q, const void* k, const void* v,
     a.v = reinterpret_cast<const bf16_t*>(v); a.qkv_plane = qkv_plane;
     a.ctx = reinterpret_cast<bf16_t*>(ctx); a.ctx_plane = ctx_plane; a.lse = lse;
     a.B = B; a.heads = heads; a.ntok = ntok; a.npad = npad; a.planes = planes;
-    a.fmt = planes == 1 ? options().op_fmt : FMT_BF16;
+    a.fmt = options().op_fmt;
     return launch_attention(a, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1088,7 +1101,7 @@ extern "C" int dinoseg_op_layernorm(const float* x, const float* gamma, const fl
                                     void* out_bf16, int64_t out_plane, int32_t planes, float* out_f32, int32_t drop_cls,
                                     int32_t ntok, void* stream) {
     return launch_layernorm(x, gamma, beta, eps, M, D, reinterpret_cast<bf16_t*>(out_bf16), out_plane, planes, out_f32,
-                            drop_cls, ntok, reinterpret_cast<hipStream_t>(stream), planes == 1 ? options().op_fmt : FMT_BF16);
+                            drop_cls, ntok, reinterpret_cast<hipStream_t>(stream), options().op_fmt);
 }
 
 extern "C" int dinoseg_op_pos_resample(const float* pos_embed, int32_t g, int32_t D, int32_t o, float* out, void* stream) {
@@ -1104,11 +1117,11 @@ extern "C" int dinoseg_op_patch_gather(const void* x, int32_t x_kind, int32_t B,
     float mean255[3], inv255[3];
     norm_consts(mean255, inv255);
     return launch_patch_gather(x, x_kind, B, r, mean255, inv255, reinterpret_cast<bf16_t*>(out), out_plane, planes,
-                               reinterpret_cast<hipStream_t>(stream));
+                               reinterpret_cast<hipStream_t>(stream), planes == 2 ? options().op_fmt : FMT_BF16);
 }
 
 extern "C" int dinoseg_op_head_final(const void* in, int64_t in_plane, int32_t ld, int32_t M, int32_t K, const float* Wc,
                                      const float* b, int32_t C, float* logp, int32_t* argmax, void* stream) {
     return launch_head_final(reinterpret_cast<const bf16_t*>(in), in_plane, ld, M, K, Wc, b, C, logp, argmax,
-                             reinterpret_cast<hipStream_t>(stream));
+                             reinterpret_cast<hipStream_t>(stream), options().op_fmt);
 }

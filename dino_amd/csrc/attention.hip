@@ -41,8 +41,11 @@ __device__ __forceinline__ int tile_off2(int row, int chunk) { return attn::tile
 //            2^RESCALE_THR the tile is redone the careful way (scores recomputed from the K tile still in LDS, row
 //            maximum, rescale).  Saves 16 v_max3 + a cross-half exchange per tile on the vector issue port.
 //     bit 1: waves whose 32 query rows are all past ntok (last q-tile of a (batch, head)) only stage and synchronise
-template <int PLANES, int NW, bool DBG, int VAR>     // NW waves per workgroup, each 32 query rows; all share the K/V tiles
+// FMT (PLANES == 2 only): FMT_FP16 = Q, K, V, the probabilities and ctx are fp16 hi + lo planes (~22 bits).  The probabilities are
+//            2^(S - m_run) with the reference m_run trailing the row maximum by at most RESCALE_THR: fp16 holds them up to 2^15.
+template <int PLANES, int NW, bool DBG, int VAR, int FMT = FMT_BF16>     // NW waves per workgroup, each 32 query rows; all share the K/V tiles
 __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
+    static_assert(FMT == FMT_BF16 || PLANES == 2, "one fp16 plane: attention_z.hip");
     constexpr int QB = NW * QW;
     const int dbg = DBG ? p.dbg : 0;        // timing ablations are compiled out of the production instantiation
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -128,7 +131,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
     // score MFMA chain as the accumulator's initial value (negm = -m_run in all 16 registers), so S' = S - m_run
     // costs no VALU.  m_run moves only when a row maximum exceeds it by more than RESCALE_THR (rare after the first
     // tiles), so the O / l rescale is off the steady-state path.
-    constexpr float RESCALE_THR = 16.f;     // P <= 2^16: far from fp32 / bf16 overflow
+    constexpr float RESCALE_THR = FMT == FMT_FP16 ? 14.f : 16.f;     // P <= 2^16: far from fp32 / bf16 overflow (fp16: a lane's 32-key sum <= 2^15)
     f32x16 negm;
 #pragma unroll
     for (int r = 0; r < 16; ++r) negm[r] = 0.f;
@@ -183,10 +186,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     if (PLANES == 2) {
-                        sacc[kb] = mfma32(kf[PLANES - 1][kb][s], qf[0][s], sacc[kb]);
-                        sacc[kb] = mfma32(kf[0][kb][s], qf[PLANES - 1][s], sacc[kb]);
+                        sacc[kb] = mfma32f<FMT>(kf[PLANES - 1][kb][s], qf[0][s], sacc[kb]);
+                        sacc[kb] = mfma32f<FMT>(kf[0][kb][s], qf[PLANES - 1][s], sacc[kb]);
                     }
-                    sacc[kb] = mfma32(kf[0][kb][s], qf[0][s], sacc[kb]);
+                    sacc[kb] = mfma32f<FMT>(kf[0][kb][s], qf[0][s], sacc[kb]);
                 }
             // lane (query lr, half lh): sacc[kb][8*s2 + j] is key  t*64 + kb*32 + s2*16 + lh*8 + j
             if ((t + 1) * KB > ntok) {   // ragged last tile: mask keys >= ntok (wave-uniform branch)
@@ -246,7 +249,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
             if (!careful) {
                 ps = exponentiate();
                 // 2^RESCALE_THR bounds every P of the tile on the fast path; !(<=) also catches inf / NaN sums
-                careful = __any(!(ps <= 65536.f));
+                careful = __any(!(ps <= (FMT == FMT_FP16 ? 32768.f : 65536.f)));
                 if (careful) scores();
             }
             if (careful) {
@@ -266,10 +269,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 uint4 hi, lo;
-                split_bf16x2(sacc[kb][s2 * 8 + 0], sacc[kb][s2 * 8 + 1], hi.x, lo.x);
-                split_bf16x2(sacc[kb][s2 * 8 + 2], sacc[kb][s2 * 8 + 3], hi.y, lo.y);
-                split_bf16x2(sacc[kb][s2 * 8 + 4], sacc[kb][s2 * 8 + 5], hi.z, lo.z);
-                split_bf16x2(sacc[kb][s2 * 8 + 6], sacc[kb][s2 * 8 + 7], hi.w, lo.w);
+                split2<FMT>(sacc[kb][s2 * 8 + 0], sacc[kb][s2 * 8 + 1], hi.x, lo.x);
+                split2<FMT>(sacc[kb][s2 * 8 + 2], sacc[kb][s2 * 8 + 3], hi.y, lo.y);
+                split2<FMT>(sacc[kb][s2 * 8 + 4], sacc[kb][s2 * 8 + 5], hi.z, lo.z);
+                split2<FMT>(sacc[kb][s2 * 8 + 6], sacc[kb][s2 * 8 + 7], hi.w, lo.w);
                 pf[0][kb * 2 + s2] = __builtin_bit_cast(bf16x8, hi);
                 if (PLANES == 2) pf[PLANES - 1][kb * 2 + s2] = __builtin_bit_cast(bf16x8, lo);
             }
@@ -288,10 +291,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
                 const bf16x8 vhi = tr_frag(sb + off0, sb + off1);
                 if (PLANES == 2) {
                     const bf16x8 vlo = tr_frag(sb + 2 * KV_TILE + off0, sb + 2 * KV_TILE + off1);
-                    o[db] = mfma32(vlo, pf[0][ks], o[db]);
-                    o[db] = mfma32(vhi, pf[PLANES - 1][ks], o[db]);
+                    o[db] = mfma32f<FMT>(vlo, pf[0][ks], o[db]);
+                    o[db] = mfma32f<FMT>(vhi, pf[PLANES - 1][ks], o[db]);
                 }
-                o[db] = mfma32(vhi, pf[0][ks], o[db]);
+                o[db] = mfma32f<FMT>(vhi, pf[0][ks], o[db]);
             }
         }
 
@@ -324,8 +327,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint2 hi, lo;
-                    split_bf16x2(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv, hi.x, lo.x);
-                    split_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv, hi.y, lo.y);
+                    split2<FMT, true>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv, hi.x, lo.x);
+                    split2<FMT, true>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv, hi.y, lo.y);
                     *reinterpret_cast<uint2*>(patch + lr * 128 + (((db * 4 + g) ^ (lr & 7)) << 4) + lh * 8) = pl == 0 ? hi : lo;
                 }
             // one wave's LDS requests execute in order; the compiler must keep them in order too (the 8-byte writes and the
@@ -344,18 +347,18 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p) {
     }
 }
 
-template <int PLANES, int NW, bool DBG, int VAR>
+template <int PLANES, int NW, bool DBG, int VAR, int FMT = FMT_BF16>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
-    attn_fwd_body<PLANES, NW, DBG, VAR>(p);
+    attn_fwd_body<PLANES, NW, DBG, VAR, FMT>(p);
 }
 
-template <int PLANES, int NW, bool DBG, int VAR>
+template <int PLANES, int NW, bool DBG, int VAR, int FMT = FMT_BF16>
 static int launch_attn(const AttnParams& p, hipStream_t s) {
     const int nq = (p.ntok + NW * QW - 1) / (NW * QW);
     const int npairs = p.B * p.heads;
     const int grid = ((npairs + 7) / 8) * 8 * nq;
     const size_t lds = (size_t)2 * PLANES * 2 * KV_TILE;
-    hipLaunchKernelGGL((attn_fwd_kernel<PLANES, NW, DBG, VAR>), dim3(grid), dim3(NW * 64), lds, s, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<PLANES, NW, DBG, VAR, FMT>), dim3(grid), dim3(NW * 64), lds, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -377,12 +380,15 @@ int launch_attention(const AttnParams& p0, hipStream_t s) {
         dinoseg_set_error("attention: npad=%d must be a multiple of 64 and >= ntok=%d", p.npad, p.ntok);
         return -1;
     }
-    if (p.fmt == FMT_FP16) {      // fp16 Q / K / ctx (inference): the zero-reference kernel only; no log-sum-exp for a backward
-        if (p.planes != 1 || p.lse != nullptr) {
-            dinoseg_set_error("attention: the fp16 operand format is single-plane and inference-only");
+    if (p.fmt == FMT_FP16) {      // fp16 operands (inference: no log-sum-exp for a backward): one plane = the zero-reference kernel with bf16
+        if (p.lse != nullptr) {   // P / V; hi + lo planes = this file's kernel, every operand fp16
+            dinoseg_set_error("attention: the fp16 operand format is inference-only");
             return -1;
         }
-        return launch_attention_z(p, s);
+        if (p.planes == 1) return launch_attention_z(p, s);
+        if (p.planes == 2) return launch_attn<2, 4, false, 3, FMT_FP16>(p, s);
+        dinoseg_set_error("attention: planes must be 1 or 2");
+        return -1;
     }
     if (p.dbg != 0 && p.planes == 1) return launch_attn<1, 4, true, 0>(p, s);      // ablation build (tools/bench_ops.py)
     if (p.planes == 1 && (options().attn_variant & 8)) return launch_attention_z(p, s);      // zero-reference, 4 waves / SIMD

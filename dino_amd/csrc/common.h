@@ -66,6 +66,34 @@ __device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uin
     lo = pack_bf16x2(a - bf16_lo_to_f32(hi), b - bf16_hi_to_f32(hi));
 }
 
+// the same split in either operand format: fp16 hi + fp16 lo carries ~22 significand bits for |x| >= 2^-13 (below that the lo plane is
+// subnormal: the absolute error stays <= 2^-25), bf16 hi + lo ~16 bits at any magnitude.  SAT: clamp to the fp16 range first (an
+// unbounded value -- a GEMM output -- saturates at +-65504 instead of turning into inf - inf = NaN); bounded values skip it.
+template <int FMT, bool SAT = false>
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    if constexpr (FMT == FMT_FP16) {
+        if constexpr (SAT) {
+            a = __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f);
+            b = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
+        }
+        hi = pack_f16x2(a, b);
+        lo = pack_f16x2(a - lo_to_f32<FMT_FP16>(hi), b - hi_to_f32<FMT_FP16>(hi));
+    } else {
+        split_bf16x2(a, b, hi, lo);
+    }
+}
+// single plane, saturating where the format has a range to leave
+template <int FMT>
+__device__ __forceinline__ uint32_t pack2_sat(float a, float b) {
+    if constexpr (FMT == FMT_FP16) return pack_f16x2(__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f));
+    else return pack_bf16x2(a, b);
+}
+// run-time form of the split (pack / gather kernels)
+__device__ __forceinline__ void split1(float v, int fmt, bf16_t& hi, bf16_t& lo) {
+    hi = pack1(v, fmt);
+    lo = pack1(v - unpack1(hi, fmt), fmt);
+}
+
 // ---- 128-byte-row LDS tile swizzle -------------------------------------------------
 // A tile is [rows][64 bf16] = 128-B rows, i.e. 8 chunks of 16 B per row.  ds_read_b128 is
 // served in 16-lane groups over a 256-B bank row; reading the same logical chunk of 16

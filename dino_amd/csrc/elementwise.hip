@@ -15,22 +15,15 @@ __global__ void pack_planes_kernel(const float* __restrict__ src, int rows, int 
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int r = (int)(i / cols_pad), c = (int)(i - (long)r * cols_pad);
         const float v = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
-        if (fmt == FMT_FP16) {      // (single plane)
-            dst[i] = pack1(v, fmt);
-            continue;
-        }
-        const uint32_t hi = pack_bf16x2(v, 0.f);
-        dst[i] = (bf16_t)(hi & 0xFFFF);
-        if (planes == 2) dst[plane + i] = (bf16_t)(pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
+        bf16_t hi, lo;
+        split1(v, fmt, hi, lo);
+        dst[i] = hi;
+        if (planes == 2) dst[plane + i] = lo;
     }
 }
 
 int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,
                        int planes, hipStream_t s, int fmt) {
-    if (fmt != FMT_BF16 && planes != 1) {
-        dinoseg_set_error("pack_planes: the fp16 operand format is single-plane");
-        return -1;
-    }
     const long total = (long)rows_pad * cols_pad;
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
@@ -97,13 +90,10 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(MultiPackTable T) {
         }
         if (r0 + r >= j.rows_pad || c0 + c >= j.cols_pad) continue;
         const float v = tile[r][c];
-        if (j.fmt == FMT_FP16) {      // (single plane)
-            j.dst[d] = pack1(v, j.fmt);
-            continue;
-        }
-        const uint32_t hi = pack_bf16x2(v, 0.f);
-        j.dst[d] = (bf16_t)(hi & 0xFFFF);
-        if (j.planes == 2) j.dst[j.plane + d] = (bf16_t)(pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
+        bf16_t hi, lo;
+        split1(v, j.fmt, hi, lo);
+        j.dst[d] = hi;
+        if (j.planes == 2) j.dst[j.plane + d] = lo;
     }
 }
 
@@ -179,7 +169,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             }
             if (out) {
                 uint32_t hi, lo;
-                if (fmt == FMT_FP16) hi = lo = pack_f16x2(y0, y1);      // (single plane; wave-uniform)
+                if (fmt == FMT_FP16) split2<FMT_FP16>(y0, y1, hi, lo);      // (wave-uniform)
                 else split_bf16x2(y0, y1, hi, lo);
                 *reinterpret_cast<uint32_t*>(out + o) = hi;
                 if (planes == 2) *reinterpret_cast<uint32_t*>(out + out_plane + o) = lo;
@@ -191,10 +181,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, int M, int D, bf16_t* out,
                      long out_plane, int planes, float* out_f32, int drop_cls, int ntok, hipStream_t s, int fmt) {
     if (M <= 0) return 0;
-    if (fmt != FMT_BF16 && planes != 1) {
-        dinoseg_set_error("layernorm: the fp16 operand format is single-plane");
-        return -1;
-    }
     if (D % 128 != 0 || D > 1024) {
         dinoseg_set_error("layernorm: D=%d must be a multiple of 128 and <= 1024", D);
         return -1;
@@ -222,7 +208,7 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, floa
 // kind 1: fp32 CHW tensor as handed to DINOSeg.forward (pl_torch_modules.py:239).
 __global__ __launch_bounds__(256) void patch_gather_kernel(const void* __restrict__ xin, int kind, int B, int r,
                                                            f32x4 mean255, f32x4 inv255, bf16_t* __restrict__ out,
-                                                           long out_plane, int planes) {
+                                                           long out_plane, int planes, int fmt) {
     const int o = r >> 3;
     const long total = (long)B * o * o * 8;   // one work item = (patch, ky): 8 pixels x 3 channels
     for (long w = (long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long)gridDim.x * blockDim.x) {
@@ -261,10 +247,17 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const void* __restric
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             uint4 hi, lo;
-            split_bf16x2(v[c][0], v[c][1], hi.x, lo.x);
-            split_bf16x2(v[c][2], v[c][3], hi.y, lo.y);
-            split_bf16x2(v[c][4], v[c][5], hi.z, lo.z);
-            split_bf16x2(v[c][6], v[c][7], hi.w, lo.w);
+            if (fmt == FMT_FP16) {      // (uniform; pixels are bounded: no saturation needed)
+                split2<FMT_FP16>(v[c][0], v[c][1], hi.x, lo.x);
+                split2<FMT_FP16>(v[c][2], v[c][3], hi.y, lo.y);
+                split2<FMT_FP16>(v[c][4], v[c][5], hi.z, lo.z);
+                split2<FMT_FP16>(v[c][6], v[c][7], hi.w, lo.w);
+            } else {
+                split_bf16x2(v[c][0], v[c][1], hi.x, lo.x);
+                split_bf16x2(v[c][2], v[c][3], hi.y, lo.y);
+                split_bf16x2(v[c][4], v[c][5], hi.z, lo.z);
+                split_bf16x2(v[c][6], v[c][7], hi.w, lo.w);
+            }
             bf16_t* dst = out + patch * 192 + c * 64 + ky * 8;
             *reinterpret_cast<uint4*>(dst) = hi;
             if (planes == 2) *reinterpret_cast<uint4*>(dst + out_plane) = lo;
@@ -273,12 +266,12 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const void* __restric
 }
 
 int launch_patch_gather(const void* x, int kind, int B, int r, const float* mean255, const float* inv_std255,
-                        bf16_t* out, long out_plane, int planes, hipStream_t s) {
+                        bf16_t* out, long out_plane, int planes, hipStream_t s, int fmt) {
     const long total = (long)B * (r / 8) * (r / 8) * 8;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
     f32x4 m = {mean255[0], mean255[1], mean255[2], 0.f}, iv = {inv_std255[0], inv_std255[1], inv_std255[2], 0.f};
-    hipLaunchKernelGGL(patch_gather_kernel, dim3(grid), dim3(256), 0, s, x, kind, B, r, m, iv, out, out_plane, planes);
+    hipLaunchKernelGGL(patch_gather_kernel, dim3(grid), dim3(256), 0, s, x, kind, B, r, m, iv, out, out_plane, planes, fmt);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -370,7 +363,7 @@ template <int CMAX>
 __global__ __launch_bounds__(256) void head_final_kernel(const bf16_t* __restrict__ in, long in_plane, int ld, int M,
                                                          int K, const float* __restrict__ W,
                                                          const float* __restrict__ bias, int C,
-                                                         float* __restrict__ logp, int32_t* __restrict__ amax) {
+                                                         float* __restrict__ logp, int32_t* __restrict__ amax, int fmt) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     float z[CMAX];
@@ -384,8 +377,13 @@ __global__ __launch_bounds__(256) void head_final_kernel(const bf16_t* __restric
         float xv[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            xv[2 * e] = bf16_lo_to_f32(hw[e]) + bf16_lo_to_f32(lw[e]);
-            xv[2 * e + 1] = bf16_hi_to_f32(hw[e]) + bf16_hi_to_f32(lw[e]);
+            if (fmt == FMT_FP16) {
+                xv[2 * e] = lo_to_f32<FMT_FP16>(hw[e]) + lo_to_f32<FMT_FP16>(lw[e]);
+                xv[2 * e + 1] = hi_to_f32<FMT_FP16>(hw[e]) + hi_to_f32<FMT_FP16>(lw[e]);
+            } else {
+                xv[2 * e] = bf16_lo_to_f32(hw[e]) + bf16_lo_to_f32(lw[e]);
+                xv[2 * e + 1] = bf16_hi_to_f32(hw[e]) + bf16_hi_to_f32(lw[e]);
+            }
         }
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
@@ -416,7 +414,7 @@ __global__ __launch_bounds__(256) void head_final_kernel(const bf16_t* __restric
 }
 
 int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, const float* W, const float* b, int C,
-                      float* logp, int32_t* argmax, hipStream_t s) {
+                      float* logp, int32_t* argmax, hipStream_t s, int fmt) {
     if (M <= 0) return 0;
     if (C < 1 || C > 32 || ld % 8 != 0) {
         dinoseg_set_error("head_final: need 1 <= C <= 32 and ld %% 8 == 0 (C=%d ld=%d)", C, ld);
@@ -424,9 +422,9 @@ int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, con
     }
     const int grid = (M + 255) / 256;
     if (C <= 8)
-        hipLaunchKernelGGL((head_final_kernel<8>), dim3(grid), dim3(256), 0, s, in, in_plane, ld, M, K, W, b, C, logp, argmax);
+        hipLaunchKernelGGL((head_final_kernel<8>), dim3(grid), dim3(256), 0, s, in, in_plane, ld, M, K, W, b, C, logp, argmax, fmt);
     else
-        hipLaunchKernelGGL((head_final_kernel<32>), dim3(grid), dim3(256), 0, s, in, in_plane, ld, M, K, W, b, C, logp, argmax);
+        hipLaunchKernelGGL((head_final_kernel<32>), dim3(grid), dim3(256), 0, s, in, in_plane, ld, M, K, W, b, C, logp, argmax, fmt);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -447,7 +445,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restric
         const int r = i >> 6, d = i & 63;
         const int qr = q0 + r < ntok ? q0 + r : ntok - 1;
         float v = unpack1(Qg[(long)qr * 64 + d], fmt);
-        if (planes == 2) v += bf16_to_f32(Qg[plane + (long)qr * 64 + d]);
+        if (planes == 2) v += unpack1(Qg[plane + (long)qr * 64 + d], fmt);
         qs[r][d] = v;
     }
     __syncthreads();
@@ -468,8 +466,8 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t* __restric
                 const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    kv[c * 8 + 2 * e] += bf16_lo_to_f32(lw[e]);
-                    kv[c * 8 + 2 * e + 1] += bf16_hi_to_f32(lw[e]);
+                    kv[c * 8 + 2 * e] += fmt == FMT_FP16 ? lo_to_f32<FMT_FP16>(lw[e]) : bf16_lo_to_f32(lw[e]);
+                    kv[c * 8 + 2 * e + 1] += fmt == FMT_FP16 ? hi_to_f32<FMT_FP16>(lw[e]) : bf16_hi_to_f32(lw[e]);
                 }
             }
         }
@@ -525,11 +523,12 @@ __global__ __launch_bounds__(256) void cls_mask_attn_kernel(const bf16_t* __rest
     const int m = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long po = (long)hd * npad * 64;
     // (fp16 mode: Q, K and the ctx output are fp16, V is bf16 -- as the fused attention kernel has them)
-    auto ld = [&](const bf16_t* base, long idx, int f = FMT_BF16) {
+    auto ld = [&](const bf16_t* base, long idx, int f) {
         float x = unpack1(base[idx], f);
-        if (planes == 2) x += bf16_to_f32(base[plane + idx]);
+        if (planes == 2) x += unpack1(base[plane + idx], f);
         return x;
     };
+    const int vfmt = planes == 2 ? fmt : FMT_BF16;
     if (tid < 64) qs[tid] = ld(q, po + tid, fmt);                 // CLS row = token 0
     __syncthreads();
     const float* mrow = mask + (long)m * (ntok - 1);
@@ -562,16 +561,17 @@ __global__ __launch_bounds__(256) void cls_mask_attn_kernel(const bf16_t* __rest
     }
     // context: wave wv sums keys n = wv, wv+4, ...; lane = d
     float acc = 0.f;
-    for (int n = wv; n < ntok; n += 4) acc = fmaf(sc[n], ld(v, po + (long)n * 64 + lane), acc);
+    for (int n = wv; n < ntok; n += 4) acc = fmaf(sc[n], ld(v, po + (long)n * 64 + lane, vfmt), acc);
     __syncthreads();                         // everyone is done reading sc[] as probabilities
     sc[wv * 64 + lane] = acc;
     __syncthreads();
     if (tid < 64) {
         const float o = (sc[tid] + sc[64 + tid] + sc[128 + tid] + sc[192 + tid]) * inv;
-        const uint32_t hi = fmt == FMT_FP16 ? pack_f16x2(o, 0.f) : pack_bf16x2(o, 0.f);
+        bf16_t hi, lo;
+        split1(o, fmt, hi, lo);
         const long idx = (long)m * heads * 64 + hd * 64 + tid;
-        ctx[idx] = (bf16_t)(hi & 0xFFFF);
-        if (planes == 2) ctx[ctx_plane + idx] = (bf16_t)(pack_bf16x2(o - bf16_lo_to_f32(hi), 0.f) & 0xFFFF);
+        ctx[idx] = hi;
+        if (planes == 2) ctx[ctx_plane + idx] = lo;
     }
 }
 

@@ -19,10 +19,11 @@ namespace dseg {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 128;   // one [128][64] bf16 slab
 
-// FMT (PLANES == 1, inference epilogues only): FMT_FP16 = A, W and the 16-bit outputs are fp16 (EPI_QKV: V stays bf16)
+// FMT (inference epilogues only): FMT_FP16 = A, W and the 16-bit outputs are fp16 (one plane: EPI_QKV leaves V bf16; hi+lo: all fp16)
 template <int PLANES, int EPI, int FMT = FMT_BF16>
 __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(GemmParams p) {
-    static_assert(FMT == FMT_BF16 || (PLANES == 1 && (EPI == EPI_RESID || EPI == EPI_GELU || EPI == EPI_QKV)), "fp16: single plane, inference");
+    static_assert(FMT == FMT_BF16 || EPI == EPI_RESID || EPI == EPI_GELU || EPI == EPI_QKV || (PLANES == 2 && (EPI == EPI_PATCH || EPI == EPI_RELU)),
+                  "fp16 operands: inference epilogues only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = PLANES * 2 * TILE_BYTES;
 
@@ -98,8 +99,8 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (PLANES == 2) {
-                        acc[i][j] = mfma32(a[1][i], b[0][j], acc[i][j]);
-                        acc[i][j] = mfma32(a[0][i], b[1][j], acc[i][j]);
+                        acc[i][j] = mfma32f<FMT>(a[1][i], b[0][j], acc[i][j]);
+                        acc[i][j] = mfma32f<FMT>(a[0][i], b[1][j], acc[i][j]);
                     }
                     acc[i][j] = mfma32f<FMT>(a[0][i], b[0][j], acc[i][j]);
                 }
@@ -182,12 +183,20 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
                 if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
             }
             uint4 hi, lo;
-            if (FMT == FMT_FP16 && !(EPI == EPI_QKV && which == 2)) {      // (which is workgroup-uniform)
-                hi.x = pack2<FMT>(v[0], v[1]);
-                hi.y = pack2<FMT>(v[2], v[3]);
-                hi.z = pack2<FMT>(v[4], v[5]);
-                hi.w = pack2<FMT>(v[6], v[7]);
-                lo = hi;
+            if (FMT == FMT_FP16 && !(PLANES == 1 && EPI == EPI_QKV && which == 2)) {      // (which is workgroup-uniform)
+                // (GEMM outputs are unbounded: saturate at the fp16 range instead of producing inf)
+                if (PLANES == 2) {
+                    split2<FMT, true>(v[0], v[1], hi.x, lo.x);
+                    split2<FMT, true>(v[2], v[3], hi.y, lo.y);
+                    split2<FMT, true>(v[4], v[5], hi.z, lo.z);
+                    split2<FMT, true>(v[6], v[7], hi.w, lo.w);
+                } else {
+                    hi.x = pack2_sat<FMT>(v[0], v[1]);
+                    hi.y = pack2_sat<FMT>(v[2], v[3]);
+                    hi.z = pack2_sat<FMT>(v[4], v[5]);
+                    hi.w = pack2_sat<FMT>(v[6], v[7]);
+                    lo = hi;
+                }
             } else {
                 split_bf16x2(v[0], v[1], hi.x, lo.x);
                 split_bf16x2(v[2], v[3], hi.y, lo.y);
@@ -309,7 +318,12 @@ int launch_gemm_small(const GemmParams& p, hipStream_t s) {
         if (p.planes == 1 && p.epi == EPI_RESID) return launch_one<1, EPI_RESID, FMT_FP16>(p, s);
         if (p.planes == 1 && p.epi == EPI_GELU && p.aux_out == nullptr) return launch_one<1, EPI_GELU, FMT_FP16>(p, s);
         if (p.planes == 1 && p.epi == EPI_QKV) return launch_one<1, EPI_QKV, FMT_FP16>(p, s);
-        dinoseg_set_error("gemm: the fp16 operand format covers the single-plane inference epilogues only (planes=%d epi=%d)", p.planes, p.epi);
+        if (p.planes == 2 && p.epi == EPI_RESID) return launch_one<2, EPI_RESID, FMT_FP16>(p, s);
+        if (p.planes == 2 && p.epi == EPI_GELU && p.aux_out == nullptr) return launch_one<2, EPI_GELU, FMT_FP16>(p, s);
+        if (p.planes == 2 && p.epi == EPI_QKV) return launch_one<2, EPI_QKV, FMT_FP16>(p, s);
+        if (p.planes == 2 && p.epi == EPI_PATCH) return launch_one<2, EPI_PATCH, FMT_FP16>(p, s);
+        if (p.planes == 2 && p.epi == EPI_RELU) return launch_one<2, EPI_RELU, FMT_FP16>(p, s);
+        dinoseg_set_error("gemm: the fp16 operand format covers the inference epilogues only (planes=%d epi=%d)", p.planes, p.epi);
         return -1;
     }
 #define DSEG_CASE(PL, E) \

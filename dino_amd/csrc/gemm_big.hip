@@ -29,7 +29,6 @@ constexpr int BK = 32;
 template <int WM_, int WN_, int MI_, int NI_, int STAGES_, int WGS_, int PL_ = 1, int FMT_ = FMT_BF16>
 struct Cfg {
     static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, STAGES = STAGES_, WGS = WGS_, PL = PL_, FMT = FMT_;
-    static_assert(FMT_ == FMT_BF16 || PL_ == 1, "the fp16 operand format is single-plane");
     static constexpr int NWAVES = WM * WN, THREADS = NWAVES * 64;
     static constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     static constexpr int A_PLANE_BYTES = BM * BK * 2, W_PLANE_BYTES = BN * BK * 2;        // one operand plane of one k-slab
@@ -45,6 +44,7 @@ using Cfg256x384h = Cfg<2, 4, 4, 3, 3, 1, 1, FMT_FP16>;      // the same tile on
 // bf16x3 (hi + lo planes of both operands, 3 MFMAs per product): 128 x 384 tile, wave tile 64 x 96, 2 slots of 64 KiB -- one
 // slab in flight behind the one being multiplied, which takes three times as long as a bf16 slab (144 FLOP per staged byte)
 using Cfg128x384x2 = Cfg<2, 4, 2, 3, 2, 1, 2>;
+using Cfg128x384x2h = Cfg<2, 4, 2, 3, 2, 1, 2, FMT_FP16>;      // ... on fp16 hi + lo planes
 // (Cfg<2,2,2,2,2,3> = 128x128 and Cfg<2,2,2,3,2,3> = 128x192 with 3 workgroups per CU were measured: 15-25 % slower;
 //  Cfg<1,4,4,3,2,2> = 128x384 with 2 workgroups per CU: 2-28 % slower -- the two workgroups stay in phase, main loop and
 //  epilogue times simply add up as with one)
@@ -203,8 +203,8 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {      // lane: column n, registers: rows m
                     if (PL == 2) {                  // small terms first, as in gemm.hip
-                        acc[i][j] = mfma32(af[PL - 1][i], wf[0][j], acc[i][j]);
-                        acc[i][j] = mfma32(af[0][i], wf[PL - 1][j], acc[i][j]);
+                        acc[i][j] = mfma32f<C::FMT>(af[PL - 1][i], wf[0][j], acc[i][j]);
+                        acc[i][j] = mfma32f<C::FMT>(af[0][i], wf[PL - 1][j], acc[i][j]);
                     }
                     acc[i][j] = mfma32f<C::FMT>(af[0][i], wf[0][j], acc[i][j]);
                 }
@@ -353,12 +353,19 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
                                 if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
                             }
                             uint4 o[2];
-                            if (C::FMT == FMT_FP16 && !(EPI == EPI_QKV && which == 2)) {      // (V stays bf16; which is wave-uniform)
-                                o[0].x = pack2<C::FMT>(v[0], v[1]);
-                                o[0].y = pack2<C::FMT>(v[2], v[3]);
-                                o[0].z = pack2<C::FMT>(v[4], v[5]);
-                                o[0].w = pack2<C::FMT>(v[6], v[7]);
-                                o[1] = o[0];
+                            if (C::FMT == FMT_FP16 && !(PL == 1 && EPI == EPI_QKV && which == 2)) {      // (one plane: V stays bf16)
+                                if (PL == 2) {      // (outputs are unbounded: saturate at the fp16 range)
+                                    split2<C::FMT, true>(v[0], v[1], o[0].x, o[1].x);
+                                    split2<C::FMT, true>(v[2], v[3], o[0].y, o[1].y);
+                                    split2<C::FMT, true>(v[4], v[5], o[0].z, o[1].z);
+                                    split2<C::FMT, true>(v[6], v[7], o[0].w, o[1].w);
+                                } else {
+                                    o[0].x = pack2_sat<C::FMT>(v[0], v[1]);
+                                    o[0].y = pack2_sat<C::FMT>(v[2], v[3]);
+                                    o[0].z = pack2_sat<C::FMT>(v[4], v[5]);
+                                    o[0].w = pack2_sat<C::FMT>(v[6], v[7]);
+                                    o[1] = o[0];
+                                }
                             } else {
                                 split_bf16x2(v[0], v[1], o[0].x, o[1].x);
                                 split_bf16x2(v[2], v[3], o[0].y, o[1].y);
@@ -414,12 +421,13 @@ static int launch_big_cfg(const GemmParams& p, hipStream_t s) {
 
 template <int EPI>
 static int launch_big_one(const GemmParams& p, hipStream_t s) {
-    if (p.planes == 2) return launch_big_cfg<EPI, big::Cfg128x384x2>(p, s);
     if (p.fmt == FMT_FP16) {
-        if constexpr (EPI == EPI_RESID || EPI == EPI_GELU || EPI == EPI_QKV) return launch_big_cfg<EPI, big::Cfg256x384h>(p, s);
+        if constexpr (EPI == EPI_RESID || EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_RELU)
+            return p.planes == 2 ? launch_big_cfg<EPI, big::Cfg128x384x2h>(p, s) : launch_big_cfg<EPI, big::Cfg256x384h>(p, s);
         dinoseg_set_error("gemm_big: the fp16 operand format covers the inference epilogues only (epi=%d)", (int)EPI);
         return -1;
     }
+    if (p.planes == 2) return launch_big_cfg<EPI, big::Cfg128x384x2>(p, s);
 #ifdef BIG_12WAVES      // experiment: three waves per SIMD, 192 x 384 tile (3 x 4 waves of 64 x 96)
     return launch_big_cfg<EPI, big::Cfg<3, 4, 2, 3, 3, 1>>(p, s);
 #else

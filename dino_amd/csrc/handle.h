@@ -32,7 +32,7 @@ struct PackedLinear {       // W[N,K] operand planes of one nn.Linear, padded to
 struct dinoseg_handle {
     dinoseg_config cfg;
     int planes;
-    int fmt = 0;                // operand format of the single-plane kernels: FMT_BF16 / FMT_FP16 (DINOSEG_FP16: planes = 1, fmt = FMT_FP16)
+    int fmt = 0;                // operand format: FMT_BF16 / FMT_FP16 (DINOSEG_FP16: planes = 1, DINOSEG_FP16X3: planes = 2, both fmt = FMT_FP16)
     int device = -1;            // ordinal of the GPU that owns the bound tensors (set by the first dinoseg_bind_weight)
     std::map<std::string, BoundTensor> bound;
     std::map<std::string, std::vector<int64_t>> expected;
@@ -47,6 +47,7 @@ struct dinoseg_handle {
     bool packed_mlp_stale = false;         // the fragment-order packs are made on the first forward that uses them (the fine-tune
                                            // step refreshes the weights every step and never runs the fused MLP kernel)
     bool weights_ready = false;
+    int64_t generation = 0;     // dinoseg_state_generation: bumped when an address or cached content a captured forward bakes in changes
     // pos-embed cache
     float* pos_cache = nullptr;
     int pos_r = -1;
@@ -145,7 +146,10 @@ static inline void prof_end(dinoseg_handle* h, int idx, hipStream_t s) {
 static inline int head_planes() { return 2; }
 // planes of the patch-embedding GEMM: the mode's own, except that the fp16 mode runs it split like the head (raw pixel operands,
 // 0.13 % of the FLOPs)
-static inline int patch_planes(const dinoseg_handle* h) { return h->fmt == FMT_FP16 ? 2 : h->planes; }   // the classifier head always runs in split precision (it is tiny)
+static inline int patch_planes(const dinoseg_handle* h) { return h->fmt == FMT_FP16 ? 2 : h->planes; }
+// format of the split (two-plane) operands of the patch embedding and the head: fp16 only in the fp16 hi+lo mode -- the single-plane
+// fp16 mode keeps them bf16 hi+lo (their error is far below that mode's)
+static inline int split_fmt(const dinoseg_handle* h) { return h->planes == 2 ? h->fmt : (int)FMT_BF16; }   // the classifier head always runs in split precision (it is tiny)
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline const float* W(const dinoseg_handle* h, const std::string& k) { return h->bound.at(k).ptr; }
 static inline void norm_consts(float mean255[3], float inv255[3]) {

@@ -30,8 +30,9 @@ struct GemmParams {
     int n_valid;                                // ATOMIC: only columns < n_valid are written (0 = all N)
     int dbg;                                    // timing-only ablations: bit0 skip epilogue stores, bit1 skip steady-state loads
     int planes;                                 // 1: bf16 ; 2: bf16 hi+lo split (3 MFMAs per product)
-    int fmt;                                    // planes == 1 only: 0 = bf16 operands, 1 = fp16 (FMT_FP16: A, W and the bf16_t outputs of
-                                                // GELU / QKV; EPI_QKV still writes V as bf16 -- the P.V product of the attention stays bf16)
+    int fmt;                                    // operand format: 0 = bf16, 1 = fp16 (FMT_FP16: A, W and the 16-bit outputs of GELU / RELU / QKV).
+                                                // One fp16 plane: EPI_QKV still writes V as bf16 (the fast attention's P.V product stays bf16);
+                                                // fp16 hi+lo planes (planes == 2): every plane is fp16.  Inference epilogues only
     int epi;
     const float* bias;                          // [N] or null
     float* out_f32; int ldo_f32;                // PLAIN / RESID / PATCH
@@ -65,7 +66,7 @@ struct LnGemmParams {
     bf16_t* a_out; long a_plane;                // optional: the normalised planes [planes][M][K] (training: weight gradients)
     bf16_t* aux_out; long aux_plane;            // optional (GELU): pre-activation planes [planes][M][ldo] (training: gelu')
     int dbg;                                    // timing-only ablations (wrong results): 1 skip epilogue, 2 skip W DMA, 4 skip LN prologue
-    int fmt;                                    // planes == 1 only: operand format (FMT_BF16 / FMT_FP16), as GemmParams::fmt
+    int fmt;                                    // operand format (FMT_BF16 / FMT_FP16), as GemmParams::fmt
 };
 bool gemm_ln_supported(int K, int N, int planes, int epi, int dmodel);
 long gemm_ln_slab_elems(int N, int K, int planes);      // bf16 elements of the slab-major copy of W [N][K]
@@ -137,8 +138,9 @@ struct AttnParams {
     int B, heads, ntok, npad, planes;
     int dbg;                           // timing-only ablations: bit0 skip max/exp, bit1 skip steady-state loads, bit2 skip PV
     int shared_gpu;                    // hint: another stream's kernels run beside this launch (the split forward): prefer wide workgroups
-    int fmt;                           // planes == 1 only: FMT_FP16 = Q, K and ctx are fp16 (V and the probabilities stay bf16: 2^S against the
-                                       // fixed reference 0 needs bf16's exponent range); attention_z.hip only
+    int fmt;                           // FMT_FP16, one plane (attention_z.hip): Q, K and ctx are fp16, V and the probabilities stay bf16 (2^S against
+                                       // the fixed reference 0 needs bf16's exponent range); hi+lo planes (attention.hip): everything fp16, the
+                                       // probabilities bounded by the running reference (<= 2^15)
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
 int launch_attention_z(const AttnParams& p, hipStream_t s);    // zero-reference softmax, <= 128 registers: 4 waves per SIMD (attention_z.hip)
@@ -156,7 +158,7 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, floa
 // Patch gather ("im2col") for the 8x8/stride-8 patch embedding. k index = c*64 + ky*8 + kx.
 // kind 0: uint8 HWC frames [B,r,r,3] with the ImageNet normalisation fused; kind 1: fp32 CHW [B,3,r,r] as is.
 int launch_patch_gather(const void* x, int kind, int B, int r, const float* mean255, const float* inv_std255,
-                        bf16_t* out, long out_plane, int planes, hipStream_t s);
+                        bf16_t* out, long out_plane, int planes, hipStream_t s, int fmt = 0);
 
 // X[b*ntok + 0, :] = cls[:] + pos[0, :]
 int launch_cls_rows(float* X, const float* cls, const float* pos, int B, int ntok, int D, hipStream_t s);
@@ -166,7 +168,7 @@ int launch_pos_resample(const float* pos_embed, int g, int D, int o, float* out,
 
 // Final classifier layer + log_softmax + argmax.  in: bf16 hi/lo planes [2][M][ld]; W fp32 [C][K]; C <= 32.
 int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, const float* W, const float* b, int C,
-                      float* logp, int32_t* argmax, hipStream_t s);
+                      float* logp, int32_t* argmax, hipStream_t s, int fmt = 0);
 
 // materialised softmax(q k^T) of one block, fp32 [B,H,ntok,ntok] (get_last_selfattention; visualisation only)
 int launch_attn_probs(const bf16_t* q, const bf16_t* k, long plane, int planes, int B, int heads, int ntok, int npad, float* out,
@@ -222,7 +224,7 @@ int launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, 
 struct PackJob {
     const float* src; bf16_t* dst; long plane;
     int rows, cols, rows_pad, cols_pad, planes, transposed;
-    int fmt = 0;                    // planes == 1 only: FMT_BF16 / FMT_FP16
+    int fmt = 0;                    // FMT_BF16 / FMT_FP16
 };
 int launch_multi_pack(const PackJob* jobs, int count, hipStream_t s);
 // fp32 [rows, cols] -> TRANSPOSED bf16 planes [planes][cols_pad][rows_pad] (zero padded): W^T operands for dgrad

@@ -683,33 +683,48 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         return s_zero(lane_p, sB1);
     };
     // ---- the GELU of S(s), spread over the 24 MFMA gaps of the step (+ a tail slot): element n (accumulator register n) starts
-    // at slot (14 n) / 15 and issues instruction i of gelu_fast (common.h) at slot start + i; odd elements pack a dword at + 10
+    // at slot (14 n) / 15 and issues instruction i of the GELU at slot start + i; odd elements pack a dword behind their last one.
+    // (measured and not kept, round 4: the two-coefficient logistic form x / (1 + 2^(x (c1 + c3 x^2))) -- 7 instructions instead of 9, no
+    // clamp, |error| <= 2.7e-4 against 2.6e-5 -- takes 19 % of this wave's vector instructions away and 1.5 % off the launch: 4.355 ->
+    // 4.29 ms per 32-frame step, +0.3 % frames/s.  The step is not bound by wave A's instruction count.)
+#define MF2_GELU2 0
+    constexpr int GELU_LAST = MF2_GELU2 ? 8 : 10;      // slot offset of the pack
     float ex[16], ea[16], eb[16], ec[16];
     uint32_t pd[8];
     auto gelu_op = [&](auto n_tag, auto i_tag, const f32x16& s) __attribute__((always_inline)) {
         constexpr int N = decltype(n_tag)::value, I = decltype(i_tag)::value;
         if constexpr (I == 0) ex[N] = s[N];
         if (MF2_ABL & 1) {
-            if constexpr (I == 10 && (N & 1)) pd[N >> 1] = pack2<FMT>(ex[N - 1], ex[N]);
+            if constexpr (I == GELU_LAST && (N & 1)) pd[N >> 1] = pack2<FMT>(ex[N - 1], ex[N]);
             return;
         }
-        if constexpr (I == 1) ea[N] = __builtin_amdgcn_fmed3f(ex[N], -8.0f, 8.0f);
-        if constexpr (I == 2) eb[N] = ea[N] * ea[N];
-        if constexpr (I == 3) ec[N] = fmaf(1.01537542e-3f, eb[N], -1.06782573e-1f);
-        if constexpr (I == 4) ec[N] = fmaf(ec[N], eb[N], -2.30111381f);
-        if constexpr (I == 5) ec[N] = ec[N] * ea[N];
-        if constexpr (I == 6) ec[N] = __builtin_amdgcn_exp2f(ec[N]);
-        if constexpr (I == 7) ec[N] = 1.0f + ec[N];
-        if constexpr (I == 8) ec[N] = __builtin_amdgcn_rcpf(ec[N]);
-        if constexpr (I == 9) ex[N] = ex[N] * ec[N];
-        if constexpr (I == 10 && (N & 1)) pd[N >> 1] = pack2<FMT>(ex[N - 1], ex[N]);
+        if constexpr (MF2_GELU2) {
+            if constexpr (I == 1) eb[N] = ex[N] * ex[N];
+            if constexpr (I == 2) ec[N] = fmaf(-1.00125610e-1f, eb[N], -2.30876530f);      // -(1.60031416, 6.940179e-2) * log2(e)
+            if constexpr (I == 3) ec[N] = ec[N] * ex[N];
+            if constexpr (I == 4) ec[N] = __builtin_amdgcn_exp2f(ec[N]);
+            if constexpr (I == 5) ec[N] = 1.0f + ec[N];
+            if constexpr (I == 6) ec[N] = __builtin_amdgcn_rcpf(ec[N]);
+            if constexpr (I == 7) ex[N] = ex[N] * ec[N];
+        } else {
+            if constexpr (I == 1) ea[N] = __builtin_amdgcn_fmed3f(ex[N], -8.0f, 8.0f);
+            if constexpr (I == 2) eb[N] = ea[N] * ea[N];
+            if constexpr (I == 3) ec[N] = fmaf(1.01537542e-3f, eb[N], -1.06782573e-1f);
+            if constexpr (I == 4) ec[N] = fmaf(ec[N], eb[N], -2.30111381f);
+            if constexpr (I == 5) ec[N] = ec[N] * ea[N];
+            if constexpr (I == 6) ec[N] = __builtin_amdgcn_exp2f(ec[N]);
+            if constexpr (I == 7) ec[N] = 1.0f + ec[N];
+            if constexpr (I == 8) ec[N] = __builtin_amdgcn_rcpf(ec[N]);
+            if constexpr (I == 9) ex[N] = ex[N] * ec[N];
+        }
+        if constexpr (I == GELU_LAST && (N & 1)) pd[N >> 1] = pack2<FMT>(ex[N - 1], ex[N]);
     };
     auto valu_slot = [&](auto g_tag, const f32x16& s) __attribute__((always_inline)) {
         constexpr int G = decltype(g_tag)::value;
         mf_for(std::make_integer_sequence<int, 16>{}, [&](auto n_tag) __attribute__((always_inline)) {
             constexpr int N = decltype(n_tag)::value;
             constexpr int SG = (14 * N) / 15;
-            if constexpr (G >= SG && G - SG <= 10) gelu_op(n_tag, std::integral_constant<int, G - SG>{}, s);
+            if constexpr (G >= SG && G - SG <= GELU_LAST) gelu_op(n_tag, std::integral_constant<int, G - SG>{}, s);
         });
     };
 

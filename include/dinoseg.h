@@ -33,8 +33,12 @@ typedef struct dinoseg_handle dinoseg_handle;
  *                    v_mfma_f32_32x32x16_f16; the probabilities and V (the P.V product) stay bf16 -- 2^S against the fixed
  *                    reference 0 needs bf16's exponent range; the patch embedding and the head run split (bf16 hi+lo).
  *                    ~6x closer to the reference than DINOSEG_BF16 at the same speed; inference only (the fine-tune
- *                    entry points refuse it: fp16 gradients would need loss scaling). */
-enum { DINOSEG_BF16 = 0, DINOSEG_BF16X3 = 1, DINOSEG_FP16 = 2 };
+ *                    entry points refuse it: fp16 gradients would need loss scaling).
+ *   DINOSEG_FP16X3 : fp16 hi+lo operand pairs everywhere (patch embedding and head included), 3 MFMAs per product at the
+ *                    bf16x3 rate, ~22 significand bits instead of ~16: the parity mode with margin (2x closer to the reference
+ *                    than DINOSEG_BF16X3 on the goldens, ~8x on ill-conditioned weights -- outlier channels, sharp heads);
+ *                    values beyond +-65504 saturate; inference only. */
+enum { DINOSEG_BF16 = 0, DINOSEG_BF16X3 = 1, DINOSEG_FP16 = 2, DINOSEG_FP16X3 = 3 };
 enum { DINOSEG_HEAD_LINEAR = 0, DINOSEG_HEAD_MLP = 1 };
 enum { DINOSEG_INPUT_U8_HWC = 0,      /* uint8 [B,r,r,3] frames; ImageNet normalisation fused on device   */
        DINOSEG_INPUT_F32_CHW = 1 };   /* fp32  [B,3,r,r] already-normalised tensor (DINOSeg.forward input) */
@@ -52,7 +56,7 @@ typedef struct dinoseg_config {
     int32_t head_kind;    /* DINOSEG_HEAD_*  (pl_torch_modules.py:219-222)                       */
     int32_t pos_grid;     /* 28: stored pos_embed is [1, 28*28+1, D]                             */
     float   ln_eps;       /* 1e-6 (vision_transformer.py:303)                                    */
-    int32_t precision;    /* DINOSEG_BF16 / DINOSEG_BF16X3 / DINOSEG_FP16                        */
+    int32_t precision;    /* DINOSEG_BF16 / DINOSEG_BF16X3 / DINOSEG_FP16 / DINOSEG_FP16X3       */
 } dinoseg_config;
 
 const char* dinoseg_last_error(void);
@@ -201,6 +205,11 @@ int dinoseg_set_option(const char* key, int32_t value);
 
 /* Bytes of library-owned device memory a (B, r) forward needs (activations + packed weights). */
 int64_t dinoseg_workspace_bytes(const dinoseg_handle* h, int32_t B, int32_t r);
+/* Counts the events that invalidate device addresses or cached contents a CAPTURED dinoseg_forward has baked in: a re-allocation of
+ * the activation workspace or of the packed weights, a re-computation of the resampled position embedding (another resolution).
+ * A caller that replays a HIP graph of the forward compares it with the value read after the capture and re-captures on a change
+ * (DINOSeg.predict does: pl_torch_modules.py:276-300 is a single-frame call, launch-bound when issued kernel by kernel). */
+int64_t dinoseg_state_generation(const dinoseg_handle* h);
 
 /* ---- stand-alone operators (same kernels the forward uses; exported for unit parity tests) ------------- */
 

