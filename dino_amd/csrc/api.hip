@@ -455,7 +455,7 @@ struct MaskRequest {            // forward_mask / get_last_selfattention(x, cls_
 static bool mlp_fuse_wanted(const dinoseg_handle* h, long rows) {
     return !h->packed_mlp.empty() && (options().mlp_fused == 2 || (options().mlp_fused == 1 && rows >= options().mlp_fused_min_rows));
 }
-// fragment-order MLP weights (mlp_fused.hip), packed on first use after a weight refresh
+// fragment-order MLP weights (mlp_fused2.hip), packed on first use after a weight refresh
 static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s) {
     if (!h->packed_mlp_stale) return 0;
     const int Dm = h->cfg.embed_dim, Fh = h->cfg.embed_dim * h->cfg.mlp_ratio;
@@ -618,8 +618,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
         }
         const bool fuse_mlp = h->packed_mlp.count(b) && mlp_fuse_wanted(h, disp_M);
         // (the role-split fused MLP kernel takes the attention output projection along: x += proj(ctx) + b, then the MLP, one launch)
-        const bool variant1 = options().mlp_variant == 1 && FM == FMT_BF16;      // (mlp_fused.hip knows bf16 only)
-        const bool fuse_proj = fuse_mlp && options().proj_fused && !variant1 && P == 1 && h->packed_proj.count(b);
+        const bool fuse_proj = fuse_mlp && options().proj_fused && P == 1 && h->packed_proj.count(b);
         if (!fuse_proj) {
             const PackedLinear& pk = h->packed.at(b + "attn.proj.weight");
             GemmParams g = {};
@@ -632,7 +631,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
         }
         if (fuse_mlp) {
             DSEG_TRY(ensure_mlp_packs(h, s));      // (a split forward has done this before its fork)
-            // LN2 + fc1 + GELU + fc2 + residual in one launch: the hidden activation never reaches HBM (mlp_fused.hip)
+            // LN2 + fc1 + GELU + fc2 + residual in one launch: the hidden activation never reaches HBM (mlp_fused2.hip)
             MlpFusedParams g = {};
             g.X = X; g.ldx = D; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
             g.Wp = h->packed_mlp.at(b); g.b1 = W(h, b + "mlp.fc1.bias"); g.b2 = W(h, b + "mlp.fc2.bias");
@@ -648,7 +647,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
                     qkv_ready = true;
                 }
             }
-            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(variant1 ? launch_mlp_fused(g, s) : launch_mlp_fused2(g, s)));
+            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_mlp_fused2(g, s)));
         } else {
         if (fuse_ln && h->packed_slab.count(b + "mlp.fc1.weight") && L.hb_plane < (1L << 31)) {
             LnGemmParams g = {};
@@ -872,10 +871,7 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().train_streams = value;
         return 0;
     }
-    if (strcmp(key, "mlp_variant") == 0) {
-        dseg::options().mlp_variant = value;
-        return 0;
-    }
+    if (strcmp(key, "mlp_variant") == 0) return 0;      // (accepted and ignored: the one-wave-per-SIMD build was removed in round 4)
     if (strcmp(key, "mlp_fused_min_rows") == 0) {
         dseg::options().mlp_fused_min_rows = value;
         return 0;
@@ -994,8 +990,7 @@ extern "C" int dinoseg_op_mlp_fused(float* X, const float* gamma, const float* b
     MlpFusedParams g = {};
     g.X = X; g.ldx = D; g.gamma = gamma; g.beta = beta; g.eps = eps;
     g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M; g.fmt = options().op_fmt;
-    return options().mlp_variant == 1 && g.fmt == FMT_BF16 ? launch_mlp_fused(g, reinterpret_cast<hipStream_t>(stream))
-                                                           : launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
+    return launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t dinoseg_op_proj_pack_elems(int32_t D) { return mlp_fused_proj_pack_elems(D); }

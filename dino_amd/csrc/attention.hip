@@ -393,9 +393,6 @@ int launch_attention(const AttnParams& p0, hipStream_t s) {
     if (p.dbg != 0 && p.planes == 1) return launch_attn<1, 4, true, 0>(p, s);      // ablation build (tools/bench_ops.py)
     if (p.planes == 1 && (options().attn_variant & 8)) return launch_attention_z(p, s);      // zero-reference, 4 waves / SIMD
     if (p.planes == 2 && (options().attn_variant & 16)) return launch_attention_z(p, s);     // (hi + lo planes: experiment)
-#ifdef DSEG_EXPERIMENTS      // make EXPERIMENTS=1: the software-pipelined kernel (experiments/attention_pipe.hip; measured, not adopted)
-    if (p.planes == 1 && (options().attn_variant & 4)) return launch_attention_pipe(p, s);
-#endif
     if (p.planes == 1) return launch_attn_planes<1>(p, s);
     if (p.planes == 2) return launch_attn_planes<2>(p, s);
     dinoseg_set_error("attention: planes must be 1 or 2");

@@ -41,7 +41,7 @@ struct dinoseg_handle {
     size_t wbuf_bytes = 0;
     std::map<std::string, PackedLinear> packed;
     std::map<std::string, bf16_t*> packed_slab;     // slab-major copies of the LN-fed weights (gemm_ln.hip), when supported
-    std::map<std::string, bf16_t*> packed_mlp;      // per block ("dino.blocks.i."): fc1 + fc2 in MFMA fragment order (mlp_fused.hip)
+    std::map<std::string, bf16_t*> packed_mlp;      // per block ("dino.blocks.i."): fc1 + fc2 in MFMA fragment order (mlp_fused2.hip)
     std::map<std::string, bf16_t*> packed_proj;     // per block: attn.proj.weight in the same fragment order (mlp_fused2.hip, PROJ)
     std::map<std::string, bf16_t*> packed_qkvf;     // per block: attn.qkv.weight in fragment order (mlp_fused2.hip, QKV tail of the block before)
     bool packed_mlp_stale = false;         // the fragment-order packs are made on the first forward that uses them (the fine-tune

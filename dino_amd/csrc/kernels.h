@@ -73,14 +73,14 @@ long gemm_ln_slab_elems(int N, int K, int planes);      // bf16 elements of the 
 int launch_pack_slabs(const float* src, int N, int K, int planes, bf16_t* dst, hipStream_t s, int fmt = 0);
 int launch_gemm_ln(const LnGemmParams& p, int K, int planes, hipStream_t s);
 
-// Fused MLP of one transformer block, bf16 mode, D = 384 (mlp_fused.hip): X += fc2(gelu(fc1(LayerNorm(X))))   in place
+// Fused MLP of one transformer block, single-plane modes, D = 384 (mlp_fused2.hip): X += fc2(gelu(fc1(LayerNorm(X))))   in place
 struct MlpFusedParams {
     float* X; int ldx;                          // residual stream [M, 384] fp32
     const float* gamma; const float* beta; float eps;
     const bf16_t* Wp;                           // both weights in MFMA fragment order (launch_pack_mlp)
     const float* b1; const float* b2;           // [1536], [384]
     int M;
-    int* queue;                                 // set by launch_mlp_fused: work counter of the persistent walk (zeroed per launch)
+    int* queue;                                 // (diagnostic builds: MF2_STAMP buffer)
     int n_long, sleep_max;                      // set by launch_mlp_fused2: start-time spread of the workgroups with one item fewer
     // optional (mlp_fused2 only): the block's attention output projection in the same launch, X += ctx . Wproj^T + bproj first
     const bf16_t* ctx;                          // [M, 384] bf16 attention output (row stride 384), null = MLP only
@@ -101,7 +101,6 @@ int launch_pack_proj(const float* W, int D, bf16_t* dst, hipStream_t s, int fmt 
 bool mlp_fused_supported(int D, int F, int planes);
 long mlp_fused_pack_elems(int D, int F);        // bf16 elements of the packed copy (0: unsupported shape)
 int launch_pack_mlp(const float* W1, const float* W2, int D, int F, bf16_t* dst, hipStream_t s, int fmt = 0);
-int launch_mlp_fused(const MlpFusedParams& p, hipStream_t s);      // one wave per SIMD (mlp_fused.hip)
 int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s);     // role-split wave pairs, two waves per SIMD (mlp_fused2.hip)
 
 // tuning knobs (dinoseg_set_option): see api.hip
@@ -110,14 +109,13 @@ struct Options {
     int gemm_big = 1;        // use gemm_big.hip where it applies
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
     int attn_dbg = 0;        // same for AttnParams::dbg
-    int mlp_fused = 1;       // the MLP half of a block as one launch (mlp_fused.hip): 0 never, 1 for >= mlp_fused_min_rows rows, 2 wherever supported
+    int mlp_fused = 1;       // the MLP half of a block as one launch (mlp_fused2.hip): 0 never, 1 for >= mlp_fused_min_rows rows, 2 wherever supported
     int mlp_fused_min_rows = 12000;      // (4 frames @480: +3 %; 6 frames: +18 % with the projection inside; 2 frames: even)
     int mlp_stagger = 0;     // experiment: > 0 = one workgroup per CU, those with one item fewer start up to this many x 3.9 us late
     int mlp_grid = 0;        // workgroups of the fused MLP launch (0 = the fewest that need no extra round: mlp_fused2.hip)
     int qkv_fused = 0;       // 1: ... and LayerNorm1 + qkv of the NEXT block at its end (blocks 1.. then have no LN+qkv launch); measured
                              // +1 % on one stream, +-0 on two: the tail is bound by the same HBM write burst as the launch it replaces
-    int proj_fused = 1;      // 1: with mlp_variant 2 the block's attention output projection runs inside the fused MLP launch
-    int mlp_variant = 2;     // 1: mlp_fused.hip (one wave per SIMD), 2: mlp_fused2.hip (role-split wave pairs)
+    int proj_fused = 1;      // 1: the block's attention output projection runs inside the fused MLP launch
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 8;       // (8 frames @480: +6 %, 12: +16 %, 16: +12 %; 6 frames and fewer: slower split)
     int op_fmt = 0;          // operand format (FMT_BF16 / FMT_FP16) of the single-plane stand-alone ops (dinoseg_op_*: tests, tools); a
@@ -125,7 +123,7 @@ struct Options {
     int train_streams = 2;   // 2: backward runs the weight-gradient GEMMs of the blocks on the handle's side stream (train_api.hip)
     int splitk_tiles = 512;  // weight-gradient GEMMs: partial 128x128 tiles per launch (<= 768, the workspace holds that many)
     int attn_variant = 11;   // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
-                             // tile work; bit 2 (bf16 mode): the software-pipelined kernel (attention_pipe.hip); bit 3 (bf16 mode):
+                             // tile work; bit 2: unused (round 1-3's software-pipelined kernel, removed); bit 3 (bf16 mode):
                              // the zero-reference kernel, four waves per SIMD (attention_z.hip)
 };
 Options& options();
@@ -144,7 +142,6 @@ struct AttnParams {
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
 int launch_attention_z(const AttnParams& p, hipStream_t s);    // zero-reference softmax, <= 128 registers: 4 waves per SIMD (attention_z.hip)
-int launch_attention_pipe(const AttnParams& p, hipStream_t s); // bf16 only: software-pipelined across tiles (attention_pipe.hip)
 
 // fp32 [rows, cols] -> bf16 planes [planes][rows_pad][cols_pad], zero padded
 int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,

@@ -1,4 +1,4 @@
-// Shared by the two fused-MLP kernels (mlp_fused.hip: one wave per SIMD; mlp_fused2.hip: role-split wave pairs): the packed
+// Constants and inline-asm helpers of the fused MLP kernel (mlp_fused2.hip; round 3 had a second build on them): the packed
 // weight format and the inline-asm helpers of the explicit MFMA-gap schedules.
 #pragma once
 #include <type_traits>

@@ -1,11 +1,25 @@
 // Fused transformer MLP, bf16 mode, ViT-S width -- role-split wave pairs (two waves per SIMD).
 //     x += fc2(gelu(fc1(LayerNorm2(x))))      (vision_transformer.py:135 -> :59-65)
 //
-// Same arithmetic, same packed weights and the same per-tile dataflow as mlp_fused.hip (read its header first).  What that kernel
-// showed (profiles/r03_mlp_ablation.md): with ONE wave per SIMD everything the wave issues besides its MFMAs -- 12 LDS-DMA
-// pieces, 48 fragment reads, ~170 vector instructions of GELU per tile -- is serial with them (in-order issue: 55 cycles per MFMA
-// gap instead of 32; the bare MFMA stream alone runs at the pipe's rate).  Here the work of a 32-row block is split between TWO
-// waves that share a SIMD, so one wave's memory / vector issue overlaps the other's matrix work:
+// One launch per block instead of LN+fc1+GELU and fc2+residual: the [M, 1536] hidden activation never exists in HBM (it was 31 % of a
+// layer's bytes), and the residual stream is read once and written once (it is the accumulators' initial value).  Skeleton = the
+// attention kernel's (attention_z.hip): a W1 tile of 32 hidden units plays K, the matching W2^T tile plays V, GELU plays exp, and
+// the fc1 accumulator IS the B operand of the fc2 product.  Per 32-row block, resident in registers for a whole 128-row item:
+//   xn[24]  LayerNorm2(x) as B-operand fragments (k = 16 s + 8 h + j on lane (row, h)): 96 registers
+//   o[12]   out^T[384][32] accumulators, initialised with x + b2 (the residual): 192 registers
+// per hidden tile t (48 of them): S^T[32 hid][32 rows] = W1_t . xn^T + b1_t (24 MFMAs), P = gelu(S) (16 values per lane),
+// o^T += W2^T_t . P^T (24 MFMAs).  Weights: both matrices are re-packed once (launch_pack_mlp, below) in exactly the order the MFMAs
+// consume them -- [tile][48 fragments][64 lanes][8], W1 rows and W2 output rows permuted by sigma23 (bits 2 <-> 3) so that accumulator
+// registers 8s..8s+7 of a lane hold 8 consecutive k of the next product -- a fragment is one linear 1-KiB LDS-DMA piece and one
+// conflict-free ds_read_b128.  Every tile step is written out as explicit MFMA "gaps" (template-unrolled): the compiler's own order,
+// with or without sched_group_barrier, left the matrix pipe idle ~2/3 of the time.
+//
+// Round 3's first build of this (one wave per SIMD, 4 waves per workgroup with the whole 512-register file each; removed in round 4,
+// `git log -- dino_amd/csrc/mlp_fused.hip`) showed (profiles/r03_mlp_ablation.md): with ONE wave per SIMD everything the wave issues
+// besides its MFMAs -- 12 LDS-DMA pieces, 48 fragment reads, ~170 vector instructions of GELU per tile -- is serial with them (in-order
+// issue: 55 cycles per MFMA gap instead of 32; the bare MFMA stream alone runs at the pipe's rate): 340-375 us per layer against this
+// kernel's 305-310.  Here the work of a 32-row block is split between TWO waves that share a SIMD, so one wave's memory / vector
+// issue overlaps the other's matrix work:
 //   wave A ("fc1")  holds xn = LayerNorm2(x) of the 32 rows (96 registers).  Tile step s: S(s+1)^T = W1_{s+1} . xn^T + b1
 //                   (24 MFMAs, fragments from the W1 ring) while the GELU of S(s) runs on the vector unit; P(s) = bf16(gelu(S(s)))
 //                   goes to a 2-KiB LDS buffer in B-operand fragment order (two ds_write_b128 per lane).
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++item_k) {
             if (wave == 4) MF2_ST(1, item_k, 0);
             // per-lane constants from an opaque lane id, once per item (values that live across the item loop get spilled, and a
-            // scratch reload inside the step loop drains the weight ring: see mlp_fused.hip)
+            // scratch reload inside the step loop drains the weight ring: round 3)
             uint32_t zero = 0;
             asm volatile("" : "+v"(zero));
             const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
@@ -922,6 +936,43 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
         if (wave == 0) MF2_ST(0, item_k, 7);
     }
 }
+
+// W1 [1536][384], W2 [384][1536] fp32 -> fragments [hidden tile][24 fc1 fragments, 24 fc2 fragments][64 lanes][8] in the operand format
+__global__ __launch_bounds__(256) void pack_mlp_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
+                                                       bf16_t* __restrict__ dst, long total, int fmt) {
+    using namespace mfc;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long t = idx;
+        const int e = (int)(t & 7); t >>= 3;
+        const int lane = (int)(t & 63); t >>= 6;
+        const int frag = (int)(t % (2 * NKS));
+        const int tile = (int)(t / (2 * NKS));
+        const int i = attn::sigma23(lane & 31), h = lane >> 5;
+        float v;
+        if (frag < NKS) {        // fc1: A row = hidden unit, k = input feature
+            v = W1[(long)(tile * HT + i) * D + frag * 16 + h * 8 + e];
+        } else {                 // fc2: A row = output feature, k = hidden unit of this tile
+            const int f2 = frag - NKS, db = f2 >> 1, s2 = f2 & 1;
+            v = W2[(long)(db * 32 + i) * F + tile * HT + s2 * 16 + h * 8 + e];
+        }
+        dst[idx] = pack1(v, fmt);
+    }
+}
+
+long mlp_fused_pack_elems(int Dm, int Fh) { return Dm == mfc::D && Fh == mfc::F ? (long)mfc::NT * mfc::TILE_BYTES / 2 : 0; }
+
+int launch_pack_mlp(const float* W1, const float* W2, int Dm, int Fh, bf16_t* dst, hipStream_t s, int fmt) {
+    const long total = mlp_fused_pack_elems(Dm, Fh);
+    if (total <= 0) {
+        dinoseg_set_error("pack_mlp: unsupported shape D=%d F=%d", Dm, Fh);
+        return -1;
+    }
+    hipLaunchKernelGGL(pack_mlp_kernel, dim3(2048), dim3(256), 0, s, W1, W2, dst, total, fmt);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+bool mlp_fused_supported(int Dm, int Fh, int planes) { return Dm == mfc::D && Fh == mfc::F && planes == 1; }
 
 // Wproj [384 out][384 in] fp32 -> bf16 fragments [k-tile kt][fragment db * 2 + s2][lane][8]: the fc2 fragment format of pack_mlp with
 // the 32 input features of k-tile kt in the place of a hidden tile (A row = output feature 32 db + sigma23(lane & 31))

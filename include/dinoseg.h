@@ -195,7 +195,7 @@ int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
  *                (x += proj(ctx) + b first: vision_transformer.py:104-105), 0 = the projection stays a GEMM launch of its own;
  *   "qkv_fused"  0 [default] / 1 = ... and LayerNorm1 + qkv of the next block at its end (blocks 1.. have no LN + qkv launch then:
  *                +1 % frames/s on one stream, none on two -- the tail writes Q / K / V in the same HBM burst as the launch it replaces);
- *   "mlp_variant" 2 [default] = the role-split build of the fused MLP kernel (mlp_fused2.hip), 1 = one wave per SIMD (mlp_fused.hip);
+ *   "mlp_variant" accepted and ignored (the one-wave-per-SIMD build of the fused MLP kernel was removed in round 4);
  *   "train_streams" 2 [default] = dinoseg_backward / dinoseg_train_step run the blocks' weight-gradient GEMMs on an internal stream
  *                beside the input-gradient chain (forked from / joined to the caller's stream by events: stream-ordered, capturable),
  *                1 = everything on the caller's stream (use it when several processes share one GPU);

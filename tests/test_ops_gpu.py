@@ -450,10 +450,9 @@ def pack_mlp(W1: torch.Tensor, W2: torch.Tensor) -> torch.Tensor:
     return out
 
 
-@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("M_", [128, 77, 128 * 5 + 33, 128 * 300 + 19])
-def test_mlp_fused(cuda, M_, variant):
-    """LN2 + fc1 + GELU + fc2 + residual in one launch (mlp_fused.hip), bf16 operands: against fp64 on the operands the kernel
+def test_mlp_fused(cuda, M_):
+    """LN2 + fc1 + GELU + fc2 + residual in one launch (mlp_fused2.hip), bf16 operands: against fp64 on the operands the kernel
     sees (bf16 LayerNorm output, bf16 weights, bf16 GELU output).  M = 38 419: more items than CUs (persistent walk, the weight
     ring running on across items), ragged last item; M = 77: one partial item."""
     D_, F_ = 384, 1536
@@ -465,13 +464,9 @@ def test_mlp_fused(cuda, M_, variant):
     b2 = seeded((D_,), 37)
     Wp = pack_mlp(W1, W2)
     got = X.clone()
-    capi.check(capi.lib().dinoseg_set_option(b"mlp_variant", variant))     # 1: one wave per SIMD; 2: role-split wave pairs (default)
-    try:
-        capi.check(capi.lib().dinoseg_op_mlp_fused(got.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(),
-                                                   b2.data_ptr(), M_, D_, F_, S()))
-        torch.cuda.synchronize()
-    finally:
-        capi.check(capi.lib().dinoseg_set_option(b"mlp_variant", 2))
+    capi.check(capi.lib().dinoseg_op_mlp_fused(got.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(),
+                                               b2.data_ptr(), M_, D_, F_, S()))
+    torch.cuda.synchronize()
     A = quant_like(_ln_ref(X, gam, bet).cuda(), 1).double()
     z = A @ quant_like(W1, 1).double().t() + b1.double()
     Hq = quant_like(O.gelu_erf(z.float().cpu()).cuda(), 1).double()

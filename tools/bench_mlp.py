@@ -1,5 +1,5 @@
 """GPU box: time the fused MLP operator alone: python tools/bench_mlp.py [rows] [iters] [variant]
-(variant 1 = mlp_fused.hip, 2 = mlp_fused2.hip, 3 = mlp_fused2.hip with the attention output projection in the same launch, 4 = ... and LayerNorm1 + qkv of the next block, 0 = the
+(variant 2 = mlp_fused2.hip (1 is accepted for old command lines: the same kernel), 3 = mlp_fused2.hip with the attention output projection in the same launch, 4 = ... and LayerNorm1 + qkv of the next block, 0 = the
 separate projection GEMM (dinoseg_op_gemm EPI_RESID); DINOSEG_LIB selects the build for A/B runs of ablation variants)."""
 import os
 import sys
@@ -12,7 +12,7 @@ from tests.gpu_util import seeded  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 32 * 3601
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2]
+variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [2, 3]
 D, F = 384, 1536
 X = seeded((M, D), 1) * 1.5
 gam, bet = 1 + 0.2 * seeded((D,), 2), 0.1 * seeded((D,), 3)
@@ -60,7 +60,6 @@ def run():
 for rep in range(2):
     for v in variants:
         mode = v
-        capi.check(capi.lib().dinoseg_set_option(b"mlp_variant", 1 if v == 1 else 2))
         for _ in range(5):
             run()
         torch.cuda.synchronize()

@@ -6,7 +6,7 @@ NAME=$1; EXTRA=$2
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 B=$ROOT/build/variant_$NAME
 mkdir -p $B $ROOT/build/variants
-for f in api train_api gemm gemm_big gemm_ln gemm_ln12 mlp_fused mlp_fused2 gemm_tn attention attention_z attention_bwd elementwise train; do
+for f in api train_api gemm gemm_big gemm_ln gemm_ln12 mlp_fused2 gemm_tn attention attention_z attention_bwd elementwise train; do
   SLP=""; case $f in mlp_fused*) SLP="-fno-slp-vectorize";; esac      # (as in the Makefile)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $SLP $EXTRA -c $ROOT/dino_amd/csrc/$f.hip -o $B/$f.o &
 done
