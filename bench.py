@@ -136,6 +136,36 @@ def golden_check(model, arch, blocks, res, batch=1):
             "copies_identical": copies_identical}
 
 
+def golden_grad_check(precision, dev):
+    """The fine-tune step's gradients in `precision` against the reference ViT + torch autograd (fixture G12: 3 blocks, one frame @480,
+    all 48 tensors): |loss - ref|, the worst |norm ratio - 1| over the tensors, and the worst RMS error over the fixture's 64 sampled
+    entries relative to the tensor's RMS entry (~ ||g - g_ref|| / ||g_ref||).  The same quantities tests/test_train_gpu.py bounds."""
+    import numpy as np
+    import torch
+    from dino_amd import DINOSeg, ViTConfig, procedural_state_dict
+    from dino_amd.weights import synthetic_frames, synthetic_labels
+    path = os.path.join(ROOT, "tests", "golden", "g12_finetune_r480_ignore.npz")
+    if not os.path.exists(path):
+        return None
+    g, tag = np.load(path), "vits8_L3_r480_B1"
+    cfg = ViTConfig(n_blocks=3)
+    m = DINOSeg(head="mlp", n_blocks=3, precision=precision, arch=cfg, optimizer=torch.optim.Adam, lr=1e-3)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in procedural_state_dict(cfg).items()}, strict=True)
+    m.to(dev)
+    m.unfreeze_bb()
+    out = m.fused_training_step((torch.from_numpy(synthetic_frames(1, 480, seed=121)).to(dev),
+                                 torch.from_numpy(synthetic_labels(1, 3600, cfg.n_classes, seed=122)).to(dev)), 0)
+    worst_norm = worst_rel = 0.0
+    for k, p in m.named_parameters():
+        gv = p.grad.detach().cpu().reshape(-1)
+        gn = float(g[f"{tag}|gnorm|{k}"])
+        idx, ref = torch.from_numpy(g[f"{tag}|gidx|{k}"]), torch.from_numpy(g[f"{tag}|gval|{k}"])
+        worst_norm = max(worst_norm, abs(float(gv.norm()) / gn - 1.0))
+        worst_rel = max(worst_rel, float((gv[idx] - ref).pow(2).mean().sqrt()) / (gn / gv.numel() ** 0.5))
+    return {"fixture": "g12_finetune_r480_ignore/" + tag, "abs_dloss": float(f"{abs(float(out['loss']) - float(g[tag + '|loss'])):.3e}"),
+            "worst_norm_ratio_error": float(f"{worst_norm:.3e}"), "worst_sampled_relative_error": float(f"{worst_rel:.3e}"), "tensors": 48}
+
+
 def bench_finetune(a, world, rank, dev, rehearsal=False):
     """Fine-tune step throughput: ViT-S/8 truncated to 3 blocks + MLP head, all 48 tensors trainable, Adam lr 1e-3
     (run_experiment.py:135-136), 480x480 frames, batch 8 per GPU (global 64 at 8 GPUs), bf16 operands unless
@@ -180,7 +210,33 @@ def bench_finetune(a, world, rank, dev, rehearsal=False):
     seen = ranks_seen(dist, world, cdev)
     fl = flops_per_frame(cfg.embed_dim, cfg.num_heads, blocks, a.res)
     fps = per_gpu * world * a.steps / elapsed
+    # the dominant kernel group of the step, the flash-style attention backward (prep + dQ + dK,dV kernels: 29 % of the step), timed with
+    # HIP events by the library in an untimed pass of the same steps; algorithmic work = the five products of the backward
+    # (S, dP, dV, dK, dQ: 10 N^2 d per head; the two kernels recompute S and dP each -- 7 products issued -- which is not counted)
+    roof = None
+    if not rehearsal:
+        model.profile(2)
+        psteps = max(2, a.steps // 3)
+        for _ in range(psteps):
+            tuner.step(frames, labels)
+        torch.cuda.synchronize()
+        prof = model.profile_read()
+        model.profile(0)
+        ms, n = prof["attention_bwd"]
+        if n:
+            ntok = (a.res // 8) ** 2 + 1
+            gf = 10.0 * per_gpu * cfg.num_heads * ntok * ntok * 64 / 1e9
+            ach = gf / (ms / n)          # GFLOP / ms = TFLOP/s
+            peak = MFMA_PEAK_TFLOPS[a.precision]
+            roof = {"bound": "mfma", "kernel": "flash attention backward (attention_bwd.hip: attn_bwd_prep + attn_bwd_dq + attn_bwd_dkv kernels, "
+                                               "recompute from the forward's log-sum-exp)",
+                    "achieved": round(ach, 1), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "gflop_per_launch": round(gf, 1), "avg_launch_ms": round(ms / n, 4),
+                    "launches_timed": n, "traffic": None,
+                    "note": "algorithmic FLOPs (5 products); the kernels issue 7 products' worth of MFMAs"
+                            + (" x 3 (hi+lo planes)" if a.precision == "bf16x3" else "")}
     if rank == 0:
+        grad_parity = None if rehearsal else golden_grad_check(a.precision, dev)
         print(json.dumps({
             "metric": "frames/sec (480x480, ViT-S/8 x3 blocks) DINOSeg fine-tune step", "value": round(fps, 2),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -193,6 +249,7 @@ def bench_finetune(a, world, rank, dev, rehearsal=False):
                        "precision": a.precision, "collective": a.collective,
                        "parallelism": f"dp{world} (RCCL gradient {'all-reduce' if a.collective == 'allreduce' else 'reduce-scatter + all-gather'}, 22.1 MiB fp32)"},
             "model_mfma_frac": round(fps / world * 3 * fl["total"] / 1e12 / MFMA_PEAK_TFLOPS[a.precision], 4),
+            "roofline": roof, "gradient_parity": grad_parity,
         }), flush=True)
     if world > 1:
         dist.destroy_process_group()

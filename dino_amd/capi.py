@@ -22,7 +22,7 @@ BF16, BF16X3, FP16, FP16X3 = 0, 1, 2, 3
 HEAD_LINEAR, HEAD_MLP = 0, 1
 INPUT_U8_HWC, INPUT_F32_CHW = 0, 1
 EPI_PLAIN, EPI_RESID, EPI_GELU, EPI_RELU = 0, 1, 2, 3
-PROF_CLASSES = ("patch_embed", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm", "head")
+PROF_CLASSES = ("patch_embed", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm", "head", "attention_bwd")
 
 
 class DinosegError(RuntimeError):

@@ -226,7 +226,7 @@ static std::vector<LinSpec> linear_specs(const dinoseg_handle* h) {
     const int D = c.embed_dim, F = c.embed_dim * c.mlp_ratio, P = h->planes, FM = h->fmt;
     std::vector<LinSpec> v;
     // (fp16 mode: the patch embedding runs split like the head -- 0.13 % of the FLOPs, and its operands are raw pixels)
-    v.push_back({"dino.patch_embed.proj.weight", "dino.patch_embed.proj.bias", D, 3 * c.patch * c.patch, D, 192, patch_planes(h), split_fmt(h)});
+    v.push_back({"dino.patch_embed.proj.weight", "dino.patch_embed.proj.bias", D, 3 * c.patch * c.patch, D, 192, patch_planes(h), patch_fmt(h)});
     bool qkv_ready = false;      // Q / K / V of block i were written by block i-1's fused launch (mlp_fused2.hip, QKV tail)
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
@@ -516,13 +516,13 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     norm_consts(mean255, inv255);
     const long pg_plane = (long)L.Mp * 192;
     const int PP = patch_planes(h);
-    DSEG_PROF(DINOSEG_PROF_PATCH, DSEG_TRY(launch_patch_gather(x, x_kind, B, r, mean255, inv255, A, pg_plane, PP, s, SF)));
+    DSEG_PROF(DINOSEG_PROF_PATCH, DSEG_TRY(launch_patch_gather(x, x_kind, B, r, mean255, inv255, A, pg_plane, PP, s, patch_fmt(h))));
     {
         const PackedLinear& pk = h->packed.at("dino.patch_embed.proj.weight");
         GemmParams g = {};
         g.A = A; g.a_plane = pg_plane; g.lda = 192;
         g.W = pk.w; g.w_plane = pk.plane;
-        g.M = L.Mp; g.N = D; g.K = 192; g.planes = PP; g.fmt = SF; g.epi = EPI_PATCH; g.dispatch_rows = disp_Mp;
+        g.M = L.Mp; g.N = D; g.K = 192; g.planes = PP; g.fmt = patch_fmt(h); g.epi = EPI_PATCH; g.dispatch_rows = disp_Mp;
         g.bias = W(h, "dino.patch_embed.proj.bias");
         g.out_f32 = X; g.ldo_f32 = D;
         g.pos = h->pos_cache; g.n_patches = L.n;
@@ -829,6 +829,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
     }
     if (strcmp(key, "gemm_big") == 0) {
         dseg::options().gemm_big = value;
+        return 0;
+    }
+    if (strcmp(key, "fp16_patch_planes") == 0) {
+        dseg::options().fp16_patch_planes = value == 1 ? 1 : 2;
         return 0;
     }
     if (strcmp(key, "op_fmt") == 0) {      // operand format of the single-plane stand-alone ops (dinoseg_op_*): 0 bf16, 1 fp16

@@ -22,7 +22,7 @@ constexpr int TILE_BYTES = 128 * 128;   // one [128][64] bf16 slab
 // FMT (inference epilogues only): FMT_FP16 = A, W and the 16-bit outputs are fp16 (one plane: EPI_QKV leaves V bf16; hi+lo: all fp16)
 template <int PLANES, int EPI, int FMT = FMT_BF16>
 __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(GemmParams p) {
-    static_assert(FMT == FMT_BF16 || EPI == EPI_RESID || EPI == EPI_GELU || EPI == EPI_QKV || (PLANES == 2 && (EPI == EPI_PATCH || EPI == EPI_RELU)),
+    static_assert(FMT == FMT_BF16 || EPI == EPI_RESID || EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_PATCH || (PLANES == 2 && EPI == EPI_RELU),
                   "fp16 operands: inference epilogues only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = PLANES * 2 * TILE_BYTES;
@@ -318,6 +318,7 @@ int launch_gemm_small(const GemmParams& p, hipStream_t s) {
         if (p.planes == 1 && p.epi == EPI_RESID) return launch_one<1, EPI_RESID, FMT_FP16>(p, s);
         if (p.planes == 1 && p.epi == EPI_GELU && p.aux_out == nullptr) return launch_one<1, EPI_GELU, FMT_FP16>(p, s);
         if (p.planes == 1 && p.epi == EPI_QKV) return launch_one<1, EPI_QKV, FMT_FP16>(p, s);
+        if (p.planes == 1 && p.epi == EPI_PATCH) return launch_one<1, EPI_PATCH, FMT_FP16>(p, s);
         if (p.planes == 2 && p.epi == EPI_RESID) return launch_one<2, EPI_RESID, FMT_FP16>(p, s);
         if (p.planes == 2 && p.epi == EPI_GELU && p.aux_out == nullptr) return launch_one<2, EPI_GELU, FMT_FP16>(p, s);
         if (p.planes == 2 && p.epi == EPI_QKV) return launch_one<2, EPI_QKV, FMT_FP16>(p, s);

@@ -146,10 +146,12 @@ static inline void prof_end(dinoseg_handle* h, int idx, hipStream_t s) {
 static inline int head_planes() { return 2; }
 // planes of the patch-embedding GEMM: the mode's own, except that the fp16 mode runs it split like the head (raw pixel operands,
 // 0.13 % of the FLOPs)
-static inline int patch_planes(const dinoseg_handle* h) { return h->fmt == FMT_FP16 ? 2 : h->planes; }
-// format of the split (two-plane) operands of the patch embedding and the head: fp16 only in the fp16 hi+lo mode -- the single-plane
-// fp16 mode keeps them bf16 hi+lo (their error is far below that mode's)
-static inline int split_fmt(const dinoseg_handle* h) { return h->planes == 2 ? h->fmt : (int)FMT_BF16; }   // the classifier head always runs in split precision (it is tiny)
+static inline int patch_planes(const dinoseg_handle* h) { return (h->fmt == FMT_FP16 && options().fp16_patch_planes == 2) ? 2 : h->planes; }
+// format of the split (two-plane) operands of the head (and of the patch embedding where it runs split): fp16 only in the fp16 hi+lo
+// mode -- the single-plane fp16 mode keeps them bf16 hi+lo (their error is far below that mode's)
+static inline int split_fmt(const dinoseg_handle* h) { return h->planes == 2 ? h->fmt : (int)FMT_BF16; }
+// format of the patch-embedding operands: the mode's own when it runs on the mode's planes, the split format otherwise
+static inline int patch_fmt(const dinoseg_handle* h) { return patch_planes(h) == h->planes ? h->fmt : split_fmt(h); }   // the classifier head always runs in split precision (it is tiny)
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline const float* W(const dinoseg_handle* h, const std::string& k) { return h->bound.at(k).ptr; }
 static inline void norm_consts(float mean255[3], float inv255[3]) {

@@ -723,7 +723,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
             a.neg_lse = F32(L.NLSE); a.neg_delta = F32(L.NDEL);
             a.dqkv = G; a.dqkv_plane = (long)L.M * 3 * D;
             a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P;
-            DSEG_TRY(launch_attention_bwd(a, s));
+            DSEG_PROF(DINOSEG_PROF_ATTN_BWD, DSEG_TRY(launch_attention_bwd(a, s)));
         }
         // ---- attn.qkv : qkv = A1 Wqkv^T + b
         DSEG_TRY(side_begin());

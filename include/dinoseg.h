@@ -31,7 +31,7 @@ typedef struct dinoseg_handle dinoseg_handle;
  *                    that meets "argmax identical, |dlogp| <= 1e-3" against the fp32 reference.
  *   DINOSEG_FP16   : fp16 operands (11 significand bits), 1 MFMA per product at the bf16 rate: the linears and Q.K^T on
  *                    v_mfma_f32_32x32x16_f16; the probabilities and V (the P.V product) stay bf16 -- 2^S against the fixed
- *                    reference 0 needs bf16's exponent range; the patch embedding and the head run split (bf16 hi+lo).
+ *                    reference 0 needs bf16's exponent range; the head runs split (bf16 hi+lo).
  *                    ~6x closer to the reference than DINOSEG_BF16 at the same speed; inference only (the fine-tune
  *                    entry points refuse it: fp16 gradients would need loss scaling).
  *   DINOSEG_FP16X3 : fp16 hi+lo operand pairs everywhere (patch embedding and head included), 3 MFMAs per product at the
@@ -174,7 +174,9 @@ int dinoseg_adam_step_multi(int32_t count, float* const* p, const float* const* 
  * dinoseg_profile_read() waits for the recorded events, writes the summed milliseconds and launch counts
  * per class (arrays of DINOSEG_PROF_COUNT) and clears the records. */
 enum { DINOSEG_PROF_PATCH = 0, DINOSEG_PROF_LN = 1, DINOSEG_PROF_QKV = 2, DINOSEG_PROF_ATTN = 3, DINOSEG_PROF_PROJ = 4,
-       DINOSEG_PROF_FC1 = 5, DINOSEG_PROF_FC2 = 6, DINOSEG_PROF_HEAD = 7, DINOSEG_PROF_COUNT = 8 };
+       DINOSEG_PROF_FC1 = 5, DINOSEG_PROF_FC2 = 6, DINOSEG_PROF_HEAD = 7,
+       DINOSEG_PROF_ATTN_BWD = 8,      /* the flash-style attention backward of the fine-tune step: prep + dQ + dK,dV kernels */
+       DINOSEG_PROF_COUNT = 9 };
 int dinoseg_profile(dinoseg_handle* h, int32_t level);
 int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
 
@@ -185,6 +187,7 @@ int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
  *                half takes the kernel routes of the whole batch: tests/test_model_gpu.py::test_two_stream_split_equals_one_stream*;
  *                +6 to +9 % frames/s at B = 32 on MI355X: one half's attention fills the CUs the other half's GEMM tails and
  *                memory phases leave idle); 1 = one stream;
+ *   "fp16_patch_planes" 1 [default] / 2: precision fp16 only -- the patch embedding on one fp16 plane, or on bf16 hi+lo planes;
  *   "op_fmt"     0 [default] / 1: operand format of the single-plane stand-alone ops (dinoseg_op_*: tests, tools): bf16 / fp16;
  *   "gemm_big"   1 [default] = the persistent 256x384 (bf16) / 128x384 (bf16x3) GEMM where it applies, 0 = always the 128x128
  *                kernel, 2 = wherever its shape rules allow;

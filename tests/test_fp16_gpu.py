@@ -1,8 +1,8 @@
 """fp16 operand format (precision 'fp16', round 4): the single-plane kernels on fp16 operands through the C-ABI (-m gpu).
 
 Same MFMA rate as bf16 (v_mfma_f32_32x32x16_f16), 11 significand bits instead of 8: the linears and Q.K^T run on fp16, the
-probabilities and V (the P.V product) stay bf16 -- 2^S against the fixed reference 0 needs bf16's exponent range -- the patch
-embedding and the head run split (bf16 hi+lo).  Op tests: against fp64 on the operands the kernel saw, like their bf16 twins in
+probabilities and V (the P.V product) stay bf16 -- 2^S against the fixed reference 0 needs bf16's exponent range -- the head
+runs split (bf16 hi+lo).  Op tests: against fp64 on the operands the kernel saw, like their bf16 twins in
 test_ops_gpu.py (the stand-alone ops take the format from option `op_fmt`).  Model tests: against the goldens captured from the
 reference (vision_transformer.py:237-248, pl_torch_modules.py:239-256); the bounds are 1.5x what was measured on MI355X.
 """
@@ -280,9 +280,10 @@ def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
 
-# measured on MI355X (round 4) over the five routes: L=1 2.24e-2 .. 2.30e-2 / 5-6 flips, L=12 2.15e-2 .. 2.64e-2 / 6-8 flips of 3600
-# (the CPU emulation of the mix, oracle/precision_ablation.py: 2.2e-2 / 6; the bf16 mode: 0.12-0.14 / 15-24); bounds = 1.5x
-FP16_BOUND = {1: (3.5e-2, 9), 12: (4.0e-2, 12)}
+# measured on MI355X (round 4) over the five routes: L=1 2.50e-2 / 5 flips, L=12 2.15e-2 .. 2.43e-2 / 4-8 flips of 3600 (with the patch
+# embedding on bf16 hi+lo planes, option fp16_patch_planes = 2: 2.24e-2 .. 2.64e-2 / 5-8); the CPU emulation of the mix,
+# oracle/precision_ablation.py: 2.2e-2 / 6; the bf16 mode: 0.12-0.14 / 15-24.  Bounds = 1.5x
+FP16_BOUND = {1: (3.8e-2, 9), 12: (4.0e-2, 12)}
 
 
 @pytest.mark.parametrize("mlp_fused,proj_fused,qkv_fused,gemm_ln", [(0, 0, 0, 0), (0, 0, 0, 2), (2, 0, 0, 2), (2, 1, 0, 2), (2, 1, 1, 2)])
@@ -342,7 +343,7 @@ def test_g7_vitb8_fp16(cuda, golden_dir):
     rows = torch.from_numpy(g["rows"])
     err = float((lp.cpu()[rows] - torch.from_numpy(g["logp_rows"])).abs().max())
     print(f"fp16 ViT-B/8: max|dlogp| {err:.3e}")
-    assert torch.isfinite(lp).all() and err <= 1.1e-2          # measured 6.9e-3 (bf16: 4.5e-2)
+    assert torch.isfinite(lp).all() and err <= 1.2e-2          # measured 7.7e-3 (bf16: 4.5e-2)
 
 
 @pytest.mark.parametrize("chan,head", [(40.0, 5.0), (100.0, 8.0)])
