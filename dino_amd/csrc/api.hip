@@ -538,7 +538,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     bool qkv_ready = false;      // Q / K / V of block i were written by block i-1's fused launch (mlp_fused2.hip, QKV tail)
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
-        // gemm_ln: 0 never fused, 2 always, 1 (default) by measurement (round 4, tools/r4_fourth.sh, 1..6 frames @480):
+        // gemm_ln: 0 never fused, 2 always, 1 (default) by measurement (round 4, tools/r4_smallbatch.sh, 1..6 frames @480):
         //  * single plane (bf16 / fp16): fused from 80 row panels of 128 on -- below that its persistent 128 x 384 panels leave most
         //    CUs idle (one frame = 29 panels: qkv 31 against 21 us with LayerNorm + the 128x128 kernel, fc1 40 against 23; the
         //    whole single-frame forward 1.72 -> 1.33 ms at 12 blocks; crossover between 2 and 3 frames);
