@@ -44,7 +44,20 @@ def test_handle_lifecycle_and_errors_without_gpu():
     assert lib.dinoseg_bind_weight(h, b"dino.norm.weight", ctypes.addressof(buf), shape, 1) == -1
     assert lib.dinoseg_refresh_weights(h, None) == -3          # missing keys
     assert "missing key" in capi.last_error()
+    assert lib.dinoseg_state_generation(h) == 0                # nothing allocated yet
     assert lib.dinoseg_destroy(h) == 0
+    # the four precisions (include/dinoseg.h) create a handle; anything else is refused; the process-wide switches validate their values
+    for prec in (capi.BF16, capi.BF16X3, capi.FP16, capi.FP16X3):
+        cfg = capi.Config(384, 6, 1, 8, 4, 7, capi.HEAD_MLP, 28, 1e-6, prec)
+        assert lib.dinoseg_create(ctypes.byref(cfg), ctypes.byref(h)) == 0 and lib.dinoseg_destroy(h) == 0
+    cfg = capi.Config(384, 6, 1, 8, 4, 7, capi.HEAD_MLP, 28, 1e-6, 4)
+    assert lib.dinoseg_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert lib.dinoseg_set_option(b"op_fmt", 2) == -1 and "op_fmt" in capi.last_error()
+    assert lib.dinoseg_set_option(b"op_fmt", 0) == 0 and lib.dinoseg_set_option(b"mlp_variant", 1) == 0
+    assert lib.dinoseg_set_option(b"no_such_option", 1) == -1
+    assert set(dino_amd.dinoseg._PRECISIONS) == {"bf16", "bf16x3", "fp16", "fp16x3"}
+    with pytest.raises(ValueError, match="precision"):
+        DINOSeg(precision="fp32")
 
 
 def test_state_dict_keys_match_reference_schema():
