@@ -169,7 +169,7 @@ def bench_attn():
     npad = (ntok + 63) // 64 * 64
     base = dict(attn_variant=3)
     variants = [(f"variant {v}", dict(base, attn_variant=v)) for v in ATTN_VARIANTS]
-    for planes in (1, 2):
+    for planes in [int(v) for v in os.environ.get("ATTN_PLANES", "1,2").split(",")]:
         q = rand_bf16((planes, B, H, npad, 64))
         k = rand_bf16((planes, B, H, npad, 64))
         vt = rand_bf16((planes, B, H, npad, 64))
