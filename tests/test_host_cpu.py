@@ -191,3 +191,28 @@ def test_fast_signature_sees_every_kind_of_weight_change():
     assert m._fast_signature() != base
     m2 = pickle.loads(pickle.dumps(m))                                  # the index is process state: not pickled
     assert "_fast_index" not in m2.__dict__ and m2._fast_signature() is None
+
+
+def test_resize_restatement_against_an_independent_bilinear():
+    """cv2 is not in this image (oracle/resize_oracle.py: parity unpinned), so the restatement is held against an INDEPENDENT
+    implementation of the same sampling rule: torch's float64 bilinear (align_corners=False = cv2's (dx + 0.5) * scale - 0.5 with edge
+    clamping, no antialiasing; 'area' for the exact-2x case, where cv2 switches to INTER_AREA).  cv2's uint8 path rounds its taps to
+    11 bits and truncates intermediate sums, so the two may differ by one grey level, never by more."""
+    import torch.nn.functional as F
+    from dino_amd.preprocess import resize_linear_u8
+    rng = np.random.default_rng(1)
+    for sh, sw, dh, dw in [(5, 7, 8, 8), (12, 16, 8, 8), (3, 3, 16, 16), (48, 64, 40, 40), (9, 4, 16, 24), (300, 400, 240, 240),
+                           (480, 640, 480, 480), (16, 16, 8, 8), (96, 128, 48, 64)]:
+        img = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        x = torch.from_numpy(img).permute(2, 0, 1)[None].double()
+        if sh == 2 * dh and sw == 2 * dw:
+            ref = F.interpolate(x, size=(dh, dw), mode="area")
+        else:
+            ref = F.interpolate(x, size=(dh, dw), mode="bilinear", align_corners=False, antialias=False)
+        ref = ref[0].permute(1, 2, 0).numpy()
+        got = resize_linear_u8(img, dh, dw).astype(np.float64)
+        d = got - ref
+        assert np.abs(d).max() <= 1.0 + 1e-9, (sh, sw, dh, dw, np.abs(d).max())
+        # (rounding to a grey level: mean |d| about 0.25; cv2's vertical pass truncates twice -- ((b0 * (S0 >> 4)) >> 16) + ... -- which
+        #  shows as a bias of up to about +-0.1 grey levels against exact arithmetic, by the tap values)
+        assert abs(d.mean()) < 0.2 and np.abs(d).mean() < 0.3, (sh, sw, dh, dw, d.mean(), np.abs(d).mean())
