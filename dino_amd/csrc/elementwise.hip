@@ -364,67 +364,98 @@ __global__ __launch_bounds__(256) void head_final_kernel(const bf16_t* __restric
                                                          int K, const float* __restrict__ W,
                                                          const float* __restrict__ bias, int C,
                                                          float* __restrict__ logp, int32_t* __restrict__ amax, int fmt) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    float z[CMAX];
+    // Sixteen lanes per row: a lane group reads 256 contiguous bytes of the row per step (one thread per row -- the round-1 form --
+    // touched 64 rows per load instruction and read 4.6x the activation's bytes from HBM: profiles/r04_pmc_hbm.csv), every lane
+    // accumulates its eight columns against the classifier rows staged in LDS, a butterfly over the group finishes the sums.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ws = reinterpret_cast<float*>(smem);          // [C][Kp], Kp = ld rounded up to 8, zero beyond K
+    const int Kp = (ld + 7) & ~7;
+    for (int i = threadIdx.x; i < C * Kp; i += 256) {
+        const int c = i / Kp, k = i - c * Kp;
+        Ws[i] = k < K ? W[c * K + k] : 0.f;
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int nchunk = ld >> 3;
+    for (long m = (long)blockIdx.x * 16 + grp; m < M; m += (long)gridDim.x * 16) {
+        float z[CMAX];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) z[c] = c < C ? bias[c] : -INFINITY;
-    const bf16_t* hi = in + (long)m * ld;
-    const bf16_t* lo = hi + in_plane;
-    for (int k0 = 0; k0 < K; k0 += 8) {
-        const uint4 h = *reinterpret_cast<const uint4*>(hi + k0), l = *reinterpret_cast<const uint4*>(lo + k0);
-        const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
-        float xv[8];
+        for (int c = 0; c < CMAX; ++c) z[c] = 0.f;
+        const bf16_t* hi = in + m * ld;
+        const bf16_t* lo = hi + in_plane;
+        for (int ch = sub; ch < nchunk; ch += 16) {
+            const uint4 h = *reinterpret_cast<const uint4*>(hi + ch * 8), l = *reinterpret_cast<const uint4*>(lo + ch * 8);
+            const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+            float xv[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (fmt == FMT_FP16) {
-                xv[2 * e] = lo_to_f32<FMT_FP16>(hw[e]) + lo_to_f32<FMT_FP16>(lw[e]);
-                xv[2 * e + 1] = hi_to_f32<FMT_FP16>(hw[e]) + hi_to_f32<FMT_FP16>(lw[e]);
-            } else {
-                xv[2 * e] = bf16_lo_to_f32(hw[e]) + bf16_lo_to_f32(lw[e]);
-                xv[2 * e + 1] = bf16_hi_to_f32(hw[e]) + bf16_hi_to_f32(lw[e]);
+            for (int e = 0; e < 4; ++e) {
+                if (fmt == FMT_FP16) {
+                    xv[2 * e] = lo_to_f32<FMT_FP16>(hw[e]) + lo_to_f32<FMT_FP16>(lw[e]);
+                    xv[2 * e + 1] = hi_to_f32<FMT_FP16>(hw[e]) + hi_to_f32<FMT_FP16>(lw[e]);
+                } else {
+                    xv[2 * e] = bf16_lo_to_f32(hw[e]) + bf16_lo_to_f32(lw[e]);
+                    xv[2 * e + 1] = bf16_hi_to_f32(hw[e]) + bf16_hi_to_f32(lw[e]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                if (c < C) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(Ws + c * Kp + ch * 8);
+                    const float4 w1 = *reinterpret_cast<const float4*>(Ws + c * Kp + ch * 8 + 4);
+                    float a = z[c];
+                    a = fmaf(xv[0], w0.x, a); a = fmaf(xv[1], w0.y, a); a = fmaf(xv[2], w0.z, a); a = fmaf(xv[3], w0.w, a);
+                    a = fmaf(xv[4], w1.x, a); a = fmaf(xv[5], w1.y, a); a = fmaf(xv[6], w1.z, a); a = fmaf(xv[7], w1.w, a);
+                    z[c] = a;
+                }
             }
         }
+        // butterfly over the 16 lanes of the group: every lane ends with the full sums (+ bias)
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
             if (c < C) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (k0 + e < K) z[c] = fmaf(xv[e], W[c * K + k0 + e], z[c]);
+                float a = z[c];
+                a += __shfl_xor(a, 1, 16); a += __shfl_xor(a, 2, 16); a += __shfl_xor(a, 4, 16); a += __shfl_xor(a, 8, 16);
+                z[c] = a + bias[c];
+            } else {
+                z[c] = -INFINITY;
             }
         }
+        float mx = z[0];
+        int am = 0;
+#pragma unroll
+        for (int c = 1; c < CMAX; ++c)
+            if (c < C && z[c] > mx) {
+                mx = z[c];
+                am = c;
+            }
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) sum += expf(z[c] - mx);
+        const float lse = logf(sum);
+        // lane `sub` writes classes sub, sub + 16 (the group's stores are one contiguous run of C floats)
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C && (c & 15) == sub) logp[m * C + c] = (z[c] - mx) - lse;
+        if (amax && sub == 0) amax[m] = am;
     }
-    float mx = z[0];
-    int am = 0;
-#pragma unroll
-    for (int c = 1; c < CMAX; ++c)
-        if (c < C && z[c] > mx) {
-            mx = z[c];
-            am = c;
-        }
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-        if (c < C) sum += expf(z[c] - mx);
-    const float lse = logf(sum);
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-        if (c < C) logp[(long)m * C + c] = (z[c] - mx) - lse;
-    if (amax) amax[m] = am;
 }
 
 int launch_head_final(const bf16_t* in, long in_plane, int ld, int M, int K, const float* W, const float* b, int C,
                       float* logp, int32_t* argmax, hipStream_t s, int fmt) {
     if (M <= 0) return 0;
-    if (C < 1 || C > 32 || ld % 8 != 0) {
-        dinoseg_set_error("head_final: need 1 <= C <= 32 and ld %% 8 == 0 (C=%d ld=%d)", C, ld);
+    if (C < 1 || C > 32 || ld % 8 != 0 || K > ld || (long)C * ld > 16384) {
+        dinoseg_set_error("head_final: need 1 <= C <= 32, K <= ld, ld %% 8 == 0 and C * ld <= 16384 (C=%d K=%d ld=%d)", C, K, ld);
         return -1;
     }
-    const int grid = (M + 255) / 256;
+    const int ncu = device_cu_count();
+    const int want = (M + 15) / 16;
+    const int grid = ncu > 0 && want > 8 * ncu ? 8 * ncu : want;       // (grid-stride: the classifier is staged once per workgroup)
+    const size_t lds = (size_t)C * ld * sizeof(float);
     if (C <= 8)
-        hipLaunchKernelGGL((head_final_kernel<8>), dim3(grid), dim3(256), 0, s, in, in_plane, ld, M, K, W, b, C, logp, argmax, fmt);
+        hipLaunchKernelGGL((head_final_kernel<8>), dim3(grid), dim3(256), lds, s, in, in_plane, ld, M, K, W, b, C, logp, argmax, fmt);
     else
-        hipLaunchKernelGGL((head_final_kernel<32>), dim3(grid), dim3(256), 0, s, in, in_plane, ld, M, K, W, b, C, logp, argmax, fmt);
+        hipLaunchKernelGGL((head_final_kernel<32>), dim3(grid), dim3(256), lds, s, in, in_plane, ld, M, K, W, b, C, logp, argmax, fmt);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
