@@ -114,6 +114,76 @@ __global__ __launch_bounds__(256) void mfma_shape_kernel(int iters, uint32_t see
     if (s == 12345.678f) out[0] = s;
 }
 
+
+// One wave's attention tile as a hand-placed instruction stream (registers only): 16 "gaps" per trip, each one MFMA followed by
+// the vector work of one packed pair of probabilities.  FILL: 0 bare MFMAs; 1: + 2 v_exp_f32; 2: + 2 v_exp + 2 v_add (row sums,
+// two chains, consumers one gap behind their producers); 3: + 2 v_exp + 2 v_add + 1 v_cvt_pk_bf16_f32 (the full mix of
+// attention_z.hip's tile: 5 fillers, 28.5 issue cycles by MI355X_MICROARCH.md's table); 4: the same multiset per tile, NOT
+// interleaved (16 MFMAs, then 32 exp, 32 add, 16 cvt: what a wave does without software pipelining).
+template <int FILL>
+__global__ __launch_bounds__(256) void attn_gap_kernel(int iters, uint32_t seed, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    uint32_t h = seed * 2654435761u + (uint32_t)(blockIdx.x * 256 + threadIdx.x) * 40503u;
+    auto next = [&]() {
+        h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+        const uint32_t lo = 0x3F80u | (h & 0x807Fu), hi = 0x3F80u | ((h >> 16) & 0x807Fu);
+        return seed ? (lo | (hi << 16)) : 0u;
+    };
+    uint4 au = {next(), next(), next(), next()}, bu = {next(), next(), next(), next()};
+    const bf16x8 a = __builtin_bit_cast(bf16x8, au), b = __builtin_bit_cast(bf16x8, bu);
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float sc[32], pr[32];
+    uint32_t pk[16];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        sc[i] = seed ? (float)((int)(next() & 0xFFF) - 2048) * (1.0f / 512.0f) : 0.f;      // scores in [-4, 4)
+        pr[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pk[i] = 0;
+    float sum0 = 0.f, sum1 = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        if (FILL == 4) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int g = 0; g < 32; ++g) asm volatile("v_exp_f32 %0, %1" : "=v"(pr[g]) : "v"(sc[g]));
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum0) : "v"(pr[2 * g]));
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum1) : "v"(pr[2 * g + 1]));
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[g]) : "v"(pr[2 * g]), "v"(pr[2 * g + 1]));
+        } else {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int q = (g + 15) & 15;        // the pair produced one gap earlier
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a), "v"(b));
+                if (FILL >= 1) {
+                    asm volatile("v_exp_f32 %0, %1" : "=v"(pr[2 * g]) : "v"(sc[2 * g]));
+                    if (FILL >= 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum0) : "v"(pr[2 * q]));
+                    asm volatile("v_exp_f32 %0, %1" : "=v"(pr[2 * g + 1]) : "v"(sc[2 * g + 1]));
+                    if (FILL >= 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum1) : "v"(pr[2 * q + 1]));
+                    if (FILL >= 3) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[q]) : "v"(pr[2 * q]), "v"(pr[2 * q + 1]));
+                }
+            }
+        }
+    }
+    float s = sum0 + sum1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][lane & 15];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += (float)pk[i];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += pr[i];
+    if (s == 12345.678f) out[0] = s;
+}
+
 // grid = CUs x waves_per_simd workgroups of 4 waves (one per SIMD); returns the launch through *flops = MFMA FLOPs issued
 // chains: 1, 2, 4 independent accumulator chains; or 100 + n: four chains and n VALU fillers per four MFMAs (n = 8, 16, 32);
 // or 200 + n: n SALU fillers; 300 + n (16, 32): s_nop 0; 400 + n (16, 32): s_waitcnt lgkmcnt(0)
@@ -143,6 +213,11 @@ static int launch_mfma_peak(int waves_per_simd, int iters, uint32_t seed, int ch
         case 504: hipLaunchKernelGGL((mfma_shape_kernel<1, 0>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
         case 604: hipLaunchKernelGGL((mfma_shape_kernel<0, 1>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
         case 704: hipLaunchKernelGGL((mfma_shape_kernel<1, 1>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
+        case 800: hipLaunchKernelGGL((attn_gap_kernel<0>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
+        case 801: hipLaunchKernelGGL((attn_gap_kernel<1>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
+        case 802: hipLaunchKernelGGL((attn_gap_kernel<2>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
+        case 803: hipLaunchKernelGGL((attn_gap_kernel<3>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
+        case 804: hipLaunchKernelGGL((attn_gap_kernel<4>), dim3(grid), dim3(256), 0, s, iters, seed, out); break;
         default: fprintf(stderr, "mfma_peak: chains = %d\n", chains); return -1;
     }
 #undef DSEG_PK

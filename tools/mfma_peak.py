@@ -42,6 +42,7 @@ ONLY = os.environ.get("MFMA_MODES")
 MODES = [(4, "4 chains"), (1, "1 chain")] + [(100 + n, f"+{n} VALU / 4 MFMA") for n in (8, 16, 32)] + \
         [(200 + n, f"+{n} SALU / 4 MFMA") for n in (8, 16, 32)] + [(300 + n, f"+{n} s_nop / 4 MFMA") for n in (16, 32)] + \
         [(400 + n, f"+{n} s_waitcnt / 4 MFMA") for n in (16, 32)] + \
+        [(800, "gap: bare MFMA"), (801, "gap: +2 exp"), (802, "gap: +2 exp 2 add"), (803, "gap: +2exp 2add 1cvt"), (804, "tile: not interleaved")] + \
         [(500, "32x32x16 regs (ctl)"), (504, "16x16x32 regs"), (604, "32x32x16 LDS-fed"), (704, "16x16x32 LDS-fed")]
 if ONLY:
     MODES = [m for m in MODES if str(m[0]) in ONLY.split(",")]
