@@ -614,6 +614,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             a.ctx = CTX; a.ctx_plane = L.ctx_plane; a.lse = nullptr;
             a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P; a.fmt = FM;
             a.shared_gpu = h->in_split ? 1 : 0;
+            a.dispatch_B = dB;
             DSEG_PROF(DINOSEG_PROF_ATTN, DSEG_TRY(launch_attention(a, s)));
         }
         const bool fuse_mlp = h->packed_mlp.count(b) && mlp_fuse_wanted(h, disp_M);

@@ -127,7 +127,8 @@ struct Options {
     int splitk_tiles = 512;  // weight-gradient GEMMs: partial 128x128 tiles per launch (<= 768, the workspace holds that many)
     int attn_variant = 11;   // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
                              // tile work; bit 2: unused (round 1-3's software-pipelined kernel, removed); bit 3 (bf16 mode):
-                             // the zero-reference kernel, four waves per SIMD (attention_z.hip)
+                             // the zero-reference kernel, four waves per SIMD (attention_z.hip); bit 9: never split the keys of a
+                             // q-tile over wave groups (attn_fwd_zs_kernel, the small-grid form: A/B and tests)
 };
 Options& options();
 
@@ -139,6 +140,8 @@ struct AttnParams {
     int B, heads, ntok, npad, planes;
     int dbg;                           // timing-only ablations: bit0 skip max/exp, bit1 skip steady-state loads, bit2 skip PV
     int shared_gpu;                    // hint: another stream's kernels run beside this launch (the split forward): prefer wide workgroups
+    int dispatch_B;                    // > 0: choices that change the arithmetic (the key split of small grids) are made for this batch: the
+                                       // half-batches of a split forward run what the whole call would (as GemmParams::dispatch_rows)
     int fmt;                           // FMT_FP16, one plane (attention_z.hip): Q, K and ctx are fp16, V and the probabilities stay bf16 (2^S against
                                        // the fixed reference 0 needs bf16's exponent range); hi+lo planes (attention.hip): everything fp16, the
                                        // probabilities bounded by the running reference (<= 2^15)

@@ -113,7 +113,7 @@ def test_qkv_gemm_layout(cuda, planes, H, ntok):
 ATTN_VARIANT_DEFAULT = 11
 
 
-def _attention_case(B, H, ntok, planes, seed, spike=False):
+def _attention_case(B, H, ntok, planes, seed, spike=False, want_lse=True):
     npad = (ntok + 63) // 64 * 64
     g = np.random.default_rng(seed)
     Q = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32)) * 1.5
@@ -147,8 +147,8 @@ def _attention_case(B, H, ntok, planes, seed, spike=False):
     ctx = torch.zeros((planes, B * ntok, H * 64), dtype=torch.int16, device="cuda")
     lse = torch.zeros((B, H, ntok), dtype=torch.float32, device="cuda")
     capi.check(capi.lib().dinoseg_op_attention(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), B * H * npad * 64,
-                                               ctx.data_ptr(), B * ntok * H * 64, lse.data_ptr(), B, H, ntok, npad,
-                                               planes, S()))
+                                               ctx.data_ptr(), B * ntok * H * 64, lse.data_ptr() if want_lse else None, B, H, ntok,
+                                               npad, planes, S()))
     torch.cuda.synchronize()
     # fp64 reference on the operands the kernel saw
     qq = unpack(qp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu() / LOG2E
@@ -284,6 +284,33 @@ def test_head_final(cuda, C, K, ld):
     ref = torch.log_softmax(z, dim=1)
     assert float((logp.cpu() - ref).abs().max()) <= 2e-5
     assert torch.equal(am.cpu().long(), ref.argmax(dim=1))
+
+
+@pytest.mark.parametrize("B,H,ntok", [(1, 6, 3601), (1, 2, 1024), (2, 3, 901), (1, 1, 257)])
+def test_attention_key_split_for_small_grids(cuda, B, H, ntok):
+    """Fewer 128-query workgroups than CUs (a single frame) in an inference call (no LSE asked for): attn_fwd_zs_kernel splits the K/V
+    tiles of a q-tile over two or three wave groups and adds the partial O / row sums.  Against the unsplit kernel (attn_variant bit 9):
+    the same result up to the summation order -- one place of the bf16 output on a few elements per thousand -- and both within the
+    usual bound of the fp64 reference; on the exact path (a dominant key late in the sweep) group 0 recomputes in the unsplit kernel's
+    order: identical.  With an LSE output (the training forward) the keys are never split: one arithmetic at every batch size."""
+    lib = capi.lib()
+    try:
+        capi.check(lib.dinoseg_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT | 512))
+        base, ref, _, _ = _attention_case(B, H, ntok, 1, seed=ntok, want_lse=False)
+        ex0 = _attention_case(1, 1, 300, 1, seed=77, spike="over", want_lse=False)
+        tr0 = _attention_case(B, H, ntok, 1, seed=ntok)
+        capi.check(lib.dinoseg_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT))
+        got, _, _, _ = _attention_case(B, H, ntok, 1, seed=ntok, want_lse=False)
+        ex1 = _attention_case(1, 1, 300, 1, seed=77, spike="over", want_lse=False)
+        tr1 = _attention_case(B, H, ntok, 1, seed=ntok)
+    finally:
+        capi.check(lib.dinoseg_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT))
+    assert float((got - ref).abs().max()) <= 1.5e-2 and float((base - ref).abs().max()) <= 1.5e-2
+    d = (got - base).abs()
+    assert bool((d > 0).any()), "the split kernel was not dispatched"
+    assert float((d / (base.abs() + 1e-3)).max()) <= 2.0 ** -7 and float((d > 0).float().mean()) <= 5e-3
+    assert torch.equal(ex0[0], ex1[0])
+    assert torch.equal(tr0[0], tr1[0]) and torch.equal(tr0[2], tr1[2])
 
 
 @pytest.mark.parametrize("planes,M", [(1, 3000), (2, 3000), (2, 1409)])
