@@ -20,8 +20,13 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 128;   // one [128][64] bf16 slab
 
 // FMT (inference epilogues only): FMT_FP16 = A, W and the 16-bit outputs are fp16 (one plane: EPI_QKV leaves V bf16; hi+lo: all fp16)
-template <int PLANES, int EPI, int FMT = FMT_BF16>
+// HALFM (EPI_RESID only): 64 x 128 tiles, wave tile 32 x 64 -- twice the workgroups for a small batch (one frame @480: attn.proj and
+// mlp.fc2 are 29 x 3 = 87 tiles of 128 x 128 on 256 CUs).  Every output element sees the same MFMAs in the same order: bit-identical.
+template <int PLANES, int EPI, int FMT = FMT_BF16, bool HALFM = false>
 __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(GemmParams p) {
+    static_assert(!HALFM || EPI == EPI_RESID, "64-row tiles: the residual epilogue only");
+    constexpr int BM = HALFM ? 64 : 128;     // (shadows the file-scope tile height)
+    constexpr int MI = HALFM ? 1 : 2;
     static_assert(FMT == FMT_BF16 || EPI == EPI_RESID || EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_PATCH || (PLANES == 2 && EPI == EPI_RELU),
                   "fp16 operands: inference epilogues only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -49,19 +54,23 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
                 const int piece = wave * 4 + i;            // 1-KiB piece = 8 rows
                 const int row = piece * 8 + (lane >> 3);
                 const int c = swz_chunk(row, lane & 7);    // logical chunk that lives in physical slot lane&7
-                int gm = m0 + row;
-                gm = gm < M ? gm : M - 1;
-                const bf16_t* srcA = p.A + pl * p.a_plane + (long)gm * p.lda + kt * BK + c * 8;
-                glds16(srcA, sbase + (pl * 2 + 0) * TILE_BYTES + piece * 1024);
+                if (!HALFM || i < 2) {                     // (64-row tiles: 8 A pieces, two per wave)
+                    const int apiece = HALFM ? wave * 2 + i : piece;
+                    const int arow = apiece * 8 + (lane >> 3);
+                    int gm = m0 + arow;
+                    gm = gm < M ? gm : M - 1;
+                    const bf16_t* srcA = p.A + pl * p.a_plane + (long)gm * p.lda + kt * BK + swz_chunk(arow, lane & 7) * 8;
+                    glds16(srcA, sbase + (pl * 2 + 0) * TILE_BYTES + apiece * 1024);
+                }
                 const bf16_t* srcW = p.W + pl * p.w_plane + (long)(n0 + row) * K + kt * BK + c * 8;
                 glds16(srcW, sbase + (pl * 2 + 1) * TILE_BYTES + piece * 1024);
             }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -85,17 +94,18 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
         const char* sb = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 a[PLANES][2], b[PLANES][2];
+            bf16x8 a[PLANES][MI], b[PLANES][2];
 #pragma unroll
             for (int pl = 0; pl < PLANES; ++pl) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    a[pl][i] = lds_frag(sb + (pl * 2 + 0) * TILE_BYTES + tile_off_bytes(wr * 64 + i * 32 + lr, kk * 2 + lh));
+                for (int i = 0; i < MI; ++i)
+                    a[pl][i] = lds_frag(sb + (pl * 2 + 0) * TILE_BYTES + tile_off_bytes(wr * (MI * 32) + i * 32 + lr, kk * 2 + lh));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
                     b[pl][i] = lds_frag(sb + (pl * 2 + 1) * TILE_BYTES + tile_off_bytes(wc * 64 + i * 32 + lr, kk * 2 + lh));
-                }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (PLANES == 2) {
@@ -110,15 +120,15 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
     }
 
     if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;   // ablation: no epilogue (keeps the accumulators live)
-    // ---- stage accumulators through LDS: C[128][128] fp32 (64 KiB) ----
+    // ---- stage accumulators through LDS: C[BM][128] fp32 (64 KiB at 128 rows) ----
     float* C = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                C[(wr * 64 + i * 32 + acc_row(r, lh)) * 128 + wc * 64 + j * 32 + lr] = acc[i][j][r];
+                C[(wr * (MI * 32) + i * 32 + acc_row(r, lh)) * 128 + wc * 64 + j * 32 + lr] = acc[i][j][r];
     __syncthreads();
 
     // ---- bf16-plane outputs: 8 columns per thread -> one 16-byte store per plane (8-byte stores were
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
         // out = resid + acc + bias (usually in place).  The residual rows are fetched 8 at a time before any store:
         // a load issued after a store to the same buffer waits for the store's acknowledgement (one vmcnt for both).
 #pragma unroll
-        for (int it0 = 0; it0 < 16; it0 += 8) {
+        for (int it0 = 0; it0 < BM / 8; it0 += 8) {
             f32x4 x[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -269,18 +279,19 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
     }
 }
 
-template <int PLANES, int EPI, int FMT = FMT_BF16>
+template <int PLANES, int EPI, int FMT = FMT_BF16, bool HALFM = false>
 static int launch_one(const GemmParams& p, hipStream_t s) {
-    const int nbn = p.N / BN, nbm = (p.M + BM - 1) / BM;
+    constexpr int BMt = HALFM ? 64 : BM;
+    const int nbn = p.N / BN, nbm = (p.M + BMt - 1) / BMt;
     const int grid = ((nbm + 7) / 8) * 8 * nbn;
     const size_t lds = (size_t)PLANES * 2 * 2 * TILE_BYTES;
     static PerDeviceOnce once;
     if (once.first()) {
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<PLANES, EPI, FMT>),
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<PLANES, EPI, FMT, HALFM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.mark();
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<PLANES, EPI, FMT>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<PLANES, EPI, FMT, HALFM>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3(256), lds, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -313,6 +324,21 @@ int launch_gemm_small(const GemmParams& p, hipStream_t s) {
     if (p.epi == EPI_QKV && (p.dmodel % 128 != 0 || p.N != 3 * p.dmodel)) {
         dinoseg_set_error("gemm: QKV epilogue needs dmodel%%128==0 and N==3*dmodel");
         return -1;
+    }
+    // the residual GEMMs of a small batch (attn.proj, mlp.fc2: N = embed_dim, three column tiles): 64-row tiles while 128-row ones
+    // would leave half the CUs without a workgroup (one frame @480: 87 -> 171 workgroups; fc2 24 -> 15 us, proj 12.5 -> 8.5)
+    {
+        const int ncu = device_cu_count();
+        const long wgs128 = (long)((p.M + 127) / 128) * (p.N / BN);
+        if (p.epi == EPI_RESID && p.ksplit <= 1 && ncu > 0 && 2 * wgs128 <= ncu && !(options().gemm_dbg & 8)) {
+            if (p.fmt == FMT_FP16) {
+                if (p.planes == 1) return launch_one<1, EPI_RESID, FMT_FP16, true>(p, s);
+                if (p.planes == 2) return launch_one<2, EPI_RESID, FMT_FP16, true>(p, s);
+            } else {
+                if (p.planes == 1) return launch_one<1, EPI_RESID, FMT_BF16, true>(p, s);
+                if (p.planes == 2) return launch_one<2, EPI_RESID, FMT_BF16, true>(p, s);
+            }
+        }
     }
     if (p.fmt == FMT_FP16) {
         if (p.planes == 1 && p.epi == EPI_RESID) return launch_one<1, EPI_RESID, FMT_FP16>(p, s);
