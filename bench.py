@@ -24,7 +24,8 @@ The JSON line also carries
                  max_abs_dlogp against the reference's log-probabilities); parity_mode = the same config in bf16x3
                  (the mode that meets argmax-identical / 1e-3) with its own frames/s and match; bf16_mode = the same in bf16.
   cpu_baseline : the oracle (oracle/dinoseg_oracle.py = CPU fp32 restatement of the reference path, kind "port")
-                 timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                 timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only); --mode finetune:
+                 the oracle's forward + loss + autograd backward of one frame.
 """
 import argparse
 import json
@@ -100,6 +101,41 @@ def cpu_baseline(cfg, sd, r, warm=2, timed=10, budget_s=60.0):
             "sample": f"oracle fp32 forward (same unfused op order as the reference, materialised attention), B=1 {r}x{r} frame, "
                       f"ViT-S/8 L={cfg.n_blocks}, {warm} warm-up + {len(times)} timed runs, median {med * 1e3:.0f} ms "
                       f"(min {min(times) * 1e3:.0f}), torch {torch.__version__}, {cores} threads"}
+
+
+def cpu_baseline_finetune(cfg, sd, r, warm=1, timed=5, budget_s=40.0):
+    """The fine-tune step's CPU baseline: the oracle's forward + nll_loss + torch autograd backward over all 48 tensors (the reference's
+    training_step, pl_torch_modules.py:258-268, without the optimizer update) on this box's host cores, ONE frame of the same
+    workload; median of a bounded number of steps (kind "port")."""
+    import statistics
+
+    import torch
+    from dino_amd.weights import synthetic_frames, synthetic_labels
+    from oracle import dinoseg_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("DINOSEG_CPU_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    W = O.to_torch(sd, requires_grad=True)
+    x = O.preprocess(synthetic_frames(1, r, seed=0))
+    labels = torch.from_numpy(synthetic_labels(1, (r // 8) ** 2, cfg.n_classes, seed=1)).reshape(-1).long()
+    times, t_start = [], time.time()
+    for i in range(warm + timed):
+        for t in W.values():
+            t.grad = None
+        t0 = time.time()
+        O.nll_loss(O.dinoseg_forward(x, W, cfg.num_heads), labels).backward()
+        if i >= warm:
+            times.append(time.time() - t0)
+        if len(times) >= 2 and time.time() - t_start > budget_s:
+            break
+    med = statistics.median(times)
+    return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
+            "sample": f"oracle fp32 forward + nll_loss + autograd backward over all tensors (no optimizer update), B=1 {r}x{r} frame, "
+                      f"ViT-S/8 L={cfg.n_blocks}, {warm} warm-up + {len(times)} timed steps, median {med * 1e3:.0f} ms, "
+                      f"torch {torch.__version__}, {cores} threads"}
 
 
 def golden_check(model, arch, blocks, res, batch=1):
@@ -250,6 +286,7 @@ def bench_finetune(a, world, rank, dev, rehearsal=False):
                        "parallelism": f"dp{world} (RCCL gradient {'all-reduce' if a.collective == 'allreduce' else 'reduce-scatter + all-gather'}, 22.1 MiB fp32)"},
             "model_mfma_frac": round(fps / world * 3 * fl["total"] / 1e12 / MFMA_PEAK_TFLOPS[a.precision], 4),
             "roofline": roof, "gradient_parity": grad_parity,
+            "cpu_baseline": cpu_baseline_finetune(cfg, sd, a.res) if world == 1 and not rehearsal and not a.no_cpu_baseline else None,
         }), flush=True)
     if world > 1:
         dist.destroy_process_group()
