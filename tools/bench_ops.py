@@ -68,6 +68,30 @@ def bench_gemm(quick=True):
     lib.dinoseg_set_option(b"gemm_dbg", 0)
 
 
+def bench_gemm_vitb():
+    """the persistent kernel on ViT-B/8's shapes (16 frames @480: 57 616 rows), bf16, with the timing ablations"""
+    lib = capi.lib()
+    M, D = 16 * 3601, 768
+    for name, N, K, epi in [("proj", D, D, capi.EPI_RESID), ("fc2", D, 4 * D, capi.EPI_RESID), ("fc1", 4 * D, D, capi.EPI_GELU)]:
+        A, W = rand_bf16((M, K)), rand_bf16((N, K))
+        bias = torch.randn(N, device="cuda")
+        X = torch.zeros((M, N), device="cuda") if epi == capi.EPI_RESID else None
+        O = torch.zeros((M, N), dtype=torch.int16, device="cuda") if epi == capi.EPI_GELU else None
+        for dbg in (0, 1, 2, 3):
+            capi.check(lib.dinoseg_set_option(b"gemm_big", 2))
+            capi.check(lib.dinoseg_set_option(b"gemm_dbg", dbg))
+
+            def run():
+                capi.check(lib.dinoseg_op_gemm(A.data_ptr(), M * K, K, W.data_ptr(), N * K, M, N, K, 1, epi,
+                                               bias.data_ptr(), capi.ptr(X), capi.ptr(O), M * N, N, capi.stream_ptr()))
+            ms = timeit(run)
+            tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+            print(f"vitb {name:5s} N={N:5d} K={K:5d} skip_epilogue={dbg & 1} skip_loads={dbg >> 1}: {ms * 1e3:8.1f} us  {tf:7.1f} TFLOP/s", flush=True)
+        del A, W, X, O
+    lib.dinoseg_set_option(b"gemm_big", 1)
+    lib.dinoseg_set_option(b"gemm_dbg", 0)
+
+
 def bench_gemm_planes2():
     """bf16x3 (hi + lo planes): the 128x128 kernel against the 128x384 configuration of the persistent kernel"""
     lib = capi.lib()
@@ -196,4 +220,4 @@ def bench_attn():
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    {"gemm": bench_gemm, "gemm2": bench_gemm_planes2, "attn": bench_attn, "lngemm": bench_lngemm}[what]()
+    {"gemm": bench_gemm, "gemm2": bench_gemm_planes2, "gemmb": bench_gemm_vitb, "attn": bench_attn, "lngemm": bench_lngemm}[what]()
