@@ -5,6 +5,7 @@
 // gemm.hip; weight gradients use operands transposed by transpose_planes_kernel so that the contraction over the
 // batch rows is K-contiguous for the same NT MFMA kernel (split-K + fp32 atomics).
 #include "common.h"
+#include "gemm_ln_common.h"
 #include "kernels.h"
 
 namespace dseg {
@@ -288,12 +289,147 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// The same with sixteen lanes per row (four rows per wavefront): 16 bytes per lane and access instead of 8, the four row statistics
+// by DPP adds inside the lane group instead of wave-wide ds_bpermute butterflies.  D = 64 * NC <= 512.  A row without dy (the CLS
+// row of the final norm) runs with dy = 0: the same result as skipping it.  (3 blocks, 8 frames @480: 69 -> ~47 us per launch, 1530 -> 1577 frames/s of the fine-tune step.)
+template <int NC>
+__global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ gamma, float eps, int M,
+                                                              float* __restrict__ dx, int accumulate,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int drop_cls, int ntok, bf16_t* __restrict__ dxp, long dxp_plane,
+                                                              int planes, float* __restrict__ colsum) {
+    constexpr int D = 64 * NC;
+    __shared__ float red[3][4][D];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane & 15, rg = lane >> 4;
+    const int wid = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
+    f32x4 g[NC], dg[NC], db[NC], dn[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        g[c] = *reinterpret_cast<const f32x4*>(gamma + c * 64 + sub * 4);
+        dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[c] = dg[c];
+        dn[c] = dg[c];
+    }
+    const float invD = 1.0f / D;
+    for (int m0 = wid * 4; m0 < M; m0 += nw * 4) {
+        const int m = m0 + rg;
+        const bool valid = m < M;
+        const int mc = valid ? m : M - 1;
+        long drow = mc;
+        bool has_dy = valid;
+        if (drop_cls) {
+            const int b = mc / ntok, t = mc - b * ntok;
+            has_dy = valid && t != 0;
+            drow = (long)b * (ntok - 1) + (t > 0 ? t - 1 : 0);
+        }
+        const float* xr = x + (long)mc * D;
+        const float* dyr = dy + drow * D;
+        float* dxr = dx + (long)mc * D;
+        f32x4 xv[NC], dv[NC], old[NC];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            xv[c] = *reinterpret_cast<const f32x4*>(xr + c * 64 + sub * 4);
+            dv[c] = *reinterpret_cast<const f32x4*>(dyr + c * 64 + sub * 4);
+            if (accumulate) old[c] = *reinterpret_cast<const f32x4*>(dxr + c * 64 + sub * 4);
+            if (!has_dy) dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (xv[c][0] + xv[c][1]) + (xv[c][2] + xv[c][3]);
+        }
+        const float mean = aln::row16_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[c][e] -= mean;
+                q += xv[c][e] * xv[c][e];
+            }
+        const float rstd = 1.0f / sqrtf(aln::row16_sum(q) * invD + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = xv[c][e] * rstd;
+                const float ge = dv[c][e] * g[c][e];
+                dg[c][e] += dv[c][e] * xh;
+                db[c][e] += dv[c][e];
+                sg += ge;
+                sgx += ge * xh;
+                xv[c][e] = xh;
+                dv[c][e] = ge;
+            }
+        sg = aln::row16_sum(sg) * invD;
+        sgx = aln::row16_sum(sgx) * invD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = rstd * (dv[c][e] - sg - xv[c][e] * sgx);
+            if (accumulate) r += old[c];
+            if (valid) {
+                *reinterpret_cast<f32x4*>(dxr + c * 64 + sub * 4) = r;
+                dn[c] += r;
+                if (dxp) {
+                    uint2 hi, lo;
+                    split_bf16x2(r[0], r[1], hi.x, lo.x);
+                    split_bf16x2(r[2], r[3], hi.y, lo.y);
+                    bf16_t* o = dxp + (long)m * D + c * 64 + sub * 4;
+                    *reinterpret_cast<uint2*>(o) = hi;
+                    if (planes == 2) *reinterpret_cast<uint2*>(o + dxp_plane) = lo;
+                }
+            }
+        }
+    }
+    // the four row groups of the wave, then the four waves, then one atomic per column and block
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = dg[c][e], b = db[c][e], n = dn[c][e];
+            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+            n += __shfl_xor(n, 16); n += __shfl_xor(n, 32);
+            if (rg == 0) {
+                red[0][wv][c * 64 + sub * 4 + e] = a;
+                red[1][wv][c * 64 + sub * 4 + e] = b;
+                red[2][wv][c * 64 + sub * 4 + e] = n;
+            }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        if (dgamma) atomicAdd(dgamma + c, a);
+        if (dbeta) atomicAdd(dbeta + c, b);
+        if (colsum) {
+            const float n = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
+            if (n != 0.f) atomicAdd(colsum + c, n);
+        }
+    }
+}
+
 int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, float eps, int M, int D, float* dx,
                          int accumulate, float* dgamma, float* dbeta, int drop_cls, int ntok, hipStream_t s, bf16_t* dxp,
                          long dxp_plane, int planes, float* colsum) {
     if (D % 128 != 0 || D > 1024) {
         dinoseg_set_error("layernorm_bwd: D=%d must be a multiple of 128 and <= 1024", D);
         return -1;
+    }
+    if (D % 64 == 0 && D <= 512 && !(options().gemm_dbg & 16)) {      // sixteen lanes per row (gemm_dbg bit 4: the one-wave-per-row kernel, A/B)
+        int grid16 = (M + 15) / 16;
+        if (grid16 > 1024) grid16 = 1024;
+#define DSEG_LNB16(NC)                                                                                                       \
+    case NC:                                                                                                                 \
+        hipLaunchKernelGGL((layernorm_bwd16_kernel<NC>), dim3(grid16), dim3(256), 0, s, dy, x, gamma, eps, M, dx, accumulate, \
+                           dgamma, dbeta, drop_cls, ntok, dxp, dxp_plane, planes, colsum);                                   \
+        break;
+        switch (D / 64) { DSEG_LNB16(2) DSEG_LNB16(4) DSEG_LNB16(6) DSEG_LNB16(8) }
+#undef DSEG_LNB16
+        DSEG_CHECK_HIP(hipGetLastError());
+        return 0;
     }
     int grid = (M + 3) / 4;
     if (grid > 1024) grid = 1024;
