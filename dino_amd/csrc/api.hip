@@ -832,6 +832,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().gemm_big = value;
         return 0;
     }
+    if (strcmp(key, "route_ab") == 0) {
+        dseg::options().route_ab = value;
+        return 0;
+    }
     if (strcmp(key, "fp16_patch_planes") == 0) {
         dseg::options().fp16_patch_planes = value == 1 ? 1 : 2;
         return 0;

@@ -330,7 +330,7 @@ int launch_gemm_small(const GemmParams& p, hipStream_t s) {
     {
         const int ncu = device_cu_count();
         const long wgs128 = (long)((p.M + 127) / 128) * (p.N / BN);
-        if (p.epi == EPI_RESID && p.ksplit <= 1 && ncu > 0 && 2 * wgs128 <= ncu && !(options().gemm_dbg & 8)) {
+        if (p.epi == EPI_RESID && p.ksplit <= 1 && ncu > 0 && 2 * wgs128 <= ncu && !(options().route_ab & 1)) {
             if (p.fmt == FMT_FP16) {
                 if (p.planes == 1) return launch_one<1, EPI_RESID, FMT_FP16, true>(p, s);
                 if (p.planes == 2) return launch_one<2, EPI_RESID, FMT_FP16, true>(p, s);

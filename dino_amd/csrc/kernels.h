@@ -118,6 +118,9 @@ struct Options {
     int proj_fused = 1;      // 1: the block's attention output projection runs inside the fused MLP launch
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 8;       // (8 frames @480: +6 %, 12: +16 %, 16: +12 %; 6 frames and fewer: slower split)
+    int route_ab = 0;        // A/B switches of dispatch routes that do not change results: bit 0 = 128-row tiles for the residual GEMMs of a small
+                             // batch (gemm.hip HALFM off), bit 1 = one wave per row in the LayerNorm backward (train.hip), bit 2 = the weight-
+                             // gradient GEMM's split count not rounded to a multiple of 8 (its XCD-aware grid off: train_api.hip, gemm_tn.hip)
     int fp16_patch_planes = 1;      // precision fp16: 1 = the patch embedding on one fp16 plane like the rest of the mode (2466 -> 2486 frames/s,
                                     // 0.0263 / 8 flips -> 0.0218 / 5 on the G3 fixture), 2 = on bf16 hi+lo planes (round 4's first build).
                                     // Read when the weights are packed: set it before the first forward

@@ -418,7 +418,7 @@ int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, fl
         dinoseg_set_error("layernorm_bwd: D=%d must be a multiple of 128 and <= 1024", D);
         return -1;
     }
-    if (D % 64 == 0 && D <= 512 && !(options().gemm_dbg & 16)) {      // sixteen lanes per row (gemm_dbg bit 4: the one-wave-per-row kernel, A/B)
+    if (D % 64 == 0 && D <= 512 && !(options().route_ab & 2)) {      // sixteen lanes per row (route_ab bit 1: the one-wave-per-row kernel, A/B)
         int grid16 = (M + 15) / 16;
         if (grid16 > 1024) grid16 = 1024;
 #define DSEG_LNB16(NC)                                                                                                       \

@@ -595,6 +595,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
             const int row_tiles = (n_rows + 127) / 128, tiles = row_tiles * (k_pad / 128), nchunks = (m_rows + 63) / 64;
             int ks = splitk_budget() / tiles;
             if (ks > nchunks / 2) ks = nchunks / 2;
+            if (ks >= 8 && !(dseg::options().route_ab & 4)) ks &= ~7;      // a multiple of 8: the kernel's XCD-aware form (gemm_tn.hip)
             if (ks < 1) ks = 1;
             const int per = (nchunks + ks - 1) / ks, used = (nchunks + per - 1) / per;
             g.part = F32(L.SPLITK); g.ld_part = k_pad; g.split_stride = (long)row_tiles * 128 * k_pad; g.ksplit = ks;
@@ -622,6 +623,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
         const int row_tiles = (n_rows + 127) / 128, tiles = row_tiles * (k_cols / 128), nchunks = (m_rows + 63) / 64;
         int ks = splitk_budget() / tiles;
         if (ks > nchunks / 2) ks = nchunks / 2;
+        if (ks >= 8 && !(dseg::options().route_ab & 4)) ks &= ~7;      // a multiple of 8: the kernel's XCD-aware form (gemm_tn.hip)
         if (ks < 1) ks = 1;
         const int per = (nchunks + ks - 1) / ks, used = (nchunks + per - 1) / per;
         g.part = F32(L.SPLITK); g.ld_part = k_cols; g.split_stride = (long)row_tiles * 128 * k_cols; g.ksplit = ks;

@@ -203,6 +203,8 @@ int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
  *                beside the input-gradient chain (forked from / joined to the caller's stream by events: stream-ordered, capturable),
  *                1 = everything on the caller's stream (use it when several processes share one GPU);
  *   "splitk_tiles" 512 [default]: partial 128x128 tiles of one weight-gradient GEMM (<= 768);
+ *   "route_ab"   0 [default]: A/B switches of dispatch routes that do not change results (bit 0: 128-row tiles for the residual GEMMs
+ *                of a small batch; bit 1: the one-wave-per-row LayerNorm backward; bit 2: the weight-gradient GEMM's 2-D grid);
  *   "attn_variant", "gemm_dbg", "attn_dbg": kernel A/B and timing-ablation switches (tools/bench_ops.py). */
 int dinoseg_set_option(const char* key, int32_t value);
 

@@ -90,7 +90,7 @@ def test_gemm_epilogues(cuda, planes, N):
 def test_residual_gemm_small_batch_tiles(cuda, planes, M, K):
     """The residual GEMMs of a small batch (attn.proj / mlp.fc2 of one frame: 29 x 3 tiles of 128 x 128 on 256 CUs) run on 64 x 128
     tiles (gemm.hip, HALFM); every output element sees the same MFMAs in the same order: bit-identical to the 128-row tiles
-    (gemm_dbg bit 3 forces those) and right against the fp64 product of the operands the kernel saw."""
+    (route_ab bit 0 forces those) and right against the fp64 product of the operands the kernel saw."""
     N = 384
     A, W, bias = seeded((M, K), 61), seeded((N, K), 62) * 0.2, seeded((N,), 63)
     Ap, Wp = pack(A, planes), pack(W, planes)
@@ -98,14 +98,14 @@ def test_residual_gemm_small_batch_tiles(cuda, planes, M, K):
     lib = capi.lib()
     outs = []
     try:
-        for dbg in (8, 0):
-            capi.check(lib.dinoseg_set_option(b"gemm_dbg", dbg))
+        for ab in (1, 0):
+            capi.check(lib.dinoseg_set_option(b"route_ab", ab))
             X = X0.clone()
             capi.check(lib.dinoseg_op_gemm(Ap.data_ptr(), M * K, K, Wp.data_ptr(), N * K, M, N, K, planes, capi.EPI_RESID,
                                            bias.data_ptr(), X.data_ptr(), None, 0, 0, S()))
             outs.append(X)
     finally:
-        capi.check(lib.dinoseg_set_option(b"gemm_dbg", 0))
+        capi.check(lib.dinoseg_set_option(b"route_ab", 0))
     assert torch.equal(outs[0], outs[1])
     base = (quant_like(A, planes).double() @ quant_like(W, planes).double().t() + bias.double()).float()
     assert torch.allclose(outs[1], X0 + base, atol=3e-4 * math.sqrt(K / 64), rtol=1e-5)
