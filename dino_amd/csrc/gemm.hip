@@ -145,11 +145,22 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
         const int which = (EPI == EPI_QKV) ? n0 / p.dmodel : 0;
         const int hcol = (EPI == EPI_QKV) ? n0 % p.dmodel + c8 * 8 : 0;
         bf16_t* qkv_base = (EPI == EPI_QKV) ? (which == 0 ? p.q : (which == 1 ? p.k : p.v)) : nullptr;
-#pragma unroll 2
-        for (int it = 0; it < 8; ++it) {
+        // backward epilogues: the saved pre-activations of all eight row steps are fetched up front (inside the loop every step waited
+        // for its own load: eight HBM latencies per workgroup, 149 us for fc2's input gradient at 8 frames where the GEMM itself is 34 GFLOP)
+        uint4 aux_h[8], aux_l[8];
+        if (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int gmr = m0 + it * 16 + rb16;
+                const bf16_t* ax = p.aux_in + (long)(gmr < M ? gmr : M - 1) * p.ldo + gn;
+                aux_h[it] = *reinterpret_cast<const uint4*>(ax);
+                if (PLANES == 2 && EPI == EPI_DGELU) aux_l[it] = *reinterpret_cast<const uint4*>(ax + p.aux_plane);
+            }
+        }
+        auto row_step = [&](int it, const uint4& ah_in, const uint4& al_in) __attribute__((always_inline)) -> bool {
             const int row = it * 16 + rb16;
             const int gm = m0 + row;
-            if (gm >= M) break;
+            if (gm >= M) return false;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(C + row * 128 + c8 * 8);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(C + row * 128 + c8 * 8 + 4);
             float v[8] = {v0[0] + b8[0], v0[1] + b8[1], v0[2] + b8[2], v0[3] + b8[3],
@@ -165,8 +176,7 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
                 if (PLANES == 2) *reinterpret_cast<uint4*>(ad + p.aux_plane) = plo;
             }
             if (EPI == EPI_DGELU || EPI == EPI_DRELU) {
-                const bf16_t* ax = p.aux_in + (long)gm * p.ldo + gn;
-                const uint4 ah = *reinterpret_cast<const uint4*>(ax);
+                const uint4 ah = ah_in;
                 const uint32_t aw[4] = {ah.x, ah.y, ah.z, ah.w};
                 float a[8];
 #pragma unroll
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
                     a[2 * e + 1] = bf16_hi_to_f32(aw[e]);
                 }
                 if (PLANES == 2 && EPI == EPI_DGELU) {
-                    const uint4 al = *reinterpret_cast<const uint4*>(ax + p.aux_plane);
+                    const uint4 al = al_in;
                     const uint32_t lw[4] = {al.x, al.y, al.z, al.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -225,6 +235,17 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
             }
             *reinterpret_cast<uint4*>(dst) = hi;
             if (PLANES == 2) *reinterpret_cast<uint4*>(dst + plane_stride) = lo;
+            return true;
+        };
+        if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                if (!row_step(it, aux_h[it], aux_l[it])) break;
+        } else {
+            const uint4 none = {0u, 0u, 0u, 0u};
+#pragma unroll 2
+            for (int it = 0; it < 8; ++it)
+                if (!row_step(it, none, none)) break;
         }
         return;
     }
