@@ -8,8 +8,11 @@
 // exactly like the V^T fragments of the attention kernels:  A fragment (rows = n, k = m) from the dY tile, B fragment
 // (k = m, columns = k) from the X tile.
 //
-// Tile 128 (n) x 128 (k) per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 2 x 2 accumulators), 64 batch rows
-// per stage, double-buffered.  grid.y slices the batch (split-K); every slice writes its partial tile with plain
+// Tile 128 (n) x 128 (k) per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 2 x 2 accumulators), 32 batch rows
+// per stage in a four-slot ring: the LDS-DMA of stage c + 3 is issued while stage c is multiplied, one counted `s_waitcnt vmcnt`
+// + raw `s_barrier` per stage (inline-asm DMA: behind the builtin hipcc drains the queue in front of every LDS read).  The first
+// version -- 64 rows per stage, two slots, `vmcnt(0)` + `__syncthreads()` per stage -- was bound by one HBM latency per stage: 2.9 us
+// for 16 MFMAs per wave.  The batch is sliced (split-K); every slice writes its partial tile with plain
 // 16-byte stores (GemmParams-style split_stride) and launch_splitk_reduce sums the slices into the gradient.
 // Swizzle of the 256-byte rows: 16-byte chunk ^ 2*(row & 3): the 4 rows x 32 bytes a 16-lane group of a transposing read
 // touches fall on 4 distinct 32-byte slots of one 128-byte window.
@@ -20,8 +23,9 @@
 namespace dseg {
 
 namespace tn {
-constexpr int BN = 128, BKc = 128, BMr = 64;          // tile: BN rows (n) x BKc columns (k); BMr batch rows per stage
-constexpr int TILE = BMr * 256;                       // one [64][128] bf16 tile = 16 KiB
+constexpr int BN = 128, BKc = 128, BMr = 32;          // tile: BN rows (n) x BKc columns (k); BMr batch rows per stage
+constexpr int TILE = BMr * 256;                       // one [32][128] bf16 tile = 8 KiB
+constexpr int RING = 4;                               // stages in LDS: one multiplied, up to three in flight
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row & 3) << 1); }
 }  // namespace tn
 
@@ -56,15 +60,28 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_tn_kernel(TnP
     const int nc = nchunks - c_begin < per ? nchunks - c_begin : per;
     if (nc <= 0) return;
 
-    // loader: a 1-KiB piece = 4 rows x 256 B; 16 pieces per tile, 4 per wave and tile
-    auto stage = [&](int st, int chunk) {
+    // loader: a 1-KiB piece = 4 rows x 256 B; 8 pieces per tile, 2 per wave and tile.  Scalar base + 32-bit lane offset (checked by
+    // the launcher), LDS destination through m0.
+    constexpr int PP = PLANES * 4;                     // LDS-DMA instructions per wave and stage
+    auto dma = [&](const bf16_t* base, uint32_t voff, char* lds) __attribute__((always_inline)) {
+        const uint32_t lds_dst = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds);
+        const uint64_t src = reinterpret_cast<uint64_t>(base);
+        const uint64_t src_u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)src) |
+                               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(src >> 32)) << 32);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(src_u), "s"(lds_dst)
+                     : "memory");
+    };
+    auto stage = [&](int st, int chunk) __attribute__((always_inline)) {
         char* sbase = smem + st * STAGE_BYTES;
         const int prow = lane >> 4, slot = lane & 15;
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int piece = wave * 4 + i;
+            for (int i = 0; i < 2; ++i) {
+                const int piece = wave * 2 + i;
                 const int row = piece * 4 + prow;
                 const int c = swz(row, slot);              // logical chunk stored in physical slot `slot`
                 int gm = chunk * BMr + row;
@@ -72,8 +89,8 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_tn_kernel(TnP
                 // (a dY narrower than the 128-column tile -- the classifier's 64-column d logits -- repeats its last 8 columns: they
                 //  only feed output rows >= N, which are not written)
                 const int yc = n0 + c * 8 <= p.ldy - 8 ? n0 + c * 8 : p.ldy - 8;
-                glds16(p.Y + pl * p.y_plane + (long)gm * p.ldy + yc, sbase + (pl * 2 + 0) * TILE + piece * 1024);
-                glds16(p.X + pl * p.x_plane + (long)gm * p.ldx + k0 + c * 8, sbase + (pl * 2 + 1) * TILE + piece * 1024);
+                dma(p.Y, (uint32_t)((pl * p.y_plane + (long)gm * p.ldy + yc) * 2), sbase + (pl * 2 + 0) * TILE + piece * 1024);
+                dma(p.X, (uint32_t)((pl * p.x_plane + (long)gm * p.ldx + k0 + c * 8) * 2), sbase + (pl * 2 + 1) * TILE + piece * 1024);
             }
     };
 
@@ -107,18 +124,23 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_tn_kernel(TnP
     const uint4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
-    stage(0, c_begin);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RING - 1; ++c)
+        if (c < nc) stage(c, c_begin + c);
 
     for (int ci = 0; ci < nc; ++ci) {
-        const int cur = ci & 1;
-        if (ci + 1 < nc) stage(cur ^ 1, c_begin + ci + 1);
-        const char* sb = smem + cur * STAGE_BYTES;
+        // stage ci landed (this wave's pieces); the up to two younger stages stay in flight
+        const int rem = nc - 1 - ci;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // everyone's pieces of stage ci landed; everyone is done reading the slot of stage ci - 1
+        if (ci + RING - 1 < nc) stage((ci + RING - 1) & (RING - 1), c_begin + ci + RING - 1);
+        const char* sb = smem + (ci & (RING - 1)) * STAGE_BYTES;
         const int m_chunk = (c_begin + ci) * BMr;
         const bool ragged = m_chunk + BMr > M;              // wave-uniform: only the last chunk of the batch
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < BMr / 16; ++ks) {
             bf16x8 a[PLANES][2], b[PLANES][2];
 #pragma unroll
             for (int pl = 0; pl < PLANES; ++pl)
@@ -158,9 +180,9 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_tn_kernel(TnP
                 bsum = mfma32(wc ? a[0][1] : a[0][0], ones, bsum);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads of the stage are complete
     }
+    __syncthreads();          // everyone is done with the ring: the partial tile is staged in its place
 
     if (do_sum && lr == 0) {        // every column of bsum holds the same sums: column 0 adds them
 #pragma unroll
@@ -197,7 +219,11 @@ int launch_gemm_tn(const TnParams& p, hipStream_t s) {
         return -1;
     }
     const int tiles = ((p.N + BN - 1) / BN) * (p.Kc / BKc);
-    const size_t lds = (size_t)2 * p.planes * 2 * TILE;         // 64 KiB (1 plane) / 128 KiB (2 planes); >= the 64 KiB C tile
+    const size_t lds = (size_t)RING * p.planes * 2 * TILE;      // 64 KiB (1 plane) / 128 KiB (2 planes); >= the 64 KiB C tile
+    if (((long)p.planes * p.y_plane + (long)p.M * p.ldy) * 2 >= (1L << 32) || ((long)p.planes * p.x_plane + (long)p.M * p.ldx) * 2 >= (1L << 32)) {
+        dinoseg_set_error("gemm_tn: operand planes beyond 4 GiB (32-bit lane offsets)");
+        return -1;
+    }
     const bool xcd_aware = p.ksplit % 8 == 0;
     const dim3 grid = xcd_aware ? dim3(tiles * p.ksplit, 1) : dim3(tiles, p.ksplit);
     if (p.planes == 1) {

@@ -592,9 +592,9 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
             TnParams g = {};
             g.Y = Y; g.y_plane = y_plane; g.ldy = ldy; g.X = X; g.x_plane = x_plane; g.ldx = ldx;
             g.M = m_rows; g.N = n_rows; g.Kc = k_pad; g.planes = planes;
-            const int row_tiles = (n_rows + 127) / 128, tiles = row_tiles * (k_pad / 128), nchunks = (m_rows + 63) / 64;
+            const int row_tiles = (n_rows + 127) / 128, tiles = row_tiles * (k_pad / 128), nchunks = (m_rows + 31) / 32;
             int ks = splitk_budget() / tiles;
-            if (ks > nchunks / 2) ks = nchunks / 2;
+            if (ks > nchunks / 4) ks = nchunks / 4;
             if (ks >= 8 && !(dseg::options().route_ab & 4)) ks &= ~7;      // a multiple of 8: the kernel's XCD-aware form (gemm_tn.hip)
             if (ks < 1) ks = 1;
             const int per = (nchunks + ks - 1) / ks, used = (nchunks + per - 1) / per;
@@ -620,9 +620,9 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
         TnParams g = {};
         g.Y = Y; g.y_plane = y_plane; g.ldy = ldy; g.X = X; g.x_plane = x_plane; g.ldx = ldx;
         g.M = m_rows; g.N = n_rows; g.Kc = k_cols; g.planes = planes;
-        const int row_tiles = (n_rows + 127) / 128, tiles = row_tiles * (k_cols / 128), nchunks = (m_rows + 63) / 64;
+        const int row_tiles = (n_rows + 127) / 128, tiles = row_tiles * (k_cols / 128), nchunks = (m_rows + 31) / 32;
         int ks = splitk_budget() / tiles;
-        if (ks > nchunks / 2) ks = nchunks / 2;
+        if (ks > nchunks / 4) ks = nchunks / 4;
         if (ks >= 8 && !(dseg::options().route_ab & 4)) ks &= ~7;      // a multiple of 8: the kernel's XCD-aware form (gemm_tn.hip)
         if (ks < 1) ks = 1;
         const int per = (nchunks + ks - 1) / ks, used = (nchunks + per - 1) / per;
