@@ -29,8 +29,9 @@ def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
 
-@pytest.mark.parametrize("D", [128, 384])
+@pytest.mark.parametrize("D", [128, 256, 384, 512, 768])
 def test_layernorm_bwd(cuda, D):
+    # (D <= 512: sixteen lanes per row, four rows per wave -- 87 rows leave a ragged last group; 768: one wave per row)
     M, ntok = 3 * 29, 29
     x = (seeded((M, D), 1) * 2 + 0.3).cpu().requires_grad_(True)
     g = (1 + 0.2 * seeded((D,), 2)).cpu().requires_grad_(True)
