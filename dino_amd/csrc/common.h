@@ -77,7 +77,12 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
             b = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
         }
         hi = pack_f16x2(a, b);
-        lo = pack_f16x2(a - lo_to_f32<FMT_FP16>(hi), b - hi_to_f32<FMT_FP16>(hi));
+        // a - (float)hi as ONE instruction per element: v_fma_mix_f32 reads the fp16 half in place (fma(hi, -1, a): the product is exact,
+        // one rounding -- the same bits as v_cvt_f32_f16 + v_sub_f32, two issue slots less per pair in the hi+lo attention's tile body)
+        float ra, rb;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+        lo = pack_f16x2(ra, rb);
     } else {
         split_bf16x2(a, b, hi, lo);
     }
