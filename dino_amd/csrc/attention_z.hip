@@ -578,6 +578,12 @@ static int launch_zs(const AttnParams& p, hipStream_t s) {
     const int npairs = p.B * p.heads;
     const int grid = ((npairs + 7) / 8) * 8 * nq;
     const size_t lds = (size_t)KS * 2 * 2 * KV_TILE + 16;
+    static PerDeviceOnce once;          // (more than 64 KiB of dynamic LDS: say so once per device)
+    if (once.first()) {
+        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_zs_kernel<FMT, KS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.mark();
+    }
     hipLaunchKernelGGL((attn_fwd_zs_kernel<FMT, KS>), dim3(grid), dim3(KS * 256), lds, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
