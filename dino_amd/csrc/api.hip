@@ -190,7 +190,7 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
                 h->prof_recs.clear();
                 for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
                 h->prof_pool.clear();
-                h->wbuf = nullptr; h->pos_cache = nullptr;
+                h->wbuf = nullptr; h->pos_cache = nullptr; h->pos_r = -1;
                 h->wbuf_bytes = h->pos_cap = 0;
                 h->tws_B = h->tws_r = h->tr_B = -1;
                 h->packed.clear();
@@ -209,7 +209,7 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
     t.shape.assign(shape, shape + ndim);
     h->bound[name] = t;
     h->weights_ready = false;
-    h->pos_r = -1;
+    h->pos_stale = true;        // (dinoseg_refresh_weights resamples the cached resolution again)
     return 0;
 }
 
@@ -254,6 +254,9 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
             dinoseg_set_error("dinoseg_refresh_weights: missing key '%s' (strict load)", kv.first.c_str());
             return -3;
         }
+    // the process-wide option is read ONCE per refresh: the packs below and every forward until the next refresh use this value
+    // (a later dinoseg_set_option on a live handle takes effect with the next refresh, never between a pack and its GEMM)
+    h->fp16_patch_planes_snap = options().fp16_patch_planes;
     const std::vector<LinSpec> specs = linear_specs(h);
     auto ln_fed = [&](const LinSpec& sp) {        // qkv / fc1: also kept slab-major for the LayerNorm-fused kernel
         const bool qkv = sp.wname.find("attn.qkv.weight") != std::string::npos;
@@ -330,7 +333,16 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     h->packed_mlp_stale = true;
     DSEG_TRY(ensure_mlp_packs(h, s));
     h->weights_ready = true;
-    h->pos_r = -1;   // pos_embed may have changed (fine-tune)
+    // pos_embed may have changed in place (load_state_dict into the same storage, an optimizer step on an unfrozen backbone).  A
+    // captured forward contains no resample launch and never calls dinoseg_prepare_resolution, so "resample on the next forward"
+    // (pos_r = -1 alone) would let a replay read the OLD rows next to freshly packed linears: resample here, in stream order with
+    // the packs, into the SAME buffer: like the re-packed linears, the captured pointers stay valid and the replay reads new rows.
+    if (h->pos_r > 0 && h->pos_cache != nullptr && h->bound.count("dino.pos_embed")) {
+        DSEG_TRY(launch_pos_resample(W(h, "dino.pos_embed"), h->cfg.pos_grid, h->cfg.embed_dim, h->pos_r / 8, h->pos_cache, s));
+    } else {
+        h->pos_r = -1;      // (nothing cached: the next forward resamples, and dinoseg_prepare_resolution counts a new generation)
+    }
+    h->pos_stale = false;
     return 0;
 }
 
@@ -344,7 +356,7 @@ extern "C" int dinoseg_prepare_resolution(dinoseg_handle* h, int32_t r, void* st
         dinoseg_set_error("dinoseg_prepare_resolution: dino.pos_embed not bound");
         return -3;
     }
-    if (h->pos_r == r) return 0;
+    if (h->pos_r == r && !h->pos_stale) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DeviceGuard guard(h);
     const int o = r / 8, D = h->cfg.embed_dim;
@@ -358,6 +370,7 @@ extern "C" int dinoseg_prepare_resolution(dinoseg_handle* h, int32_t r, void* st
     }
     DSEG_TRY(launch_pos_resample(W(h, "dino.pos_embed"), h->cfg.pos_grid, D, o, h->pos_cache, s));
     h->pos_r = r;
+    h->pos_stale = false;
     return 0;
 }
 
@@ -433,8 +446,11 @@ static int ensure_workspace(dinoseg_handle* h, int slot, const WsLayout& L, int 
         wB = -1;
     }
     if (wB != B || wr != r) {
-        // key/value pad rows beyond ntok must be finite: zero Q/K/V once per layout (never written afterwards)
+        // key/value pad rows beyond ntok must be finite: zero Q/K/V once per layout (never written afterwards).  A layout change is a
+        // new state generation: a forward captured under the OLD layout holds no memset node, and another layout's launches have since
+        // written other things (fp32 residual rows ...) where its pad rows live -- the owner of the graph must capture again.
         DSEG_CHECK_HIP(hipMemsetAsync(ws + L.Q, 0, L.CTX - L.Q, s));
+        ++h->generation;
         wB = B;
         wr = r;
     }

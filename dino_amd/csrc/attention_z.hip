@@ -611,14 +611,16 @@ int launch_attention_z(const AttnParams& p, hipStream_t s) {
         //  the chip below one round of 128-query workgroups the finer grain wins: 1 frame 0.54 vs 0.69 ms, 4 frames 1.09 vs 1.16)
         const int ncu = device_cu_count();
         const long wgs4 = (long)((p.B * p.heads + 7) / 8) * 8 * ((p.ntok + 127) / 128);
-        const bool wide = ncu > 0 && (wgs4 >= 4L * ncu || (p.shared_gpu && wgs4 >= 2L * ncu));
+        // (attn_variant bit 12: the 256-query workgroups at every grid size -- tests compare kernels at equal workgroup granularity: the
+        //  exact recomputation is decided per workgroup)
+        const bool wide = (ncu > 0 && (wgs4 >= 4L * ncu || (p.shared_gpu && wgs4 >= 2L * ncu))) || (options().attn_variant & 4096);
         // fewer 128-query workgroups than CUs and at least four K/V tiles: split the keys over wave groups (attn_fwd_zs_kernel;
         // attn_variant bit 9 keeps the unsplit kernel: A/B and tests)
         // (decided for the batch of the WHOLE call: the split changes the summation order, and the half-batches of a two-stream forward
         //  must run what one stream would.  Inference only -- lse == nullptr: the training forward keeps one arithmetic at every batch
         //  size, tests/test_train_gpu.py: a batch-8 step is the mean of eight single-frame steps to 6e-7.)
         const long wgs4_call = (long)(((p.dispatch_B > 0 ? p.dispatch_B : p.B) * p.heads + 7) / 8) * 8 * ((p.ntok + 127) / 128);
-        const bool ksplit = ncu > 0 && wgs4_call < ncu && p.ntok > 3 * az::KB && p.lse == nullptr && !(options().attn_variant & 512);
+        const bool ksplit = ncu > 0 && wgs4_call < ncu && p.ntok > 3 * az::KB && p.lse == nullptr && !(options().attn_variant & (512 | 2048));
         if (ksplit) {      // (one frame @480, 57 tiles: 42 us unsplit, 33 with two groups, 31 with three, 37 with four -- 128 registers spill)
             if (p.ntok >= 32 * az::KB) {
                 if (p.fmt == FMT_FP16) return launch_zs<FMT_FP16, 3>(p, s);
@@ -627,6 +629,10 @@ int launch_attention_z(const AttnParams& p, hipStream_t s) {
             if (p.fmt == FMT_FP16) return launch_zs<FMT_FP16, 2>(p, s);
             return launch_zs<FMT_BF16, 2>(p, s);
         }
+        // attn_variant bit 10: the hand-scheduled assembly tile loop (attention_za.hip; bit-identical outputs)
+        // (bit 11: at every grid size -- tests)
+        if (((wide && !(options().attn_variant & 64)) || (options().attn_variant & 2048)) && (options().attn_variant & 1024))
+            return launch_attention_za(p, s);
         if (p.fmt == FMT_FP16) {
             if (wide && !(options().attn_variant & 64)) return launch_z<1, 4, 8, FMT_FP16>(p, s);
             return launch_z<1, 4, 4, FMT_FP16>(p, s);

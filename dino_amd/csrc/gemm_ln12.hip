@@ -175,8 +175,10 @@ __global__ __launch_bounds__(ln12::THREADS, 3) void gemm_ln12_kernel(LnGemmParam
                     w[q].x = pack_bf16x2(val[4 * q], val[4 * q + 1]);
                     w[q].y = pack_bf16x2(val[4 * q + 2], val[4 * q + 3]);
                 } else {
-                    w[q].x = pack2<FMT>(val[4 * q], val[4 * q + 1]);
-                    w[q].y = pack2<FMT>(val[4 * q + 2], val[4 * q + 3]);
+                    // GEMM outputs are unbounded: saturate at the fp16 range like gemm.hip / gemm_big.hip (an inf in Q or K turns
+                    // into NaN probabilities; the small-batch route of the same weights would clamp)
+                    w[q].x = pack2_sat<FMT>(val[4 * q], val[4 * q + 1]);
+                    w[q].y = pack2_sat<FMT>(val[4 * q + 2], val[4 * q + 3]);
                 }
             }
 #pragma unroll

@@ -47,10 +47,12 @@ struct dinoseg_handle {
     bool packed_mlp_stale = false;         // the fragment-order packs are made on the first forward that uses them (the fine-tune
                                            // step refreshes the weights every step and never runs the fused MLP kernel)
     bool weights_ready = false;
+    int fp16_patch_planes_snap = 1;        // option fp16_patch_planes as of the last dinoseg_refresh_weights (what the packs were made for)
     int64_t generation = 0;     // dinoseg_state_generation: bumped when an address or cached content a captured forward bakes in changes
     // pos-embed cache
     float* pos_cache = nullptr;
-    int pos_r = -1;
+    int pos_r = -1;             // resolution the cache holds (-1: nothing)
+    bool pos_stale = false;     // dino.pos_embed was (re)bound since the cache was filled
     size_t pos_cap = 0;
     // activation workspace (library-owned)
     char* ws = nullptr;
@@ -146,7 +148,7 @@ static inline void prof_end(dinoseg_handle* h, int idx, hipStream_t s) {
 static inline int head_planes() { return 2; }
 // planes of the patch-embedding GEMM: the mode's own, except that the fp16 mode runs it split like the head (raw pixel operands,
 // 0.13 % of the FLOPs)
-static inline int patch_planes(const dinoseg_handle* h) { return (h->fmt == FMT_FP16 && options().fp16_patch_planes == 2) ? 2 : h->planes; }
+static inline int patch_planes(const dinoseg_handle* h) { return (h->fmt == FMT_FP16 && h->fp16_patch_planes_snap == 2) ? 2 : h->planes; }
 // format of the split (two-plane) operands of the head (and of the patch embedding where it runs split): fp16 only in the fp16 hi+lo
 // mode -- the single-plane fp16 mode keeps them bf16 hi+lo (their error is far below that mode's)
 static inline int split_fmt(const dinoseg_handle* h) { return h->planes == 2 ? h->fmt : (int)FMT_BF16; }

@@ -151,6 +151,7 @@ struct AttnParams {
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
 int launch_attention_z(const AttnParams& p, hipStream_t s);    // zero-reference softmax, <= 128 registers: 4 waves per SIMD (attention_z.hip)
+int launch_attention_za(const AttnParams& p, hipStream_t s);   // the same arithmetic, tile loop as a hand-scheduled assembly pipeline (attention_za.hip)
 
 // fp32 [rows, cols] -> bf16 planes [planes][rows_pad][cols_pad], zero padded
 int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,

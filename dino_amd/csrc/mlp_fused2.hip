@@ -881,7 +881,7 @@ __global__ __launch_bounds__(mf2::THREADS, 2) void mlp_fused2_kernel(MlpFusedPar
                     if constexpr (G < 16) ex[G] = s_cur[G] * sc;
                     else if constexpr (G < 24) {      // (V stays bf16 in the fp16 mode: kernels.h, AttnParams::fmt; t is wave-uniform)
                         if (FMT == FMT_BF16 || t >= 2 * NDB) pd[G - 16] = pack_bf16x2(ex[2 * (G - 16)], ex[2 * (G - 16) + 1]);
-                        else pd[G - 16] = pack2<FMT>(ex[2 * (G - 16)], ex[2 * (G - 16) + 1]);
+                        else pd[G - 16] = pack2_sat<FMT>(ex[2 * (G - 16)], ex[2 * (G - 16) + 1]);      // (Q / K: saturating, as gemm_ln12.hip)
                     }
                 };
                 __builtin_amdgcn_sched_barrier(0);

@@ -23,6 +23,12 @@ from .weights import VIT_B8, VIT_S8, ViTConfig
 _IMAGENET_MEAN = (0.485, 0.456, 0.406)
 _IMAGENET_STD = (0.229, 0.224, 0.225)
 _PRECISIONS = {"bf16": capi.BF16, "bf16x3": capi.BF16X3, "fp16": capi.FP16, "fp16x3": capi.FP16X3}
+# precision "auto" (the default): the native handle of a call is chosen by what the call needs -- inference (predict,
+# forward_frames, forward under no_grad or with nothing trainable, the visualisation paths) runs fp16 hi+lo planes, the parity mode
+# that holds the flat 1e-3 bar with margin; a call that produces gradients runs bf16 hi+lo planes, the parity mode that trains
+_AUTO_INFER, _AUTO_TRAIN = "fp16x3", "bf16x3"
+# per-handle state of the model object: one set per native handle (precision "auto" keeps up to two)
+_SLOT_KEYS = ("_handle", "_bound_sig", "_grad_sig", "_ptr_key", "_fast_index", "_fast_sig", "_pred_graphs")
 
 
 # --------------------------------------------------------------------------- preprocessing mirror
@@ -213,21 +219,22 @@ class DINOSeg(nn.Module):
 
     Constructor keywords follow the reference (pl_torch_modules.py:144-147); two extra
     keyword-only arguments select what the reference hard-codes or cannot express:
-    ``arch`` ('vit_small' | 'vit_base' | a ViTConfig giving embed_dim/num_heads) and ``precision`` ('bf16x3' parity mode, default |
-    'bf16' benchmark mode).
+    ``arch`` ('vit_small' | 'vit_base' | a ViTConfig giving embed_dim/num_heads) and ``precision``: 'auto' (default: 'fp16x3'
+    for inference calls, 'bf16x3' when a gradient is requested), 'fp16x3' / 'bf16x3' (parity modes: hi + lo operand planes),
+    'fp16' / 'bf16' (benchmark modes: one plane).
     """
 
     def __init__(self, data_path=None, write_path=None, class_names=None, head="linear", n_blocks=1,
                  batch_size=1, lr=1e-6, optimizer=torch.optim.AdamW, freeze_backbone=True, max_epochs=200,
                  patience=10, grayscale=False, n_classes=7, pretrain_on_sim=False, comet_logger=None,
-                 augmented=True, random_init=False, backbone="vit", *, arch="vit_small", precision="bf16x3"):
+                 augmented=True, random_init=False, backbone="vit", *, arch="vit_small", precision="auto"):
         super().__init__()
         if backbone != "vit":
             raise NotImplementedError("only backbone='vit' is on the MI355X hot path (SURVEY.md §2 row 7)")
         if head not in ("linear", "mlp"):
             raise ValueError(f"unknown head {head!r}")
-        if precision not in _PRECISIONS:
-            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        if precision != "auto" and precision not in _PRECISIONS:
+            raise ValueError(f"precision must be 'auto' or one of {sorted(_PRECISIONS)}")
         base = arch if isinstance(arch, ViTConfig) else {"vit_small": VIT_S8, "vit_base": VIT_B8}[arch]
         self.cfg = ViTConfig(embed_dim=base.embed_dim, num_heads=base.num_heads, n_blocks=int(n_blocks),
                              n_classes=int(n_classes), head=head)
@@ -334,6 +341,8 @@ class DINOSeg(nn.Module):
         state.pop("_ptr_key", None)
         state.pop("_adam_state", None)
         state.pop("_grad_bucket_cache", None)
+        state.pop("_slots", None)
+        state.pop("_active_precision", None)
         return state
 
     def __setstate__(self, state):
@@ -343,15 +352,45 @@ class DINOSeg(nn.Module):
         self._grad_sig = None
         self.dino._set_owner(self)
 
-    def _sync_weights(self) -> None:
+    def _use(self, train: bool) -> None:
+        """precision 'auto': make the native handle of the wanted kind the active one (created on first use by _sync_weights).
+        Each handle keeps its own bound-pointer signatures, packed weights, workspaces and captured predict() graphs, so an
+        evaluation between two training steps costs no re-creation; both read the SAME parameter tensors and re-pack on their
+        own next use after an update."""
+        if self.precision != "auto":
+            return
+        want = _AUTO_TRAIN if train else _AUTO_INFER
+        cur = self.__dict__.get("_active_precision")
+        if cur == want:
+            return
+        slots = self.__dict__.setdefault("_slots", {})
+        if cur is not None:
+            slots[cur] = {k: self.__dict__.pop(k, None) for k in _SLOT_KEYS}
+        st = slots.pop(want, None) or {}
+        for k in _SLOT_KEYS:
+            v = st.get(k)
+            if v is None and k not in ("_handle", "_bound_sig", "_grad_sig"):
+                self.__dict__.pop(k, None)
+            else:
+                self.__dict__[k] = v
+        self._active_precision = want
+
+    def effective_precision(self, train: bool = False) -> str:
+        """The operand precision a call of the given kind runs in ('auto' resolved)."""
+        if self.precision != "auto":
+            return self.precision
+        return _AUTO_TRAIN if train else _AUTO_INFER
+
+    def _sync_weights(self, train: bool = False) -> None:
         """Create the native handle if needed and (re)bind + repack when any parameter moved or changed."""
         lib = capi.lib()
         self._require_gpu()
+        self._use(train)
         if self._handle is None:
             cfg = capi.Config(self.cfg.embed_dim, self.cfg.num_heads, self.cfg.n_blocks, self.cfg.patch,
                               self.cfg.mlp_ratio, self.cfg.n_classes,
                               capi.HEAD_MLP if self.head == "mlp" else capi.HEAD_LINEAR, self.cfg.pos_grid,
-                              self.cfg.ln_eps, _PRECISIONS[self.precision])
+                              self.cfg.ln_eps, _PRECISIONS[self.effective_precision(train)])
             h = C.c_void_p()
             capi.check(lib.dinoseg_create(C.byref(cfg), C.byref(h)))
             self._handle = h
@@ -377,14 +416,18 @@ class DINOSeg(nn.Module):
         self._fast_sig = self._fast_signature()
 
     def set_precision(self, precision: str) -> None:
-        if precision not in _PRECISIONS:
-            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        if precision != "auto" and precision not in _PRECISIONS:
+            raise ValueError(f"precision must be 'auto' or one of {sorted(_PRECISIONS)}")
         if precision != self.precision:
-            self.precision = precision
             self._release()
+            self.precision = precision
 
     def _release(self) -> None:
         self.__dict__.pop("_pred_graphs", None)          # captured graphs hold the handle's workspace and packed-weight addresses
+        for st in self.__dict__.pop("_slots", {}).values():      # precision 'auto': the handle that is not the active one
+            if st.get("_handle") is not None:
+                capi.lib().dinoseg_destroy(st["_handle"])
+        self.__dict__.pop("_active_precision", None)
         if self._handle is not None:
             capi.lib().dinoseg_destroy(self._handle)
             self._handle = None
@@ -639,6 +682,7 @@ class DINOSeg(nn.Module):
 
     def stream_wait_grad_stage(self, stage: int, stream) -> None:
         """Make `stream` (a torch.cuda.Stream on the model's device) wait for backward stage `stage` of the last step."""
+        self._use(True)
         capi.check(capi.lib().dinoseg_stream_wait_grad_stage(self._handle, int(stage), stream.cuda_stream))
 
     def _sync_grads(self, slot: str = "grad") -> dict:
@@ -683,6 +727,7 @@ class DINOSeg(nn.Module):
         """Raise IndexError if a training step since the last check saw a label outside [0, n_classes) other than the
         ignore_index -100 (F.nll_loss raises at the call; here the row is skipped on device and reported on request, so the
         step stays asynchronous).  Synchronises the stream; ``fit()`` calls it once per epoch."""
+        self._use(True)
         if self._handle is None:
             return
         bad = C.c_int32(0)
@@ -707,7 +752,7 @@ class DINOSeg(nn.Module):
         optimiser -- can follow.  x: fp32 [B,3,r,r] (normalised) or uint8 [B,r,r,3]; y: int [B, (r/8)^2] (-100 = ignored)."""
         x, y = batch
         self._require_gpu()
-        self._sync_weights()
+        self._sync_weights(train=True)
         self._sync_grads("grad")
         x, kind, B, r = self._prep_batch(x)
         dev = self.device
@@ -723,7 +768,7 @@ class DINOSeg(nn.Module):
         return {"loss": loss, "pred": logp.argmax(dim=-1).detach(), "gt": y, "probs": logp}
 
     def _autograd_forward(self, x: torch.Tensor, kind: int, B: int, r: int) -> torch.Tensor:
-        self._sync_weights()
+        self._sync_weights(train=True)
         n = (r // 8) ** 2
         logp = torch.empty((B * n, self.cfg.n_classes), dtype=torch.float32, device=self.device)
         capi.check(capi.lib().dinoseg_train_forward(self._handle, x.data_ptr(), kind, B, r, logp.data_ptr(), self._stream()))
@@ -734,6 +779,7 @@ class DINOSeg(nn.Module):
         if epoch != getattr(self, "_fwd_epoch", 0):
             raise RuntimeError("DINOSeg.backward: the activations of this forward were overwritten by a later forward / "
                                "training step (one saved forward per model; call backward before the next forward)")
+        self._use(True)          # (precision 'auto': an inference call may have run since the forward)
         bk = self._sync_grads("autograd")
         dlogp = dlogp.to(device=self.device, dtype=torch.float32).contiguous()
         capi.check(capi.lib().dinoseg_backward(self._handle, dlogp.data_ptr(), self._stream()))
@@ -805,8 +851,11 @@ class DINOSeg(nn.Module):
         self._no_dataset("test_dataloader")
 
     def _fit_phase(self, train_dataloader, val_dataloader, ck_path, max_epochs, step):
-        """One ``Trainer.fit`` of the reference: ``max_epochs`` epochs, validation after each, best ``val_acc`` checkpointed."""
+        """One ``Trainer.fit`` of the reference: ``max_epochs`` epochs, validation after each, best ``val_acc`` checkpointed.
+        Every phase starts from a FRESH optimizer (moments and per-parameter step counts dropped): the reference builds a new
+        ``Trainer`` per phase and per ``fit()`` call, so ``configure_optimizers()`` runs again (pl_torch_modules.py:391-421)."""
         from .ckpt import save_checkpoint
+        self.__dict__.pop("_adam_state", None)
         best, history = -1.0, []
         for epoch in range(max_epochs):
             cms, losses = [], []

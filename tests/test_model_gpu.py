@@ -594,7 +594,7 @@ def _outlier_state(sd, cfg, chan=40.0, head=5.0):
 
 
 @pytest.mark.parametrize("chan,head", [(40.0, 5.0), (100.0, 8.0)])
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "auto"])
 def test_outlier_channels_and_sharp_heads(cuda, precision, chan, head):
     """Against the CPU oracle (fp32, same op order as the reference) on weights with outlier channels and a sharp head, at two
     severities (x40 channels / x5 head; x100 / x8): the parity mode holds the north-star bar (1e-3, argmax identical outside
@@ -625,7 +625,12 @@ def test_outlier_channels_and_sharp_heads(cuda, precision, chan, head):
     gap = float((ref.double() - ref64).abs().max())
     print(f"outliers x{chan:g} / x{head:g} {precision}: max|dlogp| {err:.3e}, flips {int(flips.sum())} / {flips.numel()}, "
           f"fp32-vs-fp64 oracle {gap:.2e}")
-    if precision == "bf16x3":
+    if precision == "auto":
+        # the class default: inference runs fp16 hi+lo planes and holds the FLAT north-star bar on these weights (measured 1.1e-4 / 1.4e-4)
+        assert m._active_precision == "fp16x3"
+        assert err <= 1e-3
+        assert not bool((flips & (margin > 2e-3)).any())
+    elif precision == "bf16x3":
         # 16-bit-split operands are not enough for inputs this ill-conditioned: the error sits AT the bar and moves with the summation
         # order of the route taken (x40 / x5: 9.9e-4 through the LayerNorm-fused GEMMs, 1.22e-3 through LayerNorm + the 128x128
         # kernel the round-4 small-batch dispatch picks for 394 rows; x100 / x8: 1.36e-3).  oracle/precision_ablation.py's forward
@@ -703,3 +708,86 @@ def test_predict_replays_a_captured_graph(cuda, golden_dir):
     want = m.predict(other)
     m.predict_graph = True
     assert np.array_equal(m.predict(other), want)
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16x3"])
+def test_predict_graph_survives_another_layout_in_the_same_workspace(cuda, golden_dir, precision):
+    """a batch forward re-lays the workspace out (its fp32 residual rows land where the single-frame layout keeps the
+    zeroed K / V pad rows); the captured single-frame forward holds no memset, so the layout change must invalidate it
+    (dinoseg_state_generation) -- batch forward -> predict -> the SAME batch forward (no growth) -> predict equals the eager map."""
+    g = load(golden_dir, "g5_predict_L3")
+    m, _, _ = build(3, precision)
+    frame = g["frame_r480"]
+    m.predict_graph = False
+    eager = m.predict(frame)
+    m.predict_graph = True
+    big = torch.from_numpy(synthetic_frames(8, 480, seed=11)).cuda()
+    m.forward_frames(big)
+    assert np.array_equal(m.predict(frame), eager)          # captures the single-frame forward inside the large workspace
+    for _ in range(2):
+        m.forward_frames(big)                               # same size: no re-allocation, another layout over the pad rows
+        out = m.predict(frame)
+        assert np.array_equal(out, eager), f"{(out != eager).mean():.3f} of the map differs after a batch forward"
+
+
+def test_predict_graph_sees_an_in_place_pos_embed_update(cuda, golden_dir):
+    """the resampled position embedding is cached per resolution; an in-place update of dino.pos_embed (an optimizer step,
+    load_state_dict into the same storage) re-packs the linears AND must refresh that cache, or a graph replay reads the old rows."""
+    g = load(golden_dir, "g5_predict_L3")
+    m, sd, _ = build(3, "bf16x3")
+    frame = g["frame_r480"]
+    a = m.predict(frame)
+    with torch.no_grad():
+        m.dino.pos_embed.add_(torch.linspace(-3, 3, m.dino.pos_embed.numel(), device="cuda").reshape(m.dino.pos_embed.shape))
+    b = m.predict(frame)
+    m.predict_graph = False
+    want = m.predict(frame)
+    assert not np.array_equal(want, a), "the perturbation must change the map for the test to mean anything"
+    assert np.array_equal(b, want)
+    m.predict_graph = True
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert np.array_equal(m.predict(frame), a)
+
+
+def test_default_precision_is_auto(cuda, golden_dir, tmp_path):
+    """``DINOSeg(...)`` / ``load_from_checkpoint(path)`` run inference on fp16 hi+lo planes (the parity mode
+    with margin) and gradients on bf16 hi+lo planes (the parity mode that trains); both handles live side by side."""
+    from dino_amd.ckpt import save_checkpoint
+    g = load(golden_dir, "g3_vits8_L3_r480")
+    cfg = ViTConfig(n_blocks=3)
+    sd = procedural_state_dict(cfg)
+    src = DINOSeg(head=cfg.head, n_blocks=3, n_classes=cfg.n_classes)
+    assert src.precision == "auto" and src.effective_precision() == "fp16x3" and src.effective_precision(train=True) == "bf16x3"
+    src.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    path = str(tmp_path / "m.ckpt")
+    save_checkpoint(src, path)
+    m = DINOSeg.load_from_checkpoint(path).to("cuda:0")
+    assert m.precision == "auto"
+    frames = torch.from_numpy(synthetic_frames(1, 480, seed=int(g["frame_seed"]))).cuda()
+    logp, amax = m.forward_frames(frames)
+    err = float(np.abs(logp.cpu().numpy() - g["logp"]).max())
+    assert m._active_precision == "fp16x3" and err <= 2e-4 and np.array_equal(amax.cpu().numpy(), g["argmax"]), err
+    ref = DINOSeg(head=cfg.head, n_blocks=3, n_classes=cfg.n_classes, precision="fp16x3")
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert torch.equal(ref.to("cuda:0").forward_frames(frames)[0], logp)
+    # a training step switches to the bf16 hi+lo handle, equals an explicit bf16x3 model bit for bit, and leaves the inference handle alive
+    y = torch.from_numpy(np.random.default_rng(1).integers(0, cfg.n_classes, (1, 3600))).cuda()
+    m.unfreeze_bb()
+    out = m.fused_training_step((frames, y))
+    assert m._active_precision == "bf16x3" and "fp16x3" in m._slots
+    tr = DINOSeg(head=cfg.head, n_blocks=3, n_classes=cfg.n_classes, precision="bf16x3", freeze_backbone=False)
+    tr.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr = tr.to("cuda:0")
+    tr.unfreeze_bb()
+    out2 = tr.fused_training_step((frames, y))
+    assert torch.equal(out["loss"], out2["loss"])
+    for (n, p), (_, q) in zip(m.named_parameters(), tr.named_parameters()):
+        assert torch.equal(p.grad, q.grad), n
+    # autograd forward, an inference call in between, then backward: the backward runs on the training handle
+    m.zero_grad()
+    loss = m.training_step((m.transforms(image=frames[0].cpu().numpy())["image"].unsqueeze(0), y))["loss"]
+    _ = m.predict(frames[0].cpu().numpy())
+    assert m._active_precision == "fp16x3"
+    loss.backward()
+    assert m._active_precision == "bf16x3" and float(m.clf.layer_3.bias.grad.abs().sum()) > 0
+    assert torch.equal(m.forward_frames(frames)[0], logp)

@@ -246,6 +246,76 @@ def test_attention_kernel_variants(cuda, planes, variant):
         assert float((g - r).abs().max()) <= tol and float((l - rl).abs().max()) <= lse_tol
 
 
+@pytest.mark.parametrize("fp16", [False, True])
+def test_attention_za_is_bit_identical_to_the_compiled_kernel(cuda, fp16):
+    """attention_za.hip (attn_variant bits 10 + 11: the tile loop as a hand-scheduled assembly pipeline, at every grid size) against
+    attn_fwd_z_kernel<1, 4, 8> (bit 9: no key split; bit 12: its 256-query workgroups at every grid size -- the exact recomputation is
+    decided per workgroup, so the two kernels must cut the queries alike): ctx and the log-sum-exp equal BIT FOR BIT on one to 57 tiles,
+    ragged or not (1, 17, 32, 33, 63 valid keys in the last tile), one and several (batch, head) pairs per XCD, idle waves in the last
+    q-tile, and on the exact-recomputation path (a 2^S that overflows, a row whose 2^S all flush, |V| ~ 1000, flushed entries)."""
+    lib = capi.lib()
+    shapes = [(1, 1, 1), (1, 1, 17), (1, 1, 50), (1, 1, 64), (1, 3, 65), (1, 1, 96), (1, 1, 128), (2, 2, 129), (2, 2, 197), (1, 1, 255),
+              (1, 2, 256), (1, 1, 257), (1, 9, 300), (1, 1, 901), (2, 5, 1000), (1, 2, 3601)]
+    spikes = ["over", "under", "bigv", "lowmax", True]
+
+    def run(variant):
+        capi.check(lib.dinoseg_set_option(b"attn_variant", variant))
+        out = []
+        for B, H, ntok in shapes:
+            got, ref, lse, ref_lse = (_attention_case_fp16(B, H, ntok) if fp16 else _attention_case(B, H, ntok, 1, seed=ntok))
+            out.append((got, lse, ref, ref_lse))
+        if not fp16:
+            for sp in spikes:
+                got, ref, lse, ref_lse = _attention_case(1, 1, 300, 1, seed=77, spike=sp)
+                out.append((got, lse, ref, ref_lse))
+        return out
+    try:
+        base = run(ATTN_VARIANT_DEFAULT | 512 | 4096)
+        new = run(ATTN_VARIANT_DEFAULT | 512 | 1024 | 2048)
+    finally:
+        capi.check(lib.dinoseg_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT))
+    names = [f"{s}" for s in shapes] + ([f"spike {s}" for s in spikes] if not fp16 else [])
+    for name, (g0, l0, ref, _), (g1, l1, _, _) in zip(names, base, new):
+        assert torch.isfinite(g1).all(), name
+        assert float((g1 - ref).abs().max()) <= (2e-2 * (1000.0 if "bigv" in name else 1.0)), name
+        assert torch.equal(g0, g1), f"{name}: {(g0 != g1).float().mean():.4f} of ctx differs, max {float((g0 - g1).abs().max()):.3e}"
+        if l0 is not None:
+            assert torch.equal(l0, l1), f"{name}: lse differs"
+
+
+def _attention_case_fp16(B, H, ntok):
+    """fp16 Q / K (pre-scaled), bf16 V: the operand formats of precision 'fp16'; returns (ctx, fp64 reference, None, None)"""
+    npad = (ntok + 63) // 64 * 64
+    g = np.random.default_rng(ntok)
+    Q = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32)) * 1.5 * (0.125 * LOG2E)
+    K = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32)) * 1.5
+    V = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32))
+
+    def padded(x):
+        full = torch.zeros((B, H, npad, 64), dtype=torch.float32)
+        full[:, :, :ntok] = x
+        return full.reshape(-1, 64).cuda()
+    lib = capi.lib()
+    capi.check(lib.dinoseg_set_option(b"op_fmt", 1))
+    try:
+        qp, kp = pack(padded(Q), 1), pack(padded(K), 1)
+        capi.check(lib.dinoseg_set_option(b"op_fmt", 0))
+        vp = pack(padded(V), 1)
+        capi.check(lib.dinoseg_set_option(b"op_fmt", 1))
+        ctx = torch.zeros((1, B * ntok, H * 64), dtype=torch.int16, device="cuda")
+        capi.check(lib.dinoseg_op_attention(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), B * H * npad * 64, ctx.data_ptr(),
+                                            B * ntok * H * 64, None, B, H, ntok, npad, 1, S()))
+        torch.cuda.synchronize()
+    finally:
+        capi.check(lib.dinoseg_set_option(b"op_fmt", 0))
+    h = lambda t: t.view(torch.float16).float()
+    qq = h(qp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu() / LOG2E
+    kk = h(kp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu()
+    vv = unpack(vp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu()
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2), dim=-1) @ vv).transpose(1, 2).reshape(B * ntok, H * 64).float()
+    return h(ctx[0]).cpu(), ref, None, None
+
+
 @pytest.mark.parametrize("D", [128, 384, 768])
 def test_layernorm(cuda, D):
     M, ntok = 2 * 37, 37

@@ -193,9 +193,14 @@ def bench_attn():
     npad = (ntok + 63) // 64 * 64
     base = dict(attn_variant=3)
     variants = [(f"variant {v}", dict(base, attn_variant=v)) for v in ATTN_VARIANTS]
+    op_fmt = int(os.environ.get("OP_FMT", "0"))       # 1: fp16 Q / K (single plane), as precision 'fp16' runs the kernel
+    capi.check(lib.dinoseg_set_option(b"op_fmt", op_fmt))
     for planes in [int(v) for v in os.environ.get("ATTN_PLANES", "1,2").split(",")]:
         q = rand_bf16((planes, B, H, npad, 64))
         k = rand_bf16((planes, B, H, npad, 64))
+        if op_fmt == 1:
+            q = (torch.randn((planes, B, H, npad, 64), device="cuda") * 0.5).to(torch.float16).view(torch.int16)
+            k = (torch.randn((planes, B, H, npad, 64), device="cuda") * 0.5).to(torch.float16).view(torch.int16)
         vt = rand_bf16((planes, B, H, npad, 64))
         vt[..., ntok:, :] = 0
         ctx = torch.zeros((planes, B * ntok, H * 64), dtype=torch.int16, device="cuda")
@@ -216,6 +221,7 @@ def bench_attn():
                   f"{fl / (t[len(t) // 2] * 1e-3) / 1e12:6.1f} TFLOP/s", flush=True)
     for kk, vv in base.items():
         lib.dinoseg_set_option(kk.encode(), vv)
+    lib.dinoseg_set_option(b"op_fmt", 0)
 
 
 if __name__ == "__main__":
