@@ -246,8 +246,9 @@ def test_attention_kernel_variants(cuda, planes, variant):
         assert float((g - r).abs().max()) <= tol and float((l - rl).abs().max()) <= lse_tol
 
 
+@pytest.mark.parametrize("mq", [1, 2])
 @pytest.mark.parametrize("fp16", [False, True])
-def test_attention_za_is_bit_identical_to_the_compiled_kernel(cuda, fp16):
+def test_attention_za_is_bit_identical_to_the_compiled_kernel(cuda, fp16, mq):
     """attention_za.hip (attn_variant bits 10 + 11: the tile loop as a hand-scheduled assembly pipeline, at every grid size) against
     attn_fwd_z_kernel<1, 4, 8> (bit 9: no key split; bit 12: its 256-query workgroups at every grid size -- the exact recomputation is
     decided per workgroup, so the two kernels must cut the queries alike): ctx and the log-sum-exp equal BIT FOR BIT on one to 57 tiles,
@@ -271,7 +272,7 @@ def test_attention_za_is_bit_identical_to_the_compiled_kernel(cuda, fp16):
         return out
     try:
         base = run(ATTN_VARIANT_DEFAULT | 512 | 4096)
-        new = run(ATTN_VARIANT_DEFAULT | 512 | 1024 | 2048)
+        new = run(ATTN_VARIANT_DEFAULT | 512 | 1024 | 2048 | (65536 if mq == 2 else 0))       # (bit 16: 64 queries per wave)
     finally:
         capi.check(lib.dinoseg_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT))
     names = [f"{s}" for s in shapes] + ([f"spike {s}" for s in spikes] if not fp16 else [])

@@ -3,22 +3,24 @@
 
     python tools/gen_attn_asm.py            # rewrite the .inc
     python tools/gen_attn_asm.py --check    # exit 1 if the committed .inc is not what this script generates
+    python tools/gen_attn_asm.py --dump [--mq 2]   # one body as plain text
 
-What is generated: ONE inline-asm body per operand format -- the whole K/V tile loop of a wave of attn_fwd_za_kernel (32 queries, head
-dimension 64, 64-key tiles in a four-slot LDS ring) as a software pipeline over 32-key blocks.  Stage b of a wave runs, interleaved
-instruction by instruction,
+What is generated: ONE inline-asm body per (queries per wave, operand format) -- the whole K/V tile loop of a wave of
+attn_fwd_za_kernel (MQ blocks of 32 queries, head dimension 64, 64-key tiles in a four-slot LDS ring) as a software pipeline over
+32-key blocks.  Stage b of a wave runs, interleaved instruction by instruction,
 
-    matrix pipe :  S(b+1) = K(b+1) . Q^T   (4 MFMAs, fresh accumulator)   and   O^T += V(b-1)^T . P(b-1)^T   (4 MFMAs)
-    vector port :  P(b) = 2^S(b) in place (16 v_exp_f32), the row sum (16 v_add_f32), the pack to bf16 (8 v_cvt_pk_bf16_f32)
-    LDS         :  the K fragments of block b+1 / b+2 and the V^T fragments of block b-1 / b, each four MFMAs ahead of its use
+    matrix pipe :  S(b+1) = K(b+1) . Q^T   (4 MFMAs per query block, fresh accumulator)   and   O^T += V(b-1)^T . P(b-1)^T   (4 per block)
+    vector port :  P(b) = 2^S(b) in place (16 v_exp_f32 per query block), the row sum (16 v_add_f32), the pack to bf16 (8 v_cvt_pk_bf16_f32)
+    LDS         :  the K fragments of block b+1 / b+2 and the V^T fragments of block b-1 / b, each four fragment uses ahead
 
-so every MFMA is followed by two exponentials, two adds, one pack and one or two fragment reads ("gap"), and no instruction of a gap
+so every MFMA is followed by two exponentials, two adds, one pack and at most two fragment reads ("gap"), and no instruction of a gap
 depends on the MFMA in front of it.  Arithmetic, operand orientation, LDS image and summation order are those of attention_z.hip's
-attn_fwd_z_kernel<1, 4, 8>: the outputs are bit-identical (tests/test_ops_gpu.py).
+attn_fwd_z_kernel<1, 4, 8>: the outputs are bit-identical (tests/test_ops_gpu.py).  With MQ = 2 every K / V^T fragment read from LDS
+feeds TWO MFMAs (one per query block): half the LDS read bytes per score at two waves per SIMD instead of four.
 
 Why a generator: the waits.  LDS reads return in order, so the wait in front of an MFMA is `s_waitcnt lgkmcnt(N)` with N = the number of
 reads issued after the one the MFMA needs; the emitter keeps the queue of outstanding reads and computes every N, and checks at every
-label that all paths arrive with the same queue.  Registers are assigned by hand (the map below) and pinned in the asm statement's
+label that all paths arrive with the same queue.  Registers are assigned by hand (class Regs) and pinned in the asm statement's
 constraints; hipcc only moves the inputs in and the accumulators out.
 """
 import argparse
@@ -28,25 +30,37 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "dino_amd", "csrc", "attention_za_gen.inc")
 
-# ---- register map (VGPRs; the kernel's constraint list in attention_za.hip mirrors it) -------------------------------------------
-O0, O1 = 0, 16                 # O^T accumulators, d-blocks 0 / 1               v[0:15], v[16:31]      in/out
-Q = 32                         # four Q fragments (B operand of S^T = K Q^T)    v[32:47]               in
-SA, SB = 48, 64                # two score blocks (32 keys x 32 queries)        v[48:63], v[64:79]     scratch
-PA, PB = 80, 88                # two packed probability blocks (2 fragments)    v[80:87], v[88:95]     PB in (zeros), both scratch
-KFA, KFB = 96, 100             # K fragment buffers                             v[96:99], v[100:103]   scratch
-VFA, VFB = 104, 108            # V^T fragment buffers                           v[104:107], v[108:111] scratch
-KA = 112                       # LDS addresses of the K fragment reads, s = 0..3  v112..v115           in
-VA = 116                       # LDS addresses of the V^T reads [db][h]         v116..v119             in
-SOFF = 120                     # lane offset of the LDS-DMA source, next tile   v120                   in/out
-PS = 121                       # row-sum partial of the current tile            v121                   scratch
-L = 122                        # running row sum                                v122                   in/out
-THR = 123                      # valid keys of the last tile minus 8 * (lane >> 5)   v123              in
-NINF = 124                     # -inf (the last tile's mask value: a literal and vcc do not fit one VOP2)   v124   scratch
-NV = 125                       # first VGPR the asm does not touch
-
 SLOT = 16384                   # bytes per ring slot: K slab (8 KiB) + V slab (8 KiB)
 NSLOT = 4
 TILE_BYTES = 8192              # one tile of K (or V) rows in HBM: 64 rows x 128 B
+
+
+class Regs:
+    """VGPR map of a wave with MQ blocks of 32 queries (the kernel's constraint list in attention_za.hip mirrors it)."""
+
+    def __init__(self, mq):
+        self.mq = mq
+        n = 0
+
+        def take(k):
+            nonlocal n
+            r = n
+            n += k
+            return r
+        self.O = [[take(16) for _ in range(2)] for _ in range(mq)]     # O^T accumulators [query block][d-block]          in/out
+        self.Q = [[take(4) for _ in range(4)] for _ in range(mq)]      # Q fragments [query block][k-step]                  in
+        self.S = [[take(16) for _ in range(mq)] for _ in range(2)]     # score blocks [parity][query block]                 scratch
+        self.P = [[take(8) for _ in range(mq)] for _ in range(2)]      # packed probabilities [parity][query block]; parity 1 enters as zeros
+        self.KF = [take(4), take(4)]                                   # K fragment buffers                                 scratch
+        self.VF = [take(4), take(4)]                                   # V^T fragment buffers                               scratch
+        self.KA = take(4)                                              # LDS addresses of the K fragment reads, k-step 0..3 in
+        self.VA = take(4)                                              # LDS addresses of the V^T reads [d-block][half]     in
+        self.SOFF = take(1)                                            # lane offset of the LDS-DMA source, next tile       in/out
+        self.PS = [take(1) for _ in range(mq)]                         # row-sum partial of the current tile                scratch
+        self.L = [take(1) for _ in range(mq)]                          # running row sums                                   in/out
+        self.THR = take(1)                                             # valid keys of the last tile minus 8 * (lane >> 5)  in
+        self.NINF = take(1)                                            # -inf (a literal and vcc do not fit one VOP2)       scratch
+        self.NV = n                                                    # first VGPR the asm does not touch
 
 
 def vr(base, n=1):
@@ -54,9 +68,14 @@ def vr(base, n=1):
 
 
 class Emitter:
-    def __init__(self, qk_op):
+    def __init__(self, qk_op, mq=1, ablate=0):
         self.qk_op = qk_op
         self.pv_op = "v_mfma_f32_32x32x16_bf16"
+        self.R = Regs(mq)
+        self.mq = mq
+        self.ablate = ablate           # timing-only builds (wrong results): bit 0 = no V^T fragment reads, bit 1 = no K fragment reads,
+                                       # 4 = V fragments by ONE ds_read_b128 (K's address pattern on the V slab) instead of two transposing
+                                       # reads, 8 = V reads as they are but the P.V MFMAs take a constant A operand (the Q fragments)
         self.lines = []
         self.q = []                    # outstanding LDS reads, oldest first (tags)
         self.label_state = {}
@@ -100,38 +119,48 @@ class Emitter:
     # -- LDS --
     def read_k(self, buf, s, slot, half):
         off = (slot % NSLOT) * SLOT + half * 4096
-        self.raw(f"ds_read_b128 {vr(buf, 4)}, {vr(KA + s)} offset:{off}")
+        if self.ablate & 2:
+            return
+        self.raw(f"ds_read_b128 {vr(buf, 4)}, {vr(self.R.KA + s)} offset:{off}")
         self.q.append(buf)
 
     def read_v(self, buf, db, ks, slot):
         off = (slot % NSLOT) * SLOT + ks * 2048          # (the V slab's 8 KiB are part of the address registers)
-        self.raw(f"ds_read_b64_tr_b16 {vr(buf, 2)}, {vr(VA + 2 * db)} offset:{off}")
-        self.raw(f"ds_read_b64_tr_b16 {vr(buf + 2, 2)}, {vr(VA + 2 * db + 1)} offset:{off}")
+        if self.ablate & 1:
+            return
+        if self.ablate & 4:
+            self.raw(f"ds_read_b128 {vr(buf, 4)}, {vr(self.R.KA + 2 * db)} offset:{off + 8192}")
+            self.q += [buf]
+            return
+        self.raw(f"ds_read_b64_tr_b16 {vr(buf, 2)}, {vr(self.R.VA + 2 * db)} offset:{off}")
+        self.raw(f"ds_read_b64_tr_b16 {vr(buf + 2, 2)}, {vr(self.R.VA + 2 * db + 1)} offset:{off}")
         self.q += [buf, buf]
 
     def need(self, buf):
-        assert buf in self.q, f"fragment buffer v{buf} has no read in flight"
+        if buf not in self.q:
+            return                      # (a second consumer of a fragment already waited for, or an ablated read)
         idx = len(self.q) - 1 - self.q[::-1].index(buf)
         n = len(self.q) - 1 - idx
         self.raw(f"s_waitcnt lgkmcnt({n})")
         self.q = self.q[idx + 1:]
 
     # -- matrix --
-    def mfma_qk(self, acc, kbuf, s, first):
+    def mfma_qk(self, acc, kbuf, qb, s, first):
         self.need(kbuf)
         c = "0" if first else vr(acc, 16)
-        self.raw(f"{self.qk_op} {vr(acc, 16)}, {vr(kbuf, 4)}, {vr(Q + 4 * s, 4)}, {c}")
+        self.raw(f"{self.qk_op} {vr(acc, 16)}, {vr(kbuf, 4)}, {vr(self.R.Q[qb][s], 4)}, {c}")
 
     def mfma_pv(self, o, vbuf, p, ksl):
         self.need(vbuf)
-        self.raw(f"{self.pv_op} {vr(o, 16)}, {vr(vbuf, 4)}, {vr(p + 4 * ksl, 4)}, {vr(o, 16)}")
+        a = vr(self.R.Q[0][ksl], 4) if self.ablate & 8 else vr(vbuf, 4)
+        self.raw(f"{self.pv_op} {vr(o, 16)}, {a}, {vr(p + 4 * ksl, 4)}, {vr(o, 16)}")
 
     # -- vector --
     def mask(self, reg, const):
         """element of the last tile: -inf unless its key exists (key-in-tile `const` + 8 * (lane >> 5) < valid keys)"""
-        self.raw(f"v_cmp_lt_i32_e32 vcc, {const}, {vr(THR)}")
+        self.raw(f"v_cmp_lt_i32_e32 vcc, {const}, {vr(self.R.THR)}")
         self.raw("s_nop 1")                                # VALU write of vcc -> VALU read as a mask: two wait states
-        self.raw(f"v_cndmask_b32_e32 {vr(reg)}, {vr(NINF)}, {vr(reg)}, vcc")
+        self.raw(f"v_cndmask_b32_e32 {vr(reg)}, {vr(self.R.NINF)}, {vr(reg)}, vcc")
 
     def exp(self, reg):
         self.raw(f"v_exp_f32_e32 {vr(reg)}, {vr(reg)}", trans_dst=reg)
@@ -142,15 +171,22 @@ class Emitter:
     def pack(self, dst, a, b):
         self.raw(f"v_cvt_pk_bf16_f32 {vr(dst)}, {vr(a)}, {vr(b)}", reads=(a, b))
 
-    # -- LDS-DMA of one tile into a ring slot (this wave's K piece and V piece) --
+    # -- LDS-DMA of one tile into a ring slot: this wave's K pieces and V pieces (MQ = 1: eight waves, one 8-row piece of each slab;
+    #    MQ = 2: four waves, two pieces of each slab 32 rows apart = 4 KiB in the source and in the image) --
     def dma_tile(self, slot):
         base = (slot % NSLOT) * SLOT
-        self.raw(f"s_add_u32 m0, %[lds], {base}")
-        self.raw("s_nop 0")
-        self.raw(f"global_load_lds_dwordx4 {vr(SOFF)}, %[kb]")
-        self.raw(f"s_add_u32 m0, %[lds], {base + 8192}")
-        self.raw("s_nop 0")
-        self.raw(f"global_load_lds_dwordx4 {vr(SOFF)}, %[vb]")
+        for slab, src in ((0, "kb"), (8192, "vb")):
+            for j in range(self.mq):
+                self.raw(f"s_add_u32 m0, %[lds], {base + slab + 4096 * j}")
+                self.raw("s_nop 0")
+                self.raw(f"global_load_lds_dwordx4 {vr(self.R.SOFF)}, %[{src}{'2' if j else ''}]")
+
+    def advance_soff(self):
+        self.raw(f"v_add_u32_e32 {vr(self.R.SOFF)}, 0x{TILE_BYTES:x}, {vr(self.R.SOFF)}")
+
+    @property
+    def dma_per_tile(self):
+        return 2 * self.mq
 
 
 def key_in_tile(r, odd):
@@ -158,14 +194,16 @@ def key_in_tile(r, odd):
     return (r >> 3) * 16 + (r & 7) + 32 * odd
 
 
-def stage(e, slot, odd, *, qk=True, pv=True, masked=False, barrier=False, prefetch_k=True, prefetch_v=True, next_is_tail=False,
-          add_l=False):
+def stage(e, slot, odd, *, qk=True, pv=True, masked=False, barrier=False, prefetch_k=True, prefetch_v=True, add_l=False):
     """One pipeline stage of the tile in ring slot `slot`; odd = 0: its first 32 keys are exponentiated, 1: its last 32.
 
-    Entry: reads in flight, oldest first: KFA (s = 0), VFA (d-block 0), KFB (s = 1), VFB (d-block 1) of this stage (those that exist).
+    Entry: reads in flight, oldest first: KF[0] (k-step 0), VF[0] (d-block 0), KF[1] (k-step 1), VF[1] (d-block 1) of this stage (those
+    that exist).  Eight fragment uses per stage (k-steps 0..3 of the score product alternating with (d-block, key half) of the P.V
+    product); each is MQ MFMAs (one per query block), and the gap behind every MFMA carries two elements of ITS query block.
     """
-    s_cur, s_nxt = (SB, SA) if odd else (SA, SB)
-    p_cur, p_prv = (PB, PA) if odd else (PA, PB)
+    R, mq = e.R, e.mq
+    s_cur, s_nxt = R.S[odd], R.S[odd ^ 1]
+    p_cur, p_prv = R.P[odd], R.P[odd ^ 1]
     # operands of this stage: K of the NEXT block (same tile, second half / next tile, first half), V of the PREVIOUS block
     k_slot, k_half = (slot + 1, 0) if odd else (slot, 1)
     v_slot, v_ks0 = (slot, 0) if odd else (slot - 1, 2)
@@ -174,73 +212,78 @@ def stage(e, slot, odd, *, qk=True, pv=True, masked=False, barrier=False, prefet
     nv_slot, nv_ks0 = (slot, 2) if odd else (slot, 0)
     e.comment(f"---- stage: slot {slot % NSLOT}, {'odd' if odd else 'even'}{' masked' if masked else ''}"
               f"{'' if qk else ' no-QK'}{'' if pv else ' no-PV'}")
-    kbuf = [KFA, KFB, KFA, KFB]
     for g in range(8):
-        # ---- the MFMA in front of gap g ----
-        if g % 2 == 0:
-            if qk:
-                e.mfma_qk(s_nxt, kbuf[g // 2], g // 2, first=(g == 0))
-        else:
-            if pv:
-                db, ksl = (g // 2) & 1, g // 4
-                e.mfma_pv(O1 if db else O0, VFB if db else VFA, p_prv, ksl)
-        # ---- gap g: elements 2g, 2g + 1 of the current block ----
-        a, b = s_cur + 2 * g, s_cur + 2 * g + 1
-        if masked:
-            e.mask(a, key_in_tile(2 * g, odd))
-            e.mask(b, key_in_tile(2 * g + 1, odd))
-        e.exp(a)
-        e.exp(b)
-        if barrier and g == 4:
-            # tile t + 1 is about to be read: this wave's pieces of it have landed, then everyone's; tile t + 2 goes into the slot
-            # whose tile was last read two barriers ago
-            e.raw("s_waitcnt vmcnt(0)")
-            e.raw("s_barrier")
-            e.raw("s_cmp_lt_u32 %[cnt], 2")
-            e.branch("s_cbranch_scc1", f"NODMA{slot % NSLOT}")
-            e.dma_tile(slot + 2)
-            e.label(f"NODMA{slot % NSLOT}")
-        # fragment reads: gaps 0-3 for the second half of this stage, gaps 4-7 for the first half of the next one
-        if g == 0 and qk:
-            e.read_k(KFA, 2, k_slot, k_half)
-        elif g == 1 and pv:
-            e.read_v(VFA, 0, v_ks0 + 1, v_slot)
-        elif g == 2 and qk:
-            e.read_k(KFB, 3, k_slot, k_half)
-        elif g == 3 and pv:
-            e.read_v(VFB, 1, v_ks0 + 1, v_slot)
-        elif g == 4 and prefetch_k:
-            e.read_k(KFA, 0, nk_slot, nk_half)
-        elif g == 5 and prefetch_v:
-            e.read_v(VFA, 0, nv_ks0, nv_slot)
-        elif g == 6 and prefetch_k:
-            e.read_k(KFB, 1, nk_slot, nk_half)
-        elif g == 7 and prefetch_v:
-            e.read_v(VFB, 1, nv_ks0, nv_slot)
-        if barrier and g == 5:
-            e.raw(f"v_add_u32_e32 {vr(SOFF)}, 0x{TILE_BYTES:x}, {vr(SOFF)}")      # (harmless when the DMA was skipped: no tile follows)
-        if g == 0 and not odd:
-            e.add(PS, a, b)                                 # a fresh partial sum per tile: (0 + a) + b
-        else:
-            e.add(PS, PS, a)
-            e.add(PS, PS, b)
-        e.pack(p_cur + g, a, b)
+        for qb in range(mq):
+            last = qb == mq - 1
+            # ---- the MFMA in front of this gap ----
+            if g % 2 == 0:
+                if qk:
+                    e.mfma_qk(s_nxt[qb], R.KF[(g // 2) & 1], qb, g // 2, first=(g == 0))
+            else:
+                if pv:
+                    db, ksl = (g // 2) & 1, g // 4
+                    e.mfma_pv(R.O[qb][db], R.VF[db], p_prv[qb], ksl)
+            # ---- the gap: elements 2g, 2g + 1 of the current block of query block qb ----
+            a, b = s_cur[qb] + 2 * g, s_cur[qb] + 2 * g + 1
+            if masked:
+                e.mask(a, key_in_tile(2 * g, odd))
+                e.mask(b, key_in_tile(2 * g + 1, odd))
+            e.exp(a)
+            e.exp(b)
+            if barrier and g == 4 and last:
+                # tile t + 1 is about to be read: this wave's pieces of it have landed, then everyone's; tile t + 2 goes into the slot
+                # whose tile was last read two barriers ago
+                e.raw("s_waitcnt vmcnt(0)")
+                e.raw("s_barrier")
+                e.raw("s_cmp_lt_u32 %[cnt], 2")
+                e.branch("s_cbranch_scc1", f"NODMA{slot % NSLOT}")
+                e.dma_tile(slot + 2)
+                e.label(f"NODMA{slot % NSLOT}")
+            # fragment reads behind the LAST use of the buffer: fragment uses 0-3 reload for the second half of this stage, 4-7 for
+            # the first half of the next one
+            if last:
+                if g == 0 and qk:
+                    e.read_k(R.KF[0], 2, k_slot, k_half)
+                elif g == 1 and pv:
+                    e.read_v(R.VF[0], 0, v_ks0 + 1, v_slot)
+                elif g == 2 and qk:
+                    e.read_k(R.KF[1], 3, k_slot, k_half)
+                elif g == 3 and pv:
+                    e.read_v(R.VF[1], 1, v_ks0 + 1, v_slot)
+                elif g == 4 and prefetch_k:
+                    e.read_k(R.KF[0], 0, nk_slot, nk_half)
+                elif g == 5 and prefetch_v:
+                    e.read_v(R.VF[0], 0, nv_ks0, nv_slot)
+                elif g == 6 and prefetch_k:
+                    e.read_k(R.KF[1], 1, nk_slot, nk_half)
+                elif g == 7 and prefetch_v:
+                    e.read_v(R.VF[1], 1, nv_ks0, nv_slot)
+                if barrier and g == 5:
+                    e.advance_soff()                        # (harmless when the DMA was skipped: no tile follows)
+            if g == 0 and not odd:
+                e.add(R.PS[qb], a, b)                       # a fresh partial sum per tile: (0 + a) + b
+            else:
+                e.add(R.PS[qb], R.PS[qb], a)
+                e.add(R.PS[qb], R.PS[qb], b)
+            e.pack(p_cur[qb] + g, a, b)
     if add_l:
-        e.add(L, L, PS)
+        for qb in range(mq):
+            e.add(R.L[qb], R.L[qb], R.PS[qb])
 
 
-def generate(qk_op):
-    e = Emitter(qk_op)
+def generate(qk_op, mq=1, ablate=0):
+    e = Emitter(qk_op, mq, ablate)
+    R = e.R
     e.comment("GENERATED by tools/gen_attn_asm.py -- do not edit")
     e.raw("s_mov_b32 %[m0s], m0")
     # ---- prologue: tiles 0 and 1 on their way, tile 0 landed ----
     e.dma_tile(0)
-    e.raw(f"v_add_u32_e32 {vr(SOFF)}, 0x{TILE_BYTES:x}, {vr(SOFF)}")
+    e.advance_soff()
     e.raw("s_cmp_lt_u32 %[cnt], 1")
     e.branch("s_cbranch_scc1", "ONE")
     e.dma_tile(1)
-    e.raw(f"v_add_u32_e32 {vr(SOFF)}, 0x{TILE_BYTES:x}, {vr(SOFF)}")
-    e.raw("s_waitcnt vmcnt(2)")
+    e.advance_soff()
+    e.raw(f"s_waitcnt vmcnt({e.dma_per_tile})")
     e.branch("s_branch", "LANDED")
     e.label("ONE")
     e.raw("s_waitcnt vmcnt(0)")
@@ -248,19 +291,18 @@ def generate(qk_op):
     e.raw("s_waitcnt lgkmcnt(0)")          # (the zero fill of slot 3's last V rows, written by the kernel in front of this statement)
     e.raw("s_barrier")
     # ---- head: S(0) = K(0) Q^T, nothing to overlap it with ----
-    e.read_k(KFA, 0, 0, 0)
-    e.read_k(KFB, 1, 0, 0)
-    e.mfma_qk(SA, KFA, 0, first=True)
-    e.read_k(KFA, 2, 0, 0)
-    e.mfma_qk(SA, KFB, 1, first=False)
-    e.read_k(KFB, 3, 0, 0)
-    e.mfma_qk(SA, KFA, 2, first=False)
-    e.mfma_qk(SA, KFB, 3, first=False)
+    e.read_k(R.KF[0], 0, 0, 0)
+    e.read_k(R.KF[1], 1, 0, 0)
+    for s in range(4):
+        for qb in range(mq):
+            e.mfma_qk(R.S[0][qb], R.KF[s & 1], qb, s, first=(s == 0))
+        if s < 2:
+            e.read_k(R.KF[s & 1], s + 2, 0, 0)
     # fragments of the first stage (tile 0, even): K of block 1, V of "block -1" = slot 3's zeroed rows against P = 0
-    e.read_k(KFA, 0, 0, 1)
-    e.read_v(VFA, 0, 2, -1)
-    e.read_k(KFB, 1, 0, 1)
-    e.read_v(VFB, 1, 2, -1)
+    e.read_k(R.KF[0], 0, 0, 1)
+    e.read_v(R.VF[0], 0, 2, -1)
+    e.read_k(R.KF[1], 1, 0, 1)
+    e.read_v(R.VF[1], 1, 2, -1)
     e.raw("s_nop 7")                       # S(0) is read by the first stage's v_exp: one MFMA issue + this cover the 8-pass result latency
     entry = tuple(e.q)
     e.raw("s_cmp_eq_u32 %[cnt], 0")
@@ -280,17 +322,17 @@ def generate(qk_op):
     for s in range(NSLOT):
         e.set_queue(entry)
         e.label(f"FINAL{s}")
-        e.raw(f"v_mov_b32_e32 {vr(NINF)}, 0xff800000")
+        e.raw(f"v_mov_b32_e32 {vr(R.NINF)}, 0xff800000")
         stage(e, s, 0, masked=True, prefetch_k=False)
         e.raw("s_nop 7")                   # (no score MFMA leads the next stage: cover the latency of the last S block)
         stage(e, s, 1, masked=True, qk=False, prefetch_k=False, add_l=True)
         e.comment("---- tail")
-        e.mfma_pv(O0, VFA, PB, 0)
-        e.read_v(VFA, 0, 3, s)
-        e.mfma_pv(O1, VFB, PB, 0)
-        e.read_v(VFB, 1, 3, s)
-        e.mfma_pv(O0, VFA, PB, 1)
-        e.mfma_pv(O1, VFB, PB, 1)
+        for ksl in range(2):
+            for db in range(2):
+                for qb in range(e.mq):
+                    e.mfma_pv(R.O[qb][db], R.VF[db], R.P[1][qb], ksl)
+                if ksl == 0:
+                    e.read_v(R.VF[db], db, 3, s)
         assert not e.q
         if s != NSLOT - 1:
             e.branch("s_branch", "END")
@@ -302,12 +344,20 @@ def generate(qk_op):
     return e
 
 
+BODIES = (("AZA_BODY_BF16", "v_mfma_f32_32x32x16_bf16", 1, 0), ("AZA_BODY_FP16", "v_mfma_f32_32x32x16_f16", 1, 0),
+          ("AZA2_BODY_BF16", "v_mfma_f32_32x32x16_bf16", 2, 0), ("AZA2_BODY_FP16", "v_mfma_f32_32x32x16_f16", 2, 0),
+          ("AZA_BODY_ABL1", "v_mfma_f32_32x32x16_bf16", 1, 1), ("AZA_BODY_ABL2", "v_mfma_f32_32x32x16_bf16", 1, 2),
+          ("AZA_BODY_ABL3", "v_mfma_f32_32x32x16_bf16", 1, 4), ("AZA_BODY_ABL4", "v_mfma_f32_32x32x16_bf16", 1, 8))
+
+
 def render():
     out = ["// GENERATED by tools/gen_attn_asm.py -- do not edit (python tools/gen_attn_asm.py rewrites it; --check compares).",
-           "// The tile loop of attn_fwd_za_kernel (attention_za.hip) as one inline-asm body per operand format; register map, pipeline",
-           "// and the lgkmcnt bookkeeping are described in the generator.", ""]
-    for name, op in (("AZA_BODY_BF16", "v_mfma_f32_32x32x16_bf16"), ("AZA_BODY_FP16", "v_mfma_f32_32x32x16_f16")):
-        e = generate(op)
+           "// The tile loop of attn_fwd_za_kernel (attention_za.hip) as one inline-asm body per (queries per wave, operand format); register",
+           "// map, pipeline and the lgkmcnt bookkeeping are described in the generator.  AZA_BODY_ABL*: timing-only ablations (-DAZA_ABLATIONS).", ""]
+    for name, op, mq, abl in BODIES:
+        e = generate(op, mq, abl)
+        if abl:
+            out.append("#ifdef AZA_ABLATIONS")
         out.append(f"// {e.n_inst} instructions")
         out.append(f"#define {name} \\")
         body = [ln for ln in e.lines]
@@ -315,19 +365,80 @@ def render():
             esc = ln.replace("\\", "\\\\").replace('"', '\\"')
             out.append(f'    "{esc}\\n\\t"{"" if i == len(body) - 1 else " "}\\')
         out[-1] = out[-1].rstrip("\\").rstrip()
+        if abl:
+            out.append("#endif")
         out.append("")
-    out.append(f"#define AZA_FIRST_FREE_VGPR {NV}")
+    for mq in (1, 2):
+        out.append(f"#define AZA{'' if mq == 1 else '2'}_FIRST_FREE_VGPR {Regs(mq).NV}")
     out.append("")
+    for mq in (1, 2):
+        out += operands(mq)
     return "\n".join(out)
+
+
+def operands(mq):
+    """The asm statement's operand lists for the kernel's variable names (attention_za.hip): o[qb][db], pz[qb] (zeros), soff, l_run[qb],
+    cnt, m0s | qf[qb][s], ka_abs[s], va_abs[i], thr, kb (kb2), vb (vb2), lds_piece | clobbers = every scratch register of the map."""
+    R = Regs(mq)
+    pin = lambda base, n=1: "{" + vr(base, n) + "}"
+    outs = [f'"+{pin(R.O[qb][db], 16)}"(o[qb][db])'.replace("qb", str(qb)).replace("db", str(db)) for qb in range(mq) for db in range(2)]
+    outs += [f'"+{pin(R.P[1][qb] + 4 * h, 4)}"(pz[{2 * qb + h}])' for qb in range(mq) for h in range(2)]
+    outs += [f'"+{pin(R.SOFF)}"(soff)'] + [f'"+{pin(R.L[qb])}"(l_run[{qb}])' for qb in range(mq)]
+    outs += ['[cnt] "+s"(cnt)', '[m0s] "=&s"(m0s)']
+    ins = [f'"{pin(R.Q[qb][s], 4)}"(qf[{qb}][{s}])' for qb in range(mq) for s in range(4)]
+    ins += [f'"{pin(R.KA + s)}"(ka_abs[{s}])' for s in range(4)] + [f'"{pin(R.VA + i)}"(va_abs[{i}])' for i in range(4)]
+    ins += [f'"{pin(R.THR)}"(thr)', '[kb] "s"(kb)', '[vb] "s"(vb)']
+    if mq == 2:
+        ins += ['[kb2] "s"(kb2)', '[vb2] "s"(vb2)']
+    ins += ['[lds] "s"(lds_piece)']
+    scratch = []
+    for par in range(2):
+        for qb in range(mq):
+            scratch += list(range(R.S[par][qb], R.S[par][qb] + 16))
+    for qb in range(mq):
+        scratch += list(range(R.P[0][qb], R.P[0][qb] + 8))
+    for b in R.KF + R.VF:
+        scratch += list(range(b, b + 4))
+    scratch += R.PS + [R.NINF]
+    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"v{r}"' for r in sorted(scratch)]
+
+    def wrap(items, indent="      "):
+        lines, cur = [], indent
+        for it in items:
+            if len(cur) + len(it) + 2 > 150:
+                lines.append(cur.rstrip() + " \\")
+                cur = indent
+            cur += it + ", "
+        lines.append(cur.rstrip().rstrip(","))
+        return lines
+    name = f"AZA{'' if mq == 1 else '2'}_OPERANDS"
+    out = [f"#define {name} \\"]
+    o = wrap(outs)
+    o[0] = "    : " + o[0].lstrip()
+    i = wrap(ins)
+    i[0] = "    : " + i[0].lstrip()
+    c = wrap(clob)
+    c[0] = "    : " + c[0].lstrip()
+    for grp in (o, i):
+        out += grp[:-1] + [grp[-1] + " \\"]
+    out += c
+    out.append("")
+    return out
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
-    ap.add_argument("--dump", action="store_true", help="print the bf16 body as plain text")
+    ap.add_argument("--dump", action="store_true", help="print one bf16 body as plain text")
+    ap.add_argument("--mq", type=int, default=1)
+    ap.add_argument("--regs", action="store_true", help="print the register map")
     args = ap.parse_args()
+    if args.regs:
+        for k, v in vars(Regs(args.mq)).items():
+            print(k, v)
+        sys.exit(0)
     if args.dump:
-        print("\n".join(generate("v_mfma_f32_32x32x16_bf16").lines))
+        print("\n".join(generate("v_mfma_f32_32x32x16_bf16", args.mq).lines))
         sys.exit(0)
     text = render()
     if args.check:

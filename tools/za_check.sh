@@ -8,6 +8,6 @@ rc=$?
 tail -5 $OUT/tests.log
 [ $rc -ne 0 ] && exit $rc
 for fmt in 0 1; do
-  OP_FMT=$fmt ATTN_PLANES=1 ATTN_VARIANTS=11,1035 timeout -k 10 300 python tools/bench_ops.py attn > $OUT/bench_fmt$fmt.log 2>&1 || exit 1
+  OP_FMT=$fmt ATTN_PLANES=1 ATTN_VARIANTS=${ZA_VARIANTS:-11,1035,66571} timeout -k 10 300 python tools/bench_ops.py attn > $OUT/bench_fmt$fmt.log 2>&1 || exit 1
   cat $OUT/bench_fmt$fmt.log
 done
