@@ -23,6 +23,9 @@ The JSON line also carries
   parity       : "mask argmax match vs ref": the golden fixture's frame through the timed precision (argmax_match,
                  max_abs_dlogp against the reference's log-probabilities); parity_mode = the same config in bf16x3
                  (the mode that meets argmax-identical / 1e-3) with its own frames/s and match; bf16_mode = the same in bf16.
+  configs      : BASELINE.json configs [2] (@960 batch 8), [4] (ViT-B/8, batch 16 per GPU) and [3] (3-block fine-tune step, batch 8 per GPU)
+                 as compact records (value, ms_per_step, dominant-kernel roofline, parity / gradient_parity), each measured by a child
+                 `python bench.py --config ...` after the headline (N=1 only; --no-configs skips them).
   cpu_baseline : the oracle (oracle/dinoseg_oracle.py = CPU fp32 restatement of the reference path, kind "port")
                  timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only); --mode finetune:
                  the oracle's forward + loss + autograd backward of one frame.
@@ -314,6 +317,8 @@ def parse_args(argv=None):
                          "960 = [2] @960 batch 8; vitb = [4] ViT-B/8 @480 batch 16/GPU; finetune = [3] 3-block step, batch 8/GPU")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 and bf16 sub-records of the headline line")
     ap.add_argument("--no-two-stream", action="store_true", help="skip the one-stream sub-record")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` sub-records of the headline line (BASELINE.json configs [2], [3], [4], each in a child process)")
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2],
                     help="0 = the library default (2: a batch of >= 8 frames runs as two half-batches on two streams); 1 / 2 force it")
     ap.add_argument("--collective", default="allreduce", choices=["allreduce", "rs_ag"],
@@ -334,6 +339,36 @@ def parse_args(argv=None):
     if a.mode == "finetune" and a.precision in ("fp16", "fp16x3"):
         ap.error("the fp16 precisions are inference-only (fp16 gradients would need loss scaling): use bf16 or bf16x3")
     return a
+
+
+def other_configs(a):
+    """BASELINE.json configs [2] (@960 batch 8), [4] (ViT-B/8 batch 16 per GPU) and [3] (the 3-block fine-tune step, batch 8 per GPU) as
+    compact sub-records of the headline line: each is this script run as a CHILD process with --config (one at a time, the parent idle
+    meanwhile; started, never exec'ed), its own JSON line reduced to value / ms_per_step / the dominant kernel's roofline / parity."""
+    import subprocess
+    recs = {}
+    for name in ("960", "vitb", "finetune"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(max(5, a.steps // 2)), "--warmup", "3",
+               "--no-cpu-baseline", "--no-parity-mode", "--no-two-stream", "--no-configs"]
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError(f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}")
+            d = json.loads(lines[-1])
+            rec = {k: d.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype")}
+            rec["workload"] = d["config"].get("workload")
+            rl = d.get("roofline") or {}
+            rec["roofline"] = {k: rl.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
+            for k in ("model_mfma_frac", "parity", "gradient_parity", "outputs_valid", "final_loss"):
+                if k in d:
+                    rec[k] = d[k]
+        except Exception as e:          # a sub-record must never take the headline line with it
+            rec = {"error": repr(e)[-400:]}
+        rec["wall_s"] = round(time.time() - t0, 1)
+        recs[name] = rec
+    return recs
 
 
 def free_port():
@@ -557,9 +592,17 @@ def main():
         heads_ = 6 if a.arch == "vit_small" else 12
         wgs4 = (a.batch * heads_ + 7) // 8 * 8 * (((a.res // 8) ** 2 + 1 + 127) // 128)
         nw = 8 if wgs4 >= 4 * torch.cuda.get_device_properties(dev).multi_processor_count else 4
-        attn_symbol = (f"dseg::attn_fwd_z_kernel<1, 4, {nw}, {1 if a.precision == 'fp16' else 0}> (attention_z.hip: fused QK^T-softmax-PV, "
-                       f"head_dim 64, zero-reference softmax{'; fp16 Q.K^T, bf16 P.V' if a.precision == 'fp16' else ''})"
-                       if a.precision in ("bf16", "fp16") else
+        # (kernels.h Options::attn_variant: from four rounds of workgroups on, bit 10 = the assembly tile loop, bit 16 = 64 queries per wave)
+        av = next((int(kv.split("=")[1]) for kv in a.option if kv.startswith("attn_variant=")), 11 | 1024 | 65536)
+        fmt_note = "; fp16 Q.K^T, bf16 P.V" if a.precision == "fp16" else ""
+        if nw == 8 and (av & 1024) and not (av & 64):
+            z_symbol = (f"dseg::attn_fwd_za_kernel<{1 if a.precision == 'fp16' else 0}, {2 if av & 65536 else 1}, 0> (attention_za.hip: fused "
+                        f"QK^T-softmax-PV, head_dim 64, zero-reference softmax, tile loop = generated assembly pipeline, "
+                        f"{64 if av & 65536 else 32} queries per wave{fmt_note})")
+        else:
+            z_symbol = (f"dseg::attn_fwd_z_kernel<1, 4, {nw}, {1 if a.precision == 'fp16' else 0}> (attention_z.hip: fused QK^T-softmax-PV, "
+                        f"head_dim 64, zero-reference softmax{fmt_note})")
+        attn_symbol = (z_symbol if a.precision in ("bf16", "fp16") else
                        f"dseg::attn_fwd_kernel<2, 4, false, 3, {1 if a.precision == 'fp16x3' else 0}> (attention.hip: fused QK^T-softmax-PV, "
                        f"head_dim 64, hi+lo planes)")
         out = {
@@ -640,6 +683,10 @@ def main():
             out["bf16_mode"] = sub_mode("bf16")[0]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, a.res)
+        if world == 1 and not a.no_configs and a.config in (None, "headline") and a.arch == "vit_small" and a.res == 480 and a.batch == 32:
+            del model
+            torch.cuda.empty_cache()
+            out["configs"] = other_configs(a)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

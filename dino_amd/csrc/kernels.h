@@ -128,10 +128,15 @@ struct Options {
                              // handle's forward follows its own precision instead
     int train_streams = 2;   // 2: backward runs the weight-gradient GEMMs of the blocks on the handle's side stream (train_api.hip)
     int splitk_tiles = 512;  // weight-gradient GEMMs: partial 128x128 tiles per launch (<= 768, the workspace holds that many)
-    int attn_variant = 11;   // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
+    int attn_variant = 11 | 1024 | 65536;
+                             // bit 0: overflow check on the row sums instead of a per-tile row maximum; bit 1: idle waves skip the
                              // tile work; bit 2: unused (round 1-3's software-pipelined kernel, removed); bit 3 (bf16 mode):
                              // the zero-reference kernel, four waves per SIMD (attention_z.hip); bit 9: never split the keys of a
-                             // q-tile over wave groups (attn_fwd_zs_kernel, the small-grid form: A/B and tests)
+                             // q-tile over wave groups (attn_fwd_zs_kernel, the small-grid form: A/B and tests);
+                             // bit 10 (round 5, default): grids of four rounds and more run the tile loop as a hand-scheduled assembly
+                             // pipeline (attention_za.hip: bit-identical outputs), bit 16: with 64 queries per wave at two waves per
+                             // SIMD; bit 11: that kernel at every grid size, bit 12: attention_z.hip's 256-query workgroups at every
+                             // grid size (tests); bit 6: never the 256-query workgroups (nor attention_za.hip)
 };
 Options& options();
 

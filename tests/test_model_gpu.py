@@ -780,9 +780,10 @@ def test_default_precision_is_auto(cuda, golden_dir, tmp_path):
     tr = tr.to("cuda:0")
     tr.unfreeze_bb()
     out2 = tr.fused_training_step((frames, y))
-    assert torch.equal(out["loss"], out2["loss"])
+    # (same kernels, same operands; the loss and a few gradient sums are fp32 atomics: equal up to the order of arrival)
+    assert abs(float(out["loss"]) - float(out2["loss"])) <= 2e-6 * abs(float(out2["loss"]))
     for (n, p), (_, q) in zip(m.named_parameters(), tr.named_parameters()):
-        assert torch.equal(p.grad, q.grad), n
+        assert float((p.grad - q.grad).abs().max()) <= 1e-5 * float(q.grad.abs().max()) + 1e-12, n
     # autograd forward, an inference call in between, then backward: the backward runs on the training handle
     m.zero_grad()
     loss = m.training_step((m.transforms(image=frames[0].cpu().numpy())["image"].unsqueeze(0), y))["loss"]

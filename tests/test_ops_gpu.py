@@ -136,7 +136,7 @@ def test_qkv_gemm_layout(cuda, planes, H, ntok):
     assert torch.all(gq[:, :, ntok:] == 0) and torch.all(gk[:, :, ntok:] == 0) and torch.all(gv[:, :, ntok:] == 0)
 
 
-ATTN_VARIANT_DEFAULT = 11
+ATTN_VARIANT_DEFAULT = 11 | 1024 | 65536        # kernels.h: Options::attn_variant
 
 
 def _attention_case(B, H, ntok, planes, seed, spike=False, want_lse=True):
@@ -271,8 +271,8 @@ def test_attention_za_is_bit_identical_to_the_compiled_kernel(cuda, fp16, mq):
                 out.append((got, lse, ref, ref_lse))
         return out
     try:
-        base = run(ATTN_VARIANT_DEFAULT | 512 | 4096)
-        new = run(ATTN_VARIANT_DEFAULT | 512 | 1024 | 2048 | (65536 if mq == 2 else 0))       # (bit 16: 64 queries per wave)
+        base = run(11 | 512 | 4096)
+        new = run(11 | 512 | 1024 | 2048 | (65536 if mq == 2 else 0))       # (bit 16: 64 queries per wave)
     finally:
         capi.check(lib.dinoseg_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT))
     names = [f"{s}" for s in shapes] + ([f"spike {s}" for s in spikes] if not fp16 else [])

@@ -117,6 +117,6 @@ for variant in (3, 7, 11):
           capi.check(lib.dinoseg_op_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), B * H * npad * 64, ctx.data_ptr(),
                                               B * ntok * H * 64, lse.data_ptr(), B, H, ntok, npad, planes, S()))
       screen(f"attention variant {variant} B={B} H={H} N={ntok} planes={planes}", run, lambda: [ctx, lse])
-capi.check(lib.dinoseg_set_option(b"attn_variant", 11))
+capi.check(lib.dinoseg_set_option(b"attn_variant", 11 | 1024 | 65536))
 print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad})")
 sys.exit(1 if bad else 0)
