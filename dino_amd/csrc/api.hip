@@ -549,6 +549,10 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     if (tap_block == 0 && tap_out) DSEG_CHECK_HIP(hipMemcpyAsync(tap_out, X, xbytes, hipMemcpyDeviceToDevice, s));
 
     const float qscale = 0.125f * 1.44269504088896340736f;   // head_dim^-0.5 (vision_transformer.py:73) * log2(e)
+    // fp16 hi + lo planes: from two rounds of 256-query workgroups on, the attention is the zero-reference assembly kernel, whose
+    // probabilities and V are bf16 hi + lo planes -- the qkv epilogue writes V that way (decided for the batch of the WHOLE call; never
+    // on the visualisation paths, whose small kernels read V in the mode's own format)
+    const int v_bf16 = (P == 2 && FM == FMT_FP16 && !attn_out && !(mreq && mreq->cls_mask) && attention_x3_za(dB, H, L.ntok)) ? 1 : 0;
 
     // ---- transformer blocks (vision_transformer.py:122-140) ----
     bool qkv_ready = false;      // Q / K / V of block i were written by block i-1's fused launch (mlp_fused2.hip, QKV tail)
@@ -586,6 +590,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.A = A; g.a_plane = L.a_plane; g.lda = D;
             g.W = pk.w; g.w_plane = pk.plane;
             g.M = L.M; g.N = 3 * D; g.K = D; g.planes = P; g.fmt = FM; g.epi = EPI_QKV; g.dispatch_rows = disp_M;
+            g.v_bf16 = v_bf16;
             g.bias = W(h, b + "attn.qkv.bias");
             g.q = Q; g.k = Kb; g.v = V; g.qkv_plane = L.qkv_plane;
             g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
@@ -631,6 +636,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             a.B = B; a.heads = H; a.ntok = L.ntok; a.npad = L.npad; a.planes = P; a.fmt = FM;
             a.shared_gpu = h->in_split ? 1 : 0;
             a.dispatch_B = dB;
+            a.v_bf16 = v_bf16;
             DSEG_PROF(DINOSEG_PROF_ATTN, DSEG_TRY(launch_attention(a, s)));
         }
         const bool fuse_mlp = h->packed_mlp.count(b) && mlp_fuse_wanted(h, disp_M);
@@ -854,6 +860,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
     }
     if (strcmp(key, "fp16_patch_planes") == 0) {
         dseg::options().fp16_patch_planes = value == 1 ? 1 : 2;
+        return 0;
+    }
+    if (strcmp(key, "op_v_bf16") == 0) {      // dinoseg_op_attention with fp16 hi + lo planes: V is given as bf16 hi + lo planes (AttnParams::v_bf16)
+        dseg::options().op_v_bf16 = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "op_fmt") == 0) {      // operand format of the single-plane stand-alone ops (dinoseg_op_*): 0 bf16, 1 fp16
@@ -1114,6 +1124,7 @@ extern "C" int dinoseg_op_attention(const void* q, const void* k, const void* v,
     a.ctx = reinterpret_cast<bf16_t*>(ctx); a.ctx_plane = ctx_plane; a.lse = lse;
     a.B = B; a.heads = heads; a.ntok = ntok; a.npad = npad; a.planes = planes;
     a.fmt = options().op_fmt;
+    a.v_bf16 = options().op_v_bf16;
     return launch_attention(a, reinterpret_cast<hipStream_t>(stream));
 }
 

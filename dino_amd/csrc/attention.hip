@@ -386,13 +386,16 @@ int launch_attention(const AttnParams& p0, hipStream_t s) {
             return -1;
         }
         if (p.planes == 1) return launch_attention_z(p, s);
+        if (p.planes == 2 && p.v_bf16) return launch_attention_z(p, s);      // V on bf16 planes: the zero-reference kernels
         if (p.planes == 2) return launch_attn<2, 4, false, 3, FMT_FP16>(p, s);
         dinoseg_set_error("attention: planes must be 1 or 2");
         return -1;
     }
     if (p.dbg != 0 && p.planes == 1) return launch_attn<1, 4, true, 0>(p, s);      // ablation build (tools/bench_ops.py)
     if (p.planes == 1 && (options().attn_variant & 8)) return launch_attention_z(p, s);      // zero-reference, 4 waves / SIMD
-    if (p.planes == 2 && (options().attn_variant & 16)) return launch_attention_z(p, s);     // (hi + lo planes: experiment)
+    // hi + lo planes: the zero-reference kernels from two rounds of 256-query workgroups on (attention_za.hip), or when asked for (bit 4)
+    if (p.planes == 2 && ((options().attn_variant & 16) || attention_x3_za(p.dispatch_B > 0 ? p.dispatch_B : p.B, p.heads, p.ntok)))
+        return launch_attention_z(p, s);
     if (p.planes == 1) return launch_attn_planes<1>(p, s);
     if (p.planes == 2) return launch_attn_planes<2>(p, s);
     dinoseg_set_error("attention: planes must be 1 or 2");

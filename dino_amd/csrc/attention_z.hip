@@ -33,7 +33,8 @@ constexpr int KV_TILE = attn::KV_TILE_BYTES;
 // stay bf16 (2^S against the fixed reference 0 lives on bf16's exponent range).
 template <int PLANES, int WPS, int NW, int FMT = FMT_BF16>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_z_kernel(AttnParams p) {
-    static_assert(FMT == FMT_BF16 || PLANES == 1, "the fp16 operand format is single-plane");
+    // (PLANES == 2 with FMT_FP16: Q / K fp16 hi + lo planes, V and the probabilities bf16 hi + lo, ctx fp16 hi + lo -- the arithmetic of
+    //  attention_za.hip's hi + lo body; this instantiation is its bit-identity reference in the tests)
     using namespace az;
     constexpr int QB = NW * QW;
     using attn::sigma23;
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_z_kernel(AttnParams p) 
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (PLANES == 2) {
-                    z = mfma32(kf[PLANES - 1][s], qf[0][s], z);
-                    z = mfma32(kf[0][s], qf[PLANES - 1][s], z);
+                    z = mfma32f<FMT>(kf[PLANES - 1][s], qf[0][s], z);
+                    z = mfma32f<FMT>(kf[0][s], qf[PLANES - 1][s], z);
                 }
                 z = mfma32f<FMT>(kf[0][s], qf[0][s], z);
             }
@@ -283,7 +284,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_z_kernel(AttnParams p) 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint2 hi, lo;
-                    if constexpr (FMT == FMT_FP16) {
+                    if constexpr (FMT == FMT_FP16 && PLANES == 2) {
+                        split2<FMT>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv, hi.x, lo.x);
+                        split2<FMT>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv, hi.y, lo.y);
+                    } else if constexpr (FMT == FMT_FP16) {
                         hi.x = pack2<FMT>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
                         hi.y = pack2<FMT>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
                         lo = hi;
@@ -602,6 +606,17 @@ static int launch_z(const AttnParams& p, hipStream_t s) {
     return 0;
 }
 
+bool attention_x3_za(int batch, int heads, int ntok) {
+    // one 256-query workgroup per CU: worth it from two rounds on (below that the 128-query reference-based kernel fills the chip better);
+    // attn_variant bit 10 = the assembly kernels at all, bit 6 = never the 256-query workgroups, bit 11 = at every grid size (tests)
+    const int av = options().attn_variant;
+    if (!(av & 1024) || (av & 64)) return false;
+    if (av & 2048) return true;
+    const int ncu = device_cu_count();
+    const long wgs = (long)((batch * heads + 7) / 8) * 8 * ((ntok + 255) / 256);
+    return ncu > 0 && wgs >= 2L * ncu;
+}
+
 int launch_attention_z(const AttnParams& p, hipStream_t s) {
     if (p.planes == 1) {
         // 256-query workgroups (8 waves share a K/V tile: 2 LDS-DMA pieces per wave and tile instead of 4, half the L2 -> LDS traffic)
@@ -640,11 +655,12 @@ int launch_attention_z(const AttnParams& p, hipStream_t s) {
         if (wide && !(options().attn_variant & 64)) return launch_z<1, 4, 8>(p, s);
         return launch_z<1, 4, 4>(p, s);
     }
-    if (p.fmt != FMT_BF16) {
-        dinoseg_set_error("attention: the fp16 operand format is single-plane");
-        return -1;
-    }
-    return launch_z<2, 3, 12>(p, s);      // hi + lo planes: 168 registers, three waves per SIMD (the reference-based kernel: 213, two)
+    // hi + lo planes, zero-reference: V and the probabilities are bf16 hi + lo planes in both formats (FMT_FP16: Q, K and ctx fp16 hi + lo).
+    // attn_variant bit 10: the assembly tile loop (attention_za.hip, eight waves, one workgroup per CU); else the compiled kernel
+    // (168 registers, three waves per SIMD; the reference-based kernel of attention.hip: 213, two)
+    if (options().attn_variant & 1024) return launch_attention_za(p, s);
+    if (p.fmt == FMT_FP16) return launch_z<2, 3, 12, FMT_FP16>(p, s);
+    return launch_z<2, 3, 12>(p, s);
 }
 
 }  // namespace dseg

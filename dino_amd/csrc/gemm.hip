@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_nt_kernel(Gem
                 if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
             }
             uint4 hi, lo;
-            if (FMT == FMT_FP16 && !(PLANES == 1 && EPI == EPI_QKV && which == 2)) {      // (which is workgroup-uniform)
+            if (FMT == FMT_FP16 && !(EPI == EPI_QKV && which == 2 && (PLANES == 1 || p.v_bf16))) {      // (which is workgroup-uniform)
                 // (GEMM outputs are unbounded: saturate at the fp16 range instead of producing inf)
                 if (PLANES == 2) {
                     split2<FMT, true>(v[0], v[1], hi.x, lo.x);

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
                                 if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
                             }
                             uint4 o[2];
-                            if (C::FMT == FMT_FP16 && !(PL == 1 && EPI == EPI_QKV && which == 2)) {      // (one plane: V stays bf16)
+                            if (C::FMT == FMT_FP16 && !(EPI == EPI_QKV && which == 2 && (PL == 1 || p.v_bf16))) {      // (one plane, or asked for: V stays bf16)
                                 if (PL == 2) {      // (outputs are unbounded: saturate at the fp16 range)
                                     split2<C::FMT, true>(v[0], v[1], o[0].x, o[1].x);
                                     split2<C::FMT, true>(v[2], v[3], o[0].y, o[1].y);

@@ -43,6 +43,7 @@ struct GemmParams {
     const float* resid;                         // RESID: out = resid + acc + bias (null: in place on out_f32)
     bf16_t* aux_out;                            // GELU: also save the pre-activation planes here (training), ld = ldo
     const bf16_t* aux_in; long aux_plane;       // DGELU / DRELU operand planes [planes][M][ldo]; also plane stride of aux_out
+    int v_bf16;                                 // EPI_QKV with fp16 hi + lo planes: write V as bf16 hi + lo planes (AttnParams::v_bf16)
     int dispatch_rows;                          // launch_gemm's kernel choice is made for this many rows instead of M when > 0: the two
                                                 // half-batches of a split forward take the route of the whole batch (same summation order)
     int ksplit;                                 // >1: split the K loop over grid.y (EPI_ATOMIC, or EPI_PLAIN partial tiles)
@@ -124,6 +125,7 @@ struct Options {
     int fp16_patch_planes = 1;      // precision fp16: 1 = the patch embedding on one fp16 plane like the rest of the mode (2466 -> 2486 frames/s,
                                     // 0.0263 / 8 flips -> 0.0218 / 5 on the G3 fixture), 2 = on bf16 hi+lo planes (round 4's first build).
                                     // Read when the weights are packed: set it before the first forward
+    int op_v_bf16 = 0;       // dinoseg_op_attention: AttnParams::v_bf16 (tests)
     int op_fmt = 0;          // operand format (FMT_BF16 / FMT_FP16) of the single-plane stand-alone ops (dinoseg_op_*: tests, tools); a
                              // handle's forward follows its own precision instead
     int train_streams = 2;   // 2: backward runs the weight-gradient GEMMs of the blocks on the handle's side stream (train_api.hip)
@@ -150,13 +152,19 @@ struct AttnParams {
     int shared_gpu;                    // hint: another stream's kernels run beside this launch (the split forward): prefer wide workgroups
     int dispatch_B;                    // > 0: choices that change the arithmetic (the key split of small grids) are made for this batch: the
                                        // half-batches of a split forward run what the whole call would (as GemmParams::dispatch_rows)
+    int v_bf16;                        // hi + lo planes with fmt == FMT_FP16: V arrives as bf16 hi + lo planes (GemmParams::v_bf16) -- the
+                                       // zero-reference kernels (attention_z.hip / attention_za.hip: probabilities and V bf16, Q / K / ctx
+                                       // fp16); 0: every plane fp16, the reference-based kernel of attention.hip
     int fmt;                           // FMT_FP16, one plane (attention_z.hip): Q, K and ctx are fp16, V and the probabilities stay bf16 (2^S against
                                        // the fixed reference 0 needs bf16's exponent range); hi+lo planes (attention.hip): everything fp16, the
                                        // probabilities bounded by the running reference (<= 2^15)
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
 int launch_attention_z(const AttnParams& p, hipStream_t s);    // zero-reference softmax, <= 128 registers: 4 waves per SIMD (attention_z.hip)
-int launch_attention_za(const AttnParams& p, hipStream_t s);   // the same arithmetic, tile loop as a hand-scheduled assembly pipeline (attention_za.hip)
+int launch_attention_za(const AttnParams& p, hipStream_t s);
+// hi + lo planes: does a forward of `batch` frames (the WHOLE call's batch) run the zero-reference assembly kernel (attention_za.hip, X3)?
+// The caller of the qkv GEMM asks too: in the fp16 hi + lo mode that kernel wants V as bf16 planes (GemmParams::v_bf16).
+bool attention_x3_za(int batch, int heads, int ntok);   // the same arithmetic, tile loop as a hand-scheduled assembly pipeline (attention_za.hip)
 
 // fp32 [rows, cols] -> bf16 planes [planes][rows_pad][cols_pad], zero padded
 int launch_pack_planes(const float* src, int rows, int cols, bf16_t* dst, long plane, int rows_pad, int cols_pad,

@@ -284,6 +284,87 @@ def test_attention_za_is_bit_identical_to_the_compiled_kernel(cuda, fp16, mq):
             assert torch.equal(l0, l1), f"{name}: lse differs"
 
 
+@pytest.mark.parametrize("fp16", [False, True])
+def test_attention_za_hi_lo_planes_bit_identical(cuda, fp16):
+    """attention_za.hip's hi + lo body (three MFMAs per product, probabilities split in registers, 32 KiB ring slots) against the compiled
+    zero-reference hi + lo kernel attn_fwd_z_kernel<2, 3, 12, FMT> (attn_variant bit 4, bit 10 clear): ctx planes and log-sum-exp bit for
+    bit, bf16 planes and the mixed format of precision 'fp16x3' at large batch (Q / K / ctx fp16 hi + lo, V and P bf16 hi + lo), exact
+    path included (one workgroup on both sides: the two kernels cut the queries differently, 384 / 256 per workgroup)."""
+    lib = capi.lib()
+    shapes = [(1, 1, 1), (1, 1, 50), (1, 3, 65), (1, 1, 128), (2, 2, 197), (1, 2, 256), (1, 9, 300), (2, 5, 1000), (1, 2, 3601)]
+    spikes = ["over", "under", "bigv", "lowmax", True]
+
+    def run(variant):
+        capi.check(lib.dinoseg_set_option(b"attn_variant", variant))
+        out = [_attention_case_x3(B, H, ntok, fp16) for B, H, ntok in shapes]
+        out += [_attention_case_x3(1, 1, 200, fp16, spike=sp) for sp in spikes]
+        return out
+    try:
+        base = run(11 | 16)
+        new = run(11 | 16 | 1024 | 2048)
+    finally:
+        capi.check(lib.dinoseg_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT))
+    names = [f"{s}" for s in shapes] + [f"spike {s}" for s in spikes]
+    for name, (g0, l0, ref, ref_lse), (g1, l1, _, _) in zip(names, base, new):
+        assert torch.isfinite(g1).all(), name
+        tol = 1e-4 * (1000.0 if "bigv" in name else 1.0) * (50.0 if ("under" in name or "lowmax" in name) else 1.0)
+        assert float((g1 - ref).abs().max()) <= tol, f"{name}: {float((g1 - ref).abs().max()):.3e}"
+        assert torch.equal(g0, g1), f"{name}: {(g0 != g1).float().mean():.4f} of ctx differs, max {float((g0 - g1).abs().max()):.3e}"
+        if l0 is not None:
+            assert torch.equal(l0, l1), f"{name}: lse differs"
+            assert float((l1 - ref_lse).abs().max()) <= 5e-3, name
+
+
+def _attention_case_x3(B, H, ntok, fp16, spike=False):
+    """hi + lo planes through dinoseg_op_attention; fp16: Q / K fp16 planes, V bf16 planes (option op_v_bf16), ctx fp16 planes, no LSE;
+    returns (ctx as fp32 = hi + lo, lse or None, fp64 reference on the operands the kernel saw, reference lse)"""
+    npad = (ntok + 63) // 64 * 64
+    g = np.random.default_rng(1000 + ntok)
+    Q = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32)) * 1.5
+    K = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32)) * 1.5
+    V = torch.from_numpy(g.standard_normal((B, H, ntok, 64)).astype(np.float32))
+    if spike:
+        K[:, :, ntok - 3] = Q[:, :, 5] * {"over": 8.0, "bigv": 4.7}.get(spike, 4.0)
+        if spike == "bigv":
+            V = V * 1000.0
+        if spike in ("under", "lowmax"):
+            u = torch.zeros(64)
+            u[3] = 1.0
+            Q[:, :, 7] = (30.0 if spike == "under" else 25.0) * u
+            K = K - (30.0 if spike == "under" else 24.5) * u
+    qs = Q * (0.125 * LOG2E)
+
+    def padded(x):
+        full = torch.zeros((B, H, npad, 64), dtype=torch.float32)
+        full[:, :, :ntok] = x
+        return full.reshape(-1, 64).cuda()
+    lib = capi.lib()
+    h16 = lambda t: t.view(torch.float16).float().sum(dim=0)
+    try:
+        capi.check(lib.dinoseg_set_option(b"op_fmt", 1 if fp16 else 0))
+        qp, kp = pack(padded(qs), 2), pack(padded(K), 2)
+        capi.check(lib.dinoseg_set_option(b"op_fmt", 0))
+        vp = pack(padded(V), 2)
+        capi.check(lib.dinoseg_set_option(b"op_fmt", 1 if fp16 else 0))
+        capi.check(lib.dinoseg_set_option(b"op_v_bf16", 1 if fp16 else 0))
+        ctx = torch.zeros((2, B * ntok, H * 64), dtype=torch.int16, device="cuda")
+        lse = None if fp16 else torch.zeros((B, H, ntok), dtype=torch.float32, device="cuda")
+        capi.check(lib.dinoseg_op_attention(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), B * H * npad * 64, ctx.data_ptr(),
+                                            B * ntok * H * 64, capi.ptr(lse), B, H, ntok, npad, 2, S()))
+        torch.cuda.synchronize()
+    finally:
+        capi.check(lib.dinoseg_set_option(b"op_fmt", 0))
+        capi.check(lib.dinoseg_set_option(b"op_v_bf16", 0))
+    un = h16 if fp16 else unpack
+    qq = un(qp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu() / LOG2E
+    kk = un(kp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu()
+    vv = unpack(vp).reshape(B, H, npad, 64)[:, :, :ntok].double().cpu()
+    sc = qq @ kk.transpose(-1, -2)
+    ref = (torch.softmax(sc, dim=-1) @ vv).transpose(1, 2).reshape(B * ntok, H * 64).float()
+    ref_lse = (torch.logsumexp(sc, dim=-1) * LOG2E).float()
+    return un(ctx).cpu(), None if lse is None else lse.cpu(), ref, ref_lse
+
+
 def _attention_case_fp16(B, H, ntok):
     """fp16 Q / K (pre-scaled), bf16 V: the operand formats of precision 'fp16'; returns (ctx, fp64 reference, None, None)"""
     npad = (ntok + 63) // 64 * 64

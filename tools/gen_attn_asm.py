@@ -373,6 +373,18 @@ def render():
     out.append("")
     for mq in (1, 2):
         out += operands(mq)
+    for name, op in (("AZA3_BODY_BF16", "v_mfma_f32_32x32x16_bf16"), ("AZA3_BODY_FP16", "v_mfma_f32_32x32x16_f16")):
+        e = generate3(op)
+        out.append(f"// {e.n_inst} instructions")
+        out.append(f"#define {name} \\")
+        for i, ln in enumerate(e.lines):
+            esc = ln.replace("\\", "\\\\").replace('"', '\\"')
+            out.append(f'    "{esc}\\n\\t"{"" if i == len(e.lines) - 1 else " "}\\')
+        out[-1] = out[-1].rstrip("\\").rstrip()
+        out.append("")
+    out.append(f"#define AZA3_FIRST_FREE_VGPR {Regs3().NV}")
+    out.append("")
+    out += operands3()
     return "\n".join(out)
 
 
@@ -402,6 +414,10 @@ def operands(mq):
     scratch += R.PS + [R.NINF]
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"v{r}"' for r in sorted(scratch)]
 
+    return _operand_macro(f"AZA{'' if mq == 1 else '2'}_OPERANDS", outs, ins, clob)
+
+
+def _operand_macro(name, outs, ins, clob):
     def wrap(items, indent="      "):
         lines, cur = [], indent
         for it in items:
@@ -411,7 +427,6 @@ def operands(mq):
             cur += it + ", "
         lines.append(cur.rstrip().rstrip(","))
         return lines
-    name = f"AZA{'' if mq == 1 else '2'}_OPERANDS"
     out = [f"#define {name} \\"]
     o = wrap(outs)
     o[0] = "    : " + o[0].lstrip()
@@ -426,6 +441,250 @@ def operands(mq):
     return out
 
 
+# =====================================================================================================================================
+# hi + lo operand planes (the parity modes: three MFMAs per product).  Same pipeline, one 32-query block per wave, eight waves, ONE
+# workgroup per CU (two waves per SIMD): a ring slot is [K hi][V hi][K lo][V lo] = 32 KiB, four slots = 128 KiB.  Per 32-key block and
+# fragment use the three products are, in attention_z.hip's order, lo.hi, hi.lo, hi.hi (K x Q for the scores, V^T x P for O); the
+# probabilities are split in registers: hi = bf16(p), lo = bf16(p - hi) (common.h split_bf16x2: v_cvt_pk, shift / mask, two subtractions,
+# v_cvt_pk).  The score product's operand format is the template's (bf16 or fp16 hi + lo planes); P and V are bf16 hi + lo planes in
+# both (2^S against the fixed reference 0 lives on bf16's exponent range).
+# =====================================================================================================================================
+SLOT3 = 32768
+
+
+class Regs3:
+    def __init__(self):
+        n = 0
+
+        def take(k):
+            nonlocal n
+            r = n
+            n += k
+            return r
+        self.O = [take(16), take(16)]                                  # O^T accumulators [d-block]                         in/out
+        self.QH = [take(4) for _ in range(4)]                          # Q fragments, hi plane [k-step]                     in
+        self.QL = [take(4) for _ in range(4)]                          #              lo plane                              in
+        self.S = [take(16), take(16)]                                  # score blocks [parity]                              scratch
+        self.PH = [take(8), take(8)]                                   # packed probabilities hi [parity]; parity 1 enters as zeros
+        self.PL = [take(8), take(8)]                                   #                      lo
+        self.KFH = [take(4), take(4)]                                  # K fragment buffers hi / lo                         scratch
+        self.KFL = [take(4), take(4)]
+        self.VFH = [take(4), take(4)]                                  # V^T fragment buffers hi / lo                       scratch
+        self.VFL = [take(4), take(4)]
+        self.KA = [take(4), take(4)]                                   # LDS addresses of the K reads [slot pair][k-step]   in
+        self.VA = [take(4), take(4)]                                   # LDS addresses of the V^T reads [slot pair][db][h]  in
+        self.SOFF = take(1)
+        self.PS = take(1)
+        self.L = take(1)
+        self.THR = take(1)
+        self.NINF = take(1)
+        self.T = [take(1), take(1)]                                    # the split's temporaries                            scratch
+        self.NV = n
+
+
+class Emitter3(Emitter):
+    def __init__(self, qk_op):
+        super().__init__(qk_op, 1, 0)
+        self.R = Regs3()
+
+    def read_k3(self, i, s, slot, half):
+        slot %= NSLOT
+        off = (slot & 1) * SLOT3 + half * 4096
+        a = vr(self.R.KA[slot >> 1] + s)
+        self.raw(f"ds_read_b128 {vr(self.R.KFL[i], 4)}, {a} offset:{off + 16384}")
+        self.raw(f"ds_read_b128 {vr(self.R.KFH[i], 4)}, {a} offset:{off}")
+        self.q += [self.R.KFL[i], self.R.KFH[i]]
+
+    def read_v3(self, db, ks, slot):
+        slot %= NSLOT
+        off = (slot & 1) * SLOT3 + ks * 2048
+        a0, a1 = vr(self.R.VA[slot >> 1] + 2 * db), vr(self.R.VA[slot >> 1] + 2 * db + 1)
+        for buf, o in ((self.R.VFL[db], off + 16384), (self.R.VFH[db], off)):
+            self.raw(f"ds_read_b64_tr_b16 {vr(buf, 2)}, {a0} offset:{o}")
+            self.raw(f"ds_read_b64_tr_b16 {vr(buf + 2, 2)}, {a1} offset:{o}")
+            self.q += [buf, buf]
+
+    def mfma(self, op, acc, a, b, first=False):
+        self.need(a)
+        self.raw(f"{op} {vr(acc, 16)}, {vr(a, 4)}, {vr(b, 4)}, {'0' if first else vr(acc, 16)}")
+
+    def dma_tile3(self, slot):
+        base = (slot % NSLOT) * SLOT3
+        for off, src in ((0, "kb"), (8192, "vb"), (16384, "kbl"), (24576, "vbl")):
+            self.raw(f"s_add_u32 m0, %[lds], {base + off}")
+            self.raw("s_nop 0")
+            self.raw(f"global_load_lds_dwordx4 {vr(self.R.SOFF)}, %[{src}]")
+
+
+def stage3(e, slot, odd, *, qk=True, pv=True, masked=False, barrier=False, prefetch_k=True, prefetch_v=True, add_l=False):
+    R = e.R
+    s_cur, s_nxt = R.S[odd], R.S[odd ^ 1]
+    ph_cur, pl_cur, ph_prv, pl_prv = R.PH[odd], R.PL[odd], R.PH[odd ^ 1], R.PL[odd ^ 1]
+    k_slot, k_half = (slot + 1, 0) if odd else (slot, 1)
+    v_slot, v_ks0 = (slot, 0) if odd else (slot - 1, 2)
+    nk_slot, nk_half = (slot + 1, 1) if odd else (slot + 1, 0)
+    nv_slot, nv_ks0 = (slot, 2) if odd else (slot, 0)
+    e.comment(f"---- stage (hi+lo): slot {slot % NSLOT}, {'odd' if odd else 'even'}{' masked' if masked else ''}"
+              f"{'' if qk else ' no-QK'}{'' if pv else ' no-PV'}")
+    for g in range(8):
+        a, b = s_cur + 2 * g, s_cur + 2 * g + 1
+        for m in range(3):
+            # ---- the MFMA in front of this gap: lo.hi, hi.lo, hi.hi ----
+            if g % 2 == 0:
+                if qk:
+                    i, s = (g // 2) & 1, g // 2
+                    kf = R.KFL[i] if m == 0 else R.KFH[i]
+                    qf = R.QL[s] if m == 1 else R.QH[s]
+                    e.mfma(e.qk_op, s_nxt, kf, qf, first=(g == 0 and m == 0))
+            else:
+                if pv:
+                    db, ksl = (g // 2) & 1, g // 4
+                    vf = R.VFL[db] if m == 0 else R.VFH[db]
+                    pf = (pl_prv if m == 1 else ph_prv) + 4 * ksl
+                    e.mfma(e.pv_op, R.O[db], vf, pf)
+            # ---- the gap ----
+            if m == 0:
+                if masked:
+                    e.mask(a, key_in_tile(2 * g, odd))
+                    e.mask(b, key_in_tile(2 * g + 1, odd))
+                e.exp(a)
+                e.exp(b)
+                if barrier and g == 4:
+                    e.raw("s_waitcnt vmcnt(0)")
+                    e.raw("s_barrier")
+                    e.raw("s_cmp_lt_u32 %[cnt], 2")
+                    e.branch("s_cbranch_scc1", f"NODMA{slot % NSLOT}")
+                    e.dma_tile3(slot + 2)
+                    e.label(f"NODMA{slot % NSLOT}")
+                if g == 0 and not odd:
+                    e.add(R.PS, a, b)
+                else:
+                    e.add(R.PS, R.PS, a)
+            elif m == 1:
+                if not (g == 0 and not odd):
+                    e.add(R.PS, R.PS, b)
+                e.pack(ph_cur + g, a, b)
+                e.raw(f"v_lshlrev_b32_e32 {vr(R.T[0])}, 16, {vr(ph_cur + g)}")
+                e.raw(f"v_and_b32_e32 {vr(R.T[1])}, 0xffff0000, {vr(ph_cur + g)}")
+            else:
+                e.raw(f"v_sub_f32_e32 {vr(a)}, {vr(a)}, {vr(R.T[0])}")
+                e.raw(f"v_sub_f32_e32 {vr(b)}, {vr(b)}, {vr(R.T[1])}")
+                e.pack(pl_cur + g, a, b)
+                # fragment reads behind the last use of the buffers
+                if g == 0 and qk:
+                    e.read_k3(0, 2, k_slot, k_half)
+                elif g == 1 and pv:
+                    e.read_v3(0, v_ks0 + 1, v_slot)
+                elif g == 2 and qk:
+                    e.read_k3(1, 3, k_slot, k_half)
+                elif g == 3 and pv:
+                    e.read_v3(1, v_ks0 + 1, v_slot)
+                elif g == 4 and prefetch_k:
+                    e.read_k3(0, 0, nk_slot, nk_half)
+                elif g == 5 and prefetch_v:
+                    e.read_v3(0, nv_ks0, nv_slot)
+                elif g == 6 and prefetch_k:
+                    e.read_k3(1, 1, nk_slot, nk_half)
+                elif g == 7 and prefetch_v:
+                    e.read_v3(1, nv_ks0, nv_slot)
+                if barrier and g == 5:
+                    e.advance_soff()
+    if add_l:
+        e.add(R.L, R.L, R.PS)
+
+
+def generate3(qk_op):
+    e = Emitter3(qk_op)
+    R = e.R
+    e.comment("GENERATED by tools/gen_attn_asm.py -- do not edit (hi + lo planes)")
+    e.raw("s_mov_b32 %[m0s], m0")
+    e.dma_tile3(0)
+    e.advance_soff()
+    e.raw("s_cmp_lt_u32 %[cnt], 1")
+    e.branch("s_cbranch_scc1", "ONE")
+    e.dma_tile3(1)
+    e.advance_soff()
+    e.raw("s_waitcnt vmcnt(4)")
+    e.branch("s_branch", "LANDED")
+    e.label("ONE")
+    e.raw("s_waitcnt vmcnt(0)")
+    e.label("LANDED")
+    e.raw("s_waitcnt lgkmcnt(0)")
+    e.raw("s_barrier")
+    # head: S(0)
+    e.read_k3(0, 0, 0, 0)
+    e.read_k3(1, 1, 0, 0)
+    for s in range(4):
+        i = s & 1
+        e.mfma(e.qk_op, R.S[0], R.KFL[i], R.QH[s], first=(s == 0))
+        e.mfma(e.qk_op, R.S[0], R.KFH[i], R.QL[s])
+        e.mfma(e.qk_op, R.S[0], R.KFH[i], R.QH[s])
+        if s < 2:
+            e.read_k3(i, s + 2, 0, 0)
+    e.read_k3(0, 0, 0, 1)
+    e.read_v3(0, 2, -1)
+    e.read_k3(1, 1, 0, 1)
+    e.read_v3(1, 2, -1)
+    e.raw("s_nop 7")
+    entry = tuple(e.q)
+    e.raw("s_cmp_eq_u32 %[cnt], 0")
+    e.branch("s_cbranch_scc1", "FINAL0")
+    for s in range(NSLOT):
+        e.label(f"PLAIN{s}")
+        stage3(e, s, 0, barrier=True)
+        e.raw("s_sub_u32 %[cnt], %[cnt], 1")
+        stage3(e, s, 1, add_l=True)
+        assert tuple(e.q) == entry
+        e.raw("s_cmp_eq_u32 %[cnt], 0")
+        e.branch("s_cbranch_scc1", f"FINAL{(s + 1) % NSLOT}")
+        if s == NSLOT - 1:
+            e.branch("s_branch", "PLAIN0")
+    for s in range(NSLOT):
+        e.set_queue(entry)
+        e.label(f"FINAL{s}")
+        e.raw(f"v_mov_b32_e32 {vr(R.NINF)}, 0xff800000")
+        stage3(e, s, 0, masked=True, prefetch_k=False)
+        e.raw("s_nop 7")
+        stage3(e, s, 1, masked=True, qk=False, prefetch_k=False, add_l=True)
+        e.comment("---- tail")
+        for ksl in range(2):
+            for db in range(2):
+                e.mfma(e.pv_op, R.O[db], R.VFL[db], R.PH[1] + 4 * ksl)
+                e.mfma(e.pv_op, R.O[db], R.VFH[db], R.PL[1] + 4 * ksl)
+                e.mfma(e.pv_op, R.O[db], R.VFH[db], R.PH[1] + 4 * ksl)
+                if ksl == 0:
+                    e.read_v3(db, 3, s)
+        assert not e.q
+        if s != NSLOT - 1:
+            e.branch("s_branch", "END")
+    e.set_queue(())
+    e.label("END")
+    e.raw("s_mov_b32 m0, %[m0s]")
+    e.raw("s_nop 15")
+    e.raw("s_nop 7")
+    return e
+
+
+def operands3():
+    """operand lists of the hi + lo body for attention_za.hip's names: o3[db], pz3[i] (zeros: PH[1], PL[1]), soff, l_run[0], cnt, m0s |
+    qh[s], ql[s], ka_abs[set*4+s], va_abs[set*4+i], thr, kb, vb, kbl, vbl, lds_piece"""
+    R = Regs3()
+    pin = lambda base, n=1: "{" + vr(base, n) + "}"
+    outs = [f'"+{pin(R.O[db], 16)}"(o[0][{db}])' for db in range(2)]
+    outs += [f'"+{pin(R.PH[1] + 4 * h, 4)}"(pz[{h}])' for h in range(2)] + [f'"+{pin(R.PL[1] + 4 * h, 4)}"(pz[{2 + h}])' for h in range(2)]
+    outs += [f'"+{pin(R.SOFF)}"(soff)', f'"+{pin(R.L)}"(l_run[0])', '[cnt] "+s"(cnt)', '[m0s] "=&s"(m0s)']
+    ins = [f'"{pin(R.QH[s], 4)}"(qf[0][{s}])' for s in range(4)] + [f'"{pin(R.QL[s], 4)}"(qfl[{s}])' for s in range(4)]
+    ins += [f'"{pin(R.KA[t] + s)}"(ka_abs[{4 * t + s}])' for t in range(2) for s in range(4)]
+    ins += [f'"{pin(R.VA[t] + i)}"(va_abs[{4 * t + i}])' for t in range(2) for i in range(4)]
+    ins += [f'"{pin(R.THR)}"(thr)', '[kb] "s"(kb)', '[vb] "s"(vb)', '[kbl] "s"(kbl)', '[vbl] "s"(vbl)', '[lds] "s"(lds_piece)']
+    scratch = list(range(R.S[0], R.S[0] + 32)) + list(range(R.PH[0], R.PH[0] + 8)) + list(range(R.PL[0], R.PL[0] + 8))
+    for b in R.KFH + R.KFL + R.VFH + R.VFL:
+        scratch += list(range(b, b + 4))
+    scratch += [R.PS, R.NINF] + R.T
+    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"v{r}"' for r in sorted(scratch)]
+    return _operand_macro("AZA3_OPERANDS", outs, ins, clob)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -438,7 +697,7 @@ if __name__ == "__main__":
             print(k, v)
         sys.exit(0)
     if args.dump:
-        print("\n".join(generate("v_mfma_f32_32x32x16_bf16", args.mq).lines))
+        print("\n".join((generate3("v_mfma_f32_32x32x16_bf16") if args.mq == 3 else generate("v_mfma_f32_32x32x16_bf16", args.mq)).lines))
         sys.exit(0)
     text = render()
     if args.check:
