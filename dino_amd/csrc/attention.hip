@@ -394,7 +394,10 @@ int launch_attention(const AttnParams& p0, hipStream_t s) {
     if (p.dbg != 0 && p.planes == 1) return launch_attn<1, 4, true, 0>(p, s);      // ablation build (tools/bench_ops.py)
     if (p.planes == 1 && (options().attn_variant & 8)) return launch_attention_z(p, s);      // zero-reference, 4 waves / SIMD
     // hi + lo planes: the zero-reference kernels from two rounds of 256-query workgroups on (attention_za.hip), or when asked for (bit 4)
-    if (p.planes == 2 && ((options().attn_variant & 16) || attention_x3_za(p.dispatch_B > 0 ? p.dispatch_B : p.B, p.heads, p.ntok)))
+    // (inference only -- lse == nullptr: the training forward keeps ONE arithmetic at every batch size: tests/test_train_gpu.py, a batch-8
+    //  step is the mean of eight single-frame steps to 1e-5 of every gradient)
+    if (p.planes == 2 && ((options().attn_variant & 16) ||
+                          (p.lse == nullptr && attention_x3_za(p.dispatch_B > 0 ? p.dispatch_B : p.B, p.heads, p.ntok))))
         return launch_attention_z(p, s);
     if (p.planes == 1) return launch_attn_planes<1>(p, s);
     if (p.planes == 2) return launch_attn_planes<2>(p, s);
