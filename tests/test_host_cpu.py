@@ -216,3 +216,28 @@ def test_resize_restatement_against_an_independent_bilinear():
         # (rounding to a grey level: mean |d| about 0.25; cv2's vertical pass truncates twice -- ((b0 * (S0 >> 4)) >> 16) + ... -- which
         #  shows as a bias of up to about +-0.1 grey levels against exact arithmetic, by the tap values)
         assert abs(d.mean()) < 0.2 and np.abs(d).mean() < 0.3, (sh, sw, dh, dw, d.mean(), np.abs(d).mean())
+
+
+def test_host_side_under_address_sanitizer():
+    """SURVEY.md section 5 (sanitizers): the host side of the C-ABI library built with -fsanitize=address (`make -C dino_amd/csrc asan`:
+    device code objects as usual, every host function instrumented) runs this file's C-ABI tests -- symbol table, handle lifecycle,
+    refused arguments, strict binding, option validation -- in a child process with the ASan runtime preloaded.  Build container only
+    (needs hipcc; the GPU box never runs a sanitizer build)."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "dino_amd", "csrc")
+    if shutil.which("make") is None or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no toolchain")
+    subprocess.run(["make", "-C", csrc, "-j", str(min(8, os.cpu_count() or 1)), "asan"], check=True, capture_output=True)
+    rt = subprocess.run(["make", "-s", "-C", csrc, "asan-runtime"], check=True, capture_output=True, text=True).stdout.strip()
+    lib = os.path.join(root, "dino_amd", "lib", "libdinoseg_hip_asan.so")
+    assert os.path.exists(rt) and os.path.exists(lib)
+    syms = subprocess.run(["nm", "-D", lib], capture_output=True, text=True).stdout
+    assert "__asan_init" in syms, "the library is not instrumented"
+    env = dict(os.environ, LD_PRELOAD=rt, DINOSEG_LIB=lib, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "exports or lifecycle or no_cpu_fallback"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "AddressSanitizer" not in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]
+    assert "3 passed" in r.stdout
