@@ -902,6 +902,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().splitk_tiles = value;
         return 0;
     }
+    if (strcmp(key, "deterministic") == 0) {       // the fine-tune step's reductions in a fixed order (kernels.h Options::deterministic)
+        dseg::options().deterministic = value ? 1 : 0;
+        return 0;
+    }
     if (strcmp(key, "train_streams") == 0) {
         dseg::options().train_streams = value;
         return 0;

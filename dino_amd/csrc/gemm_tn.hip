@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_tn_kernel(TnP
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int gn = n0 + wr * 64 + wc * 32 + acc_row(r, lh);
-            if (gn < p.N && bsum[r] != 0.f) atomicAdd(p.colsum + gn, bsum[r]);
+            if (gn < p.N) {
+                if (p.det) p.det[(long)slice * p.det_ld + gn] = bsum[r];       // deterministic mode: one partial per batch slice
+                else if (bsum[r] != 0.f) atomicAdd(p.colsum + gn, bsum[r]);
+            }
         }
     }
     // ---- partial tile: accumulators through LDS C[128][128] fp32, then 16-byte row segments ----
@@ -212,8 +215,12 @@ __global__ __launch_bounds__(256, (PLANES == 1 ? 2 : 1)) void gemm_tn_kernel(TnP
     }
 }
 
-int launch_gemm_tn(const TnParams& p, hipStream_t s) {
+int launch_gemm_tn(const TnParams& p0, hipStream_t s) {
     using namespace tn;
+    TnParams p = p0;
+    p.det = nullptr;
+    p.det_ld = ((p.N + BN - 1) / BN) * BN;
+    if (p.colsum && det_scratch().ptr && (size_t)p.ksplit * p.det_ld <= det_scratch().floats) p.det = det_scratch().ptr;
     if (p.M < 1 || p.N < 1 || p.Kc % BKc != 0 || p.ksplit < 1 || (p.planes != 1 && p.planes != 2) || p.ldy % 8 != 0 || p.ldx % 8 != 0) {
         dinoseg_set_error("gemm_tn: bad shape M=%d N=%d Kc=%d ksplit=%d planes=%d", p.M, p.N, p.Kc, p.ksplit, p.planes);
         return -1;
@@ -238,6 +245,10 @@ int launch_gemm_tn(const TnParams& p, hipStream_t s) {
         hipLaunchKernelGGL(gemm_tn_kernel<2>, grid, dim3(256), lds, s, p);
     }
     DSEG_CHECK_HIP(hipGetLastError());
+    if (p.det) {        // the slices that own batch rows, in slice order
+        const int nchunks = (p.M + BMr - 1) / BMr, per = (nchunks + p.ksplit - 1) / p.ksplit, used = (nchunks + per - 1) / per;
+        return launch_det_finalize(p.det, used, p.N, p.det_ld, p.colsum, s);
+    }
     return 0;
 }
 

@@ -128,6 +128,9 @@ struct Options {
     int op_v_bf16 = 0;       // dinoseg_op_attention: AttnParams::v_bf16 (tests)
     int op_fmt = 0;          // operand format (FMT_BF16 / FMT_FP16) of the single-plane stand-alone ops (dinoseg_op_*: tests, tools); a
                              // handle's forward follows its own precision instead
+    int deterministic = 0;   // 1: the fine-tune step sums the loss, the bias and the LayerNorm gamma / beta gradients in a FIXED order (per-block
+                             // partials into a scratch area + one ordered pass) instead of fp32 atomics, and keeps the weight-gradient GEMMs
+                             // on the caller's stream: two runs from the same state are bit-identical (tests/test_train_gpu.py)
     int train_streams = 2;   // 2: backward runs the weight-gradient GEMMs of the blocks on the handle's side stream (train_api.hip)
     int splitk_tiles = 512;  // weight-gradient GEMMs: partial 128x128 tiles per launch (<= 768, the workspace holds that many)
     int attn_variant = 11 | 1024 | 65536;
@@ -228,8 +231,14 @@ struct TnParams {
     int M, N, Kc, planes;
     float* part; int ld_part; long split_stride; int ksplit;
     float* colsum;                              // optional [N]: += column sums of dY over the M rows (the layer's bias gradient)
+    float* det; int det_ld;                     // set by launch_gemm_tn in deterministic mode: per-slice partial sums [ksplit][det_ld]
 };
 int launch_gemm_tn(const TnParams& p, hipStream_t s);
+// Deterministic mode (Options::deterministic): the scratch area the partial sums of the current backward go to (set by
+// dinoseg_backward around its launches; nullptr = atomics) and the ordered pass dst[c] += sum_p part[p * ld + c], p ascending.
+struct DetScratch { float* ptr; size_t floats; };
+DetScratch& det_scratch();
+int launch_det_finalize(const float* part, int nparts, int width, int ld, float* dst, hipStream_t s);
 int launch_splitk_reduce(const float* part, int ks, long stride, int rows, int ld_part, float* out, int ldo, int cols, hipStream_t s);
 int launch_batch_sum_rows(const float* X, int B, int ntok, int D, float* out, hipStream_t s);
 int launch_pos_resample_bwd(const float* dpos, int g, int D, int o, float* dpe, float* scratch /* g*o*D floats */, hipStream_t s);

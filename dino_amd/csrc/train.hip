@@ -8,6 +8,12 @@
 #include "gemm_ln_common.h"
 #include "kernels.h"
 
+#define DSEG_TRY_RC(expr)        \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
 namespace dseg {
 
 // ------------------------------------------------------------------------------------------------
@@ -18,7 +24,7 @@ __global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __re
                                                                const bf16_t* __restrict__ src_pl, long src_plane, int lds_,
                                                                int M, int C, bf16_t* __restrict__ T, long t_plane, int m_pad,
                                                                bf16_t* __restrict__ Nout, long n_plane, int ldn,
-                                                               float* __restrict__ colsum, int planes, int drop_cls, int ntok) {
+                                                               float* __restrict__ colsum, int planes, int drop_cls, int ntok, float* __restrict__ det) {
     __shared__ uint16_t th[64][66], tl[64][66];
     __shared__ float cs[4][64];
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -62,7 +68,8 @@ __global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __re
     __syncthreads();
     if (colsum && ty == 0 && c < C) {
         const float s = cs[0][tx] + cs[1][tx] + cs[2][tx] + cs[3][tx];
-        if (s != 0.f) atomicAdd(colsum + c, s);
+        if (det) det[(long)blockIdx.x * C + c] = s;       // deterministic mode: one partial per 64-row block, summed in order afterwards
+        else if (s != 0.f) atomicAdd(colsum + c, s);
     }
     if (T) {
 #pragma unroll 4
@@ -82,9 +89,18 @@ int launch_transpose_planes(const float* src_f32, const bf16_t* src_pl, long src
         dinoseg_set_error("transpose_planes: bad padding (M=%d C=%d m_pad=%d c_pad=%d)", M, C, m_pad, c_pad);
         return -1;
     }
+    float* det = nullptr;
+    if (colsum && det_scratch().ptr) {
+        if ((size_t)(m_pad / 64) * C > det_scratch().floats) {
+            dinoseg_set_error("transpose_planes: deterministic scratch too small");
+            return -1;
+        }
+        det = det_scratch().ptr;
+    }
     hipLaunchKernelGGL(transpose_planes_kernel, dim3(m_pad / 64, c_pad / 64), dim3(256), 0, s, src_f32, src_pl, src_plane,
-                       ld_src, M, C, T, t_plane, m_pad, Nout, n_plane, ldn, colsum, planes, drop_cls, ntok);
+                       ld_src, M, C, T, t_plane, m_pad, Nout, n_plane, ldn, colsum, planes, drop_cls, ntok, det);
     DSEG_CHECK_HIP(hipGetLastError());
+    if (det) return launch_det_finalize(det, m_pad / 64, C, C, colsum, s);
     return 0;
 }
 
@@ -101,7 +117,8 @@ int launch_transpose_planes(const float* src_f32, const bf16_t* src_pl, long src
 constexpr int IGNORE_INDEX = -100;
 
 __global__ __launch_bounds__(256) void nll_reduce_kernel(const float* __restrict__ logp, const int64_t* __restrict__ labels, int M,
-                                                         int C, float* __restrict__ acc, int* __restrict__ flags) {
+                                                         int C, float* __restrict__ acc, int* __restrict__ flags, float* __restrict__ det) {
+    __shared__ float wsum[2][4];
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     float l = 0.f, n = 0.f;
     if (m < M) {
@@ -115,10 +132,40 @@ __global__ __launch_bounds__(256) void nll_reduce_kernel(const float* __restrict
     }
     l = wave_sum(l);
     n = wave_sum(n);
+    if (det) {          // deterministic mode: the block's four wave sums in wave order, one partial pair per block
+        if ((threadIdx.x & 63) == 0) {
+            wsum[0][threadIdx.x >> 6] = l;
+            wsum[1][threadIdx.x >> 6] = n;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) det[blockIdx.x * 2 + threadIdx.x] = ((wsum[threadIdx.x][0] + wsum[threadIdx.x][1]) + wsum[threadIdx.x][2]) + wsum[threadIdx.x][3];
+        return;
+    }
     if ((threadIdx.x & 63) == 0 && n != 0.f) {
         atomicAdd(acc, l);
         atomicAdd(acc + 1, n);
     }
+}
+
+// deterministic mode: dst[c] += sum over the partials p = 0 .. nparts-1 (ascending) of part[p * ld + c]
+__global__ __launch_bounds__(256) void det_finalize_kernel(const float* __restrict__ part, int nparts, int width, int ld,
+                                                           float* __restrict__ dst) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float s = 0.f;
+    for (int q = 0; q < nparts; ++q) s += part[(long)q * ld + c];
+    dst[c] += s;
+}
+
+DetScratch& det_scratch() {
+    static DetScratch d = {nullptr, 0};
+    return d;
+}
+
+int launch_det_finalize(const float* part, int nparts, int width, int ld, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(det_finalize_kernel, dim3((width + 255) / 256), dim3(256), 0, s, part, nparts, width, ld, dst);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __restrict__ logp, const float* __restrict__ dlogp,
@@ -156,7 +203,11 @@ int launch_nll_loss_grad(const float* logp, const int64_t* labels, const float* 
                          float* loss, bf16_t* dz, long dz_plane, int ldz, hipStream_t s) {
     if (labels) {
         DSEG_CHECK_HIP(hipMemsetAsync(acc, 0, 2 * sizeof(float), s));
-        hipLaunchKernelGGL(nll_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, logp, labels, M, C, acc, flags);
+        float* det = det_scratch().ptr;
+        const int nb = (M + 255) / 256;
+        if (det && (size_t)nb * 2 > det_scratch().floats) det = nullptr;
+        hipLaunchKernelGGL(nll_reduce_kernel, dim3(nb), dim3(256), 0, s, logp, labels, M, C, acc, flags, det);
+        if (det) DSEG_TRY_RC(launch_det_finalize(det, nb, 2, 2, acc, s));
     }
     hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3((M + 255) / 256), dim3(256), 0, s, logp, dlogp, labels, acc, M, C, loss, dz, dz_plane,
                        ldz);
@@ -177,7 +228,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dx, int accumulate,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int drop_cls, int ntok, bf16_t* __restrict__ dxp, long dxp_plane,
-                                                            int planes, float* __restrict__ colsum) {
+                                                            int planes, float* __restrict__ colsum, float* __restrict__ det) {
     constexpr int D = 128 * NV;
     __shared__ float red[3][4][D];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -280,6 +331,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int c = threadIdx.x; c < D; c += 256) {
         const float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
         const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        if (det) {      // deterministic mode: per-block partials [block][3][D], summed in block order by det_finalize_kernel
+            float* dp = det + (long)blockIdx.x * 3 * D;
+            dp[c] = a;
+            dp[D + c] = b;
+            dp[2 * D + c] = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
+            continue;
+        }
         if (dgamma) atomicAdd(dgamma + c, a);
         if (dbeta) atomicAdd(dbeta + c, b);
         if (colsum) {
@@ -298,7 +356,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const float* __res
                                                               float* __restrict__ dx, int accumulate,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               int drop_cls, int ntok, bf16_t* __restrict__ dxp, long dxp_plane,
-                                                              int planes, float* __restrict__ colsum) {
+                                                              int planes, float* __restrict__ colsum, float* __restrict__ det) {
     constexpr int D = 64 * NC;
     __shared__ float red[3][4][D];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -402,6 +460,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const float* __res
     for (int c = threadIdx.x; c < D; c += 256) {
         const float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
         const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        if (det) {      // deterministic mode: per-block partials [block][3][D], summed in block order by det_finalize_kernel
+            float* dp = det + (long)blockIdx.x * 3 * D;
+            dp[c] = a;
+            dp[D + c] = b;
+            dp[2 * D + c] = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
+            continue;
+        }
         if (dgamma) atomicAdd(dgamma + c, a);
         if (dbeta) atomicAdd(dbeta + c, b);
         if (colsum) {
@@ -418,30 +483,39 @@ int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, fl
         dinoseg_set_error("layernorm_bwd: D=%d must be a multiple of 128 and <= 1024", D);
         return -1;
     }
+    float* det = det_scratch().ptr;
+    if (det && (size_t)1024 * 3 * D > det_scratch().floats) det = nullptr;
+    auto finalize = [&](int blocks) -> int {
+        if (!det) return 0;
+        if (dgamma) DSEG_TRY_RC(launch_det_finalize(det, blocks, D, 3 * D, dgamma, s));
+        if (dbeta) DSEG_TRY_RC(launch_det_finalize(det + D, blocks, D, 3 * D, dbeta, s));
+        if (colsum) DSEG_TRY_RC(launch_det_finalize(det + 2 * D, blocks, D, 3 * D, colsum, s));
+        return 0;
+    };
     if (D % 64 == 0 && D <= 512 && !(options().route_ab & 2)) {      // sixteen lanes per row (route_ab bit 1: the one-wave-per-row kernel, A/B)
         int grid16 = (M + 15) / 16;
         if (grid16 > 1024) grid16 = 1024;
 #define DSEG_LNB16(NC)                                                                                                       \
     case NC:                                                                                                                 \
         hipLaunchKernelGGL((layernorm_bwd16_kernel<NC>), dim3(grid16), dim3(256), 0, s, dy, x, gamma, eps, M, dx, accumulate, \
-                           dgamma, dbeta, drop_cls, ntok, dxp, dxp_plane, planes, colsum);                                   \
+                           dgamma, dbeta, drop_cls, ntok, dxp, dxp_plane, planes, colsum, det);                              \
         break;
         switch (D / 64) { DSEG_LNB16(2) DSEG_LNB16(4) DSEG_LNB16(6) DSEG_LNB16(8) }
 #undef DSEG_LNB16
         DSEG_CHECK_HIP(hipGetLastError());
-        return 0;
+        return finalize(grid16);
     }
     int grid = (M + 3) / 4;
     if (grid > 1024) grid = 1024;
 #define DSEG_LNB(NV)                                                                                                  \
     case NV:                                                                                                          \
         hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(grid), dim3(256), 0, s, dy, x, gamma, eps, M, dx, accumulate, \
-                           dgamma, dbeta, drop_cls, ntok, dxp, dxp_plane, planes, colsum);                            \
+                           dgamma, dbeta, drop_cls, ntok, dxp, dxp_plane, planes, colsum, det);                       \
         break;
     switch (D / 128) { DSEG_LNB(1) DSEG_LNB(2) DSEG_LNB(3) DSEG_LNB(4) DSEG_LNB(5) DSEG_LNB(6) DSEG_LNB(7) DSEG_LNB(8) }
 #undef DSEG_LNB
     DSEG_CHECK_HIP(hipGetLastError());
-    return 0;
+    return finalize(grid);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 
 namespace {
 
+constexpr size_t DET_FLOATS = (size_t)1024 * 3 * 1024;      // option deterministic: scratch for per-block partial sums (12 MiB)
 constexpr int SPLITK_TILES = 768;      // partial 128x128 fp32 tiles of one weight-gradient GEMM (48 MiB): what the workspace holds
 inline int splitk_budget() {
     const int v = dseg::options().splitk_tiles;
@@ -27,7 +28,7 @@ struct TrainLayout {
     // per block (offsets are for block 0; block l adds l * blk_stride)
     size_t Xin, A1, Q, K, V, LSE, CTX, Xmid, A2, HPRE, HB, blk_stride;
     size_t Xfin, PATCH, FEAT, H1, H2, LOGP, DZ;
-    size_t dX, dA, dXp, G, dCTX, T1, T2, NLSE, NDEL, DPOS, SINK, ACC, SPLITK;
+    size_t dX, dA, dXp, G, dCTX, T1, T2, NLSE, NDEL, DPOS, SINK, ACC, SPLITK, DET;
     size_t zero_begin, zero_end;      // Q/K/V of every block (pad rows must be zero)
     size_t total;
     long a_plane, qkv_plane, f_plane, feat_plane, h1_plane, h2_plane, dz_plane, patch_plane, g_plane, t_plane;
@@ -101,6 +102,7 @@ TrainLayout make_train_layout(const dinoseg_handle* h, int B, int r) {
     L.SINK = take((size_t)4 * 1024 * 4);
     L.ACC = take(256);        // nll_loss accumulators {sum of -logp[y], valid rows} (the sticky bad-label flag lives in the handle)
     L.SPLITK = take((size_t)SPLITK_TILES * 128 * 128 * 4);     // split-K partial tiles of the weight gradients
+    L.DET = take((size_t)DET_FLOATS * 4);       // option deterministic: per-block partial sums (the largest user: LayerNorm backward, 1024 blocks x 3 x D)
     L.total = off;
     return L;
 }
@@ -479,6 +481,12 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
         }
         if (!zp.empty()) DSEG_TRY(launch_multi_zero((int)zp.size(), zp.data(), zn.data(), s));      // one launch instead of ~50 memset nodes
     }
+    // option deterministic: the launchers below write per-block partial sums here and add them in a fixed order (train.hip,
+    // gemm_tn.hip) instead of fp32 atomics; cleared on every way out
+    struct DetGuard {
+        ~DetGuard() { det_scratch() = DetScratch{nullptr, 0}; }
+    } det_guard;
+    if (options().deterministic) det_scratch() = DetScratch{F32(L.DET), DET_FLOATS};
     float* Xfin = F32(L.Xfin);
     bf16_t *FEAT = B16(L.FEAT), *H1 = B16(L.H1), *H2 = B16(L.H2), *DZ = B16(L.DZ);
     float* LOGP = F32(L.LOGP);
@@ -504,7 +512,8 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
     // weight-gradient tiles fill.  side_begin(): the side stream waits for everything queued on s so far; side_end() returns an
     // event the caller's stream waits on (side_wait) before it overwrites an operand the side kernels read, and before every
     // gradient-stage event.  Fork and join are events only: the call stays stream-ordered for the caller and capturable.
-    const bool side = options().train_streams >= 2 && D % 128 == 0 && F % 128 == 0;   // (narrow layers go through T1 / T2: one stream)
+    // (deterministic mode: ONE stream -- every [partial sums, ordered pass] pair shares the scratch area in stream order)
+    const bool side = options().train_streams >= 2 && D % 128 == 0 && F % 128 == 0 && !options().deterministic;   // (narrow layers go through T1 / T2: one stream)
     hipStream_t ws_ = s;
     size_t bw_i = 0;
     auto bw_event = [&](hipEvent_t* out) -> int {
