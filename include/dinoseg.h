@@ -202,10 +202,18 @@ int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
  *   "train_streams" 2 [default] = dinoseg_backward / dinoseg_train_step run the blocks' weight-gradient GEMMs on an internal stream
  *                beside the input-gradient chain (forked from / joined to the caller's stream by events: stream-ordered, capturable),
  *                1 = everything on the caller's stream (use it when several processes share one GPU);
+ *   "deterministic" 0 [default] / 1: the fine-tune step sums the loss, the bias gradients and the LayerNorm gamma / beta gradients from
+ *                per-block partials in a FIXED order instead of fp32 atomics and keeps the weight-gradient GEMMs on the caller's stream:
+ *                two runs from the same state are bit-identical (SURVEY.md section 8e "fixed reduction tree"; with world_size > 1 the
+ *                all-reduce's own order is RCCL's); one training step at a time per process while it is on;
+ *   "op_v_bf16"  0 [default] / 1: dinoseg_op_attention with fp16 hi + lo planes takes V as bf16 hi + lo planes (what the forward hands
+ *                the zero-reference kernels at large batch: attention_za.hip);
  *   "splitk_tiles" 512 [default]: partial 128x128 tiles of one weight-gradient GEMM (<= 768);
  *   "route_ab"   0 [default]: A/B switches of dispatch routes that do not change results (bit 0: 128-row tiles for the residual GEMMs
  *                of a small batch; bit 1: the one-wave-per-row LayerNorm backward; bit 2: the weight-gradient GEMM's 2-D grid);
- *   "attn_variant", "gemm_dbg", "attn_dbg": kernel A/B and timing-ablation switches (tools/bench_ops.py). */
+ *   "attn_variant", "gemm_dbg", "attn_dbg": kernel A/B and timing-ablation switches (tools/bench_ops.py; attn_variant's bits:
+ *                dino_amd/csrc/kernels.h -- default 11 | 1024 | 65536: from four rounds of workgroups on the attention runs its tile loop
+ *                as a generated assembly pipeline, attention_za.hip, bit-identical to the compiled kernel). */
 int dinoseg_set_option(const char* key, int32_t value);
 
 /* Bytes of library-owned device memory a (B, r) forward needs (activations + packed weights). */
