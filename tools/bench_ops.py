@@ -189,7 +189,7 @@ ATTN_VARIANTS = [int(v) for v in os.environ.get("ATTN_VARIANTS", "11").split(","
 def bench_attn():
     """Interleaved A/B rounds in one process (clocks drift by +-10 % between back-to-back measurements)."""
     lib = capi.lib()
-    B, H, ntok = 32, 6, 3601
+    B, H, ntok = int(os.environ.get("ATTN_B", "32")), 6, int(os.environ.get("ATTN_NTOK", "3601"))
     npad = (ntok + 63) // 64 * 64
     base = dict(attn_variant=3)
     variants = [(f"variant {v}", dict(base, attn_variant=v)) for v in ATTN_VARIANTS]
@@ -217,7 +217,7 @@ def bench_attn():
         fl = 4.0 * B * H * ntok * ntok * 64
         for name, _ in variants:
             t = sorted(times[name][1:])
-            print(f"attention planes={planes} {name:18s}: min {t[0] * 1e3:7.1f} us  median {t[len(t) // 2] * 1e3:7.1f} us  "
+            print(f"attention B={B} ntok={ntok} planes={planes} {name:18s}: min {t[0] * 1e3:7.1f} us  median {t[len(t) // 2] * 1e3:7.1f} us  "
                   f"{fl / (t[len(t) // 2] * 1e-3) / 1e12:6.1f} TFLOP/s", flush=True)
     for kk, vv in base.items():
         lib.dinoseg_set_option(kk.encode(), vv)

@@ -1,13 +1,14 @@
 #!/bin/bash
-# bash tools/evidence_r04.sh   (GPU box)  one JSON line per BASELINE.json config + rocprofv3 kernel-stat summaries + PMC passes
-# -> gpurun_out/ev_r04/ and gpurun_out/prof_r04/ ; condensed into profiles/r04_* by tools/collect_evidence.py r04 and
-# tools/summarize_profile.py r04 (in the build container)
+# bash tools/evidence.sh <tag>   (GPU box)  one JSON line per BASELINE.json config + rocprofv3 kernel-stat summaries + PMC passes
+# -> gpurun_out/ev_$TAG/ and gpurun_out/prof_$TAG/ ; condensed into profiles/$TAG_* by tools/collect_evidence.py <tag> and
+# tools/summarize_profile.py <tag> (in the build container)
 set -o pipefail
+TAG=${1:?usage: bash tools/evidence.sh <tag, e.g. r05>}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/ev_r04
+OUT=$ROOT/gpurun_out/ev_$TAG
 mkdir -p $OUT
 cd $ROOT
-python3 bench.py --steps 20 --warmup 5 > $OUT/bench_headline.json 2>$OUT/bench_headline.err || tail -5 $OUT/bench_headline.err
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_headline.json 2>$OUT/bench_headline.err || tail -5 $OUT/bench_headline.err     # (the driver's command: configs sub-records included)
 python3 bench.py --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode > $OUT/bench_headline_bf16.json 2>/dev/null
 python3 bench.py --config parity --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_parity.json 2>/dev/null
 python3 bench.py --config parity --precision bf16x3 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_parity_bf16x3.json 2>/dev/null
@@ -29,6 +30,6 @@ for cfg in "960:--config 960 --steps 3 --warmup 1" "vitb:--config vitb --steps 4
   find $OUT/trace_$name -name "*kernel_trace.csv" -delete
 done
 cd $ROOT
-bash tools/profile_bench.sh r04 | tail -3
-bash tools/pmc_cmd.sh clk_r04 "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --streams 1 > $OUT/clock_kernels.txt 2>&1; grep "dseg::" $OUT/clock_kernels.txt | cut -c1-220
-du -sh $OUT $ROOT/gpurun_out/prof_r04
+bash tools/profile_bench.sh $TAG | tail -3
+bash tools/pmc_cmd.sh clk_$TAG "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --streams 1 > $OUT/clock_kernels.txt 2>&1; grep "dseg::" $OUT/clock_kernels.txt | cut -c1-220
+du -sh $OUT $ROOT/gpurun_out/prof_$TAG
