@@ -72,7 +72,9 @@ def main():
     # the bf16 (one plane) forward attention kernel of the timed loop: attention_z.hip since round 2, attention.hip before
     # (the instantiation with the most launches: the batch's; the single-frame fixture check launches the narrow one a few times)
     launches = {k: len(d.get("FETCH_SIZE", [])) for k, d in pmc.items()}
-    cands = [k for k in hbm if "attn_fwd_z_kernel<1" in k] or [k for k in hbm if "attn_fwd_kernel<1" in k]
+    # (round 5: attention_za.hip's assembly tile loop from four rounds of workgroups on)
+    cands = ([k for k in hbm if "attn_fwd_za_kernel<" in k and "true" not in k] or [k for k in hbm if "attn_fwd_z_kernel<1" in k]
+             or [k for k in hbm if "attn_fwd_kernel<1" in k])
     att = max(cands, key=lambda k: launches.get(k, 0)) if cands else None
     if att and bench_line:
         cfg = bench_line["config"]
@@ -88,6 +90,15 @@ def main():
         for key, val in old_traffic.items():
             if key.startswith("clock_") or key.startswith("measured_"):
                 tj[key] = val
+        # the clock of THIS round's kernel when its pass is there (tools/evidence.sh -> profiles/<tag>_clock_kernels.txt)
+        ck = os.path.join(dst, f"{tag}_clock_kernels.txt")
+        if att and os.path.exists(ck):
+            for line in open(ck):
+                if line.startswith(att + " ") and "clock_GHz=" in line:
+                    tj["clock_ghz_under_load"] = float(line.rsplit("clock_GHz=", 1)[1])
+                    tj["clock_method"] = (f"rocprofv3 --pmc GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel duration of the same pass "
+                                          f"(tools/pmc_cmd.sh clk_{tag} ... bench.py --streams 1, profiles/{tag}_clock_kernels.txt): "
+                                          + line.strip()[:400])
         json.dump(tj, open(os.path.join(dst, "attention_traffic.json"), "w"), indent=1)
 
     with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
