@@ -102,7 +102,9 @@ for (Bq, ntok, planes) in [(32, 3601, 1), (8, 3601, 2), (3, 197, 1), (1, 65, 2),
             bad += err > tol
 
 import test_ops_gpu as T
-for variant in (3, 7, 11):
+# (round 5: 11 | 1024 [| 65536] = the assembly tile loop of attention_za.hip, 32 / 64 queries per wave; | 2048 = at every grid size;
+#  planes = 2 with bits 4 / 10 = its hi + lo body)
+for variant in (3, 11, 11 | 1024 | 2048, 11 | 1024 | 2048 | 65536, 11 | 16 | 1024 | 2048):
   capi.check(lib.dinoseg_set_option(b"attn_variant", variant))
   for (B, H, ntok, planes) in [(32, 6, 3601, 1), (2, 6, 3601, 2), (4, 2, 197, 1), (3, 3, 64, 1), (1, 1, 129, 2), (8, 6, 14401, 1)]:
       npad = (ntok + 63) // 64 * 64
