@@ -284,6 +284,33 @@ def test_attention_za_is_bit_identical_to_the_compiled_kernel(cuda, fp16, mq):
             assert torch.equal(l0, l1), f"{name}: lse differs"
 
 
+@pytest.mark.parametrize("planes", [1, 2])
+def test_attention_za_bit_identical_at_14401_tokens(cuda, planes):
+    """BASELINE configs[2]'s sequence (960 x 960: 14 401 tokens = 226 tiles, 57 q-tiles, the last with one query row): the assembly
+    kernels against the compiled ones, outputs only (the fp64 reference of this size is test_attention_14401_tokens_sampled_rows')."""
+    lib = capi.lib()
+    B, H, ntok = 1, 2, 14401
+    npad = (ntok + 63) // 64 * 64
+    g = torch.Generator(device="cuda").manual_seed(14401 + planes)
+    mk = lambda sc: (torch.randn((planes, B * H * npad, 64), device="cuda", generator=g) * sc).to(torch.bfloat16).view(torch.int16)
+    q, k, v = mk(0.5), mk(0.5), mk(1.0)
+    outs = []
+    try:
+        for variant in ((11 | 512 | 4096, 11 | 512 | 1024 | 2048, 11 | 512 | 1024 | 2048 | 65536) if planes == 1 else (11 | 16, 11 | 16 | 1024 | 2048)):
+            capi.check(lib.dinoseg_set_option(b"attn_variant", variant))
+            ctx = torch.zeros((planes, B * ntok, H * 64), dtype=torch.int16, device="cuda")
+            lse = torch.zeros((B, H, ntok), dtype=torch.float32, device="cuda")
+            capi.check(lib.dinoseg_op_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), B * H * npad * 64, ctx.data_ptr(),
+                                                B * ntok * H * 64, lse.data_ptr(), B, H, ntok, npad, planes, S()))
+            torch.cuda.synchronize()
+            outs.append((ctx, lse))
+    finally:
+        capi.check(lib.dinoseg_set_option(b"attn_variant", ATTN_VARIANT_DEFAULT))
+    assert torch.isfinite(outs[0][1]).all() and bool((outs[0][0] != 0).any())
+    for ctx, lse in outs[1:]:
+        assert torch.equal(ctx, outs[0][0]) and torch.equal(lse, outs[0][1])
+
+
 @pytest.mark.parametrize("fp16", [False, True])
 def test_attention_za_hi_lo_planes_bit_identical(cuda, fp16):
     """attention_za.hip's hi + lo body (three MFMAs per product, probabilities split in registers, 32 KiB ring slots) against the compiled

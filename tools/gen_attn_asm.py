@@ -276,18 +276,9 @@ def generate(qk_op, mq=1, ablate=0):
     R = e.R
     e.comment("GENERATED by tools/gen_attn_asm.py -- do not edit")
     e.raw("s_mov_b32 %[m0s], m0")
-    # ---- prologue: tiles 0 and 1 on their way, tile 0 landed ----
-    e.dma_tile(0)
-    e.advance_soff()
-    e.raw("s_cmp_lt_u32 %[cnt], 1")
-    e.branch("s_cbranch_scc1", "ONE")
-    e.dma_tile(1)
-    e.advance_soff()
-    e.raw(f"s_waitcnt vmcnt({e.dma_per_tile})")
-    e.branch("s_branch", "LANDED")
-    e.label("ONE")
+    # ---- prologue: tiles 0 and 1 were issued by the kernel AHEAD of its Q loads (their latencies overlap; the Q wait covers them: one
+    #      in-order counter), SOFF enters two tiles on ----
     e.raw("s_waitcnt vmcnt(0)")
-    e.label("LANDED")
     e.raw("s_waitcnt lgkmcnt(0)")          # (the zero fill of slot 3's last V rows, written by the kernel in front of this statement)
     e.raw("s_barrier")
     # ---- head: S(0) = K(0) Q^T, nothing to overlap it with ----
@@ -598,17 +589,7 @@ def generate3(qk_op):
     R = e.R
     e.comment("GENERATED by tools/gen_attn_asm.py -- do not edit (hi + lo planes)")
     e.raw("s_mov_b32 %[m0s], m0")
-    e.dma_tile3(0)
-    e.advance_soff()
-    e.raw("s_cmp_lt_u32 %[cnt], 1")
-    e.branch("s_cbranch_scc1", "ONE")
-    e.dma_tile3(1)
-    e.advance_soff()
-    e.raw("s_waitcnt vmcnt(4)")
-    e.branch("s_branch", "LANDED")
-    e.label("ONE")
-    e.raw("s_waitcnt vmcnt(0)")
-    e.label("LANDED")
+    e.raw("s_waitcnt vmcnt(0)")            # (tiles 0 / 1: issued by the kernel ahead of its Q loads, as in the single-plane bodies)
     e.raw("s_waitcnt lgkmcnt(0)")
     e.raw("s_barrier")
     # head: S(0)
