@@ -129,8 +129,8 @@ struct Options {
     int op_fmt = 0;          // operand format (FMT_BF16 / FMT_FP16) of the single-plane stand-alone ops (dinoseg_op_*: tests, tools); a
                              // handle's forward follows its own precision instead
     int deterministic = 0;   // 1: the fine-tune step sums the loss, the bias and the LayerNorm gamma / beta gradients in a FIXED order (per-block
-                             // partials into a scratch area + one ordered pass) instead of fp32 atomics, and keeps the weight-gradient GEMMs
-                             // on the caller's stream: two runs from the same state are bit-identical (tests/test_train_gpu.py)
+                             // partials into a scratch area + one ordered pass; the side stream's gemm_tn launches have their own region)
+                             // instead of fp32 atomics: two runs from the same state are bit-identical (tests/test_train_gpu.py)
     int train_streams = 2;   // 2: backward runs the weight-gradient GEMMs of the blocks on the handle's side stream (train_api.hip)
     int splitk_tiles = 512;  // weight-gradient GEMMs: partial 128x128 tiles per launch (<= 768, the workspace holds that many)
     int attn_variant = 11 | 1024 | 65536;
@@ -232,11 +232,12 @@ struct TnParams {
     float* part; int ld_part; long split_stride; int ksplit;
     float* colsum;                              // optional [N]: += column sums of dY over the M rows (the layer's bias gradient)
     float* det; int det_ld;                     // set by launch_gemm_tn in deterministic mode: per-slice partial sums [ksplit][det_ld]
+    int det_region;                             // deterministic mode: 0 = the caller's stream, 1 = the weight-gradient side stream (its own part of the scratch)
 };
 int launch_gemm_tn(const TnParams& p, hipStream_t s);
 // Deterministic mode (Options::deterministic): the scratch area the partial sums of the current backward go to (set by
 // dinoseg_backward around its launches; nullptr = atomics) and the ordered pass dst[c] += sum_p part[p * ld + c], p ascending.
-struct DetScratch { float* ptr; size_t floats; };
+struct DetScratch { float* ptr; size_t floats; float* tn[2]; size_t tn_floats; };      // tn[r]: gemm_tn's partials, per stream region
 DetScratch& det_scratch();
 int launch_det_finalize(const float* part, int nparts, int width, int ld, float* dst, hipStream_t s);
 int launch_splitk_reduce(const float* part, int ks, long stride, int rows, int ld_part, float* out, int ldo, int cols, hipStream_t s);

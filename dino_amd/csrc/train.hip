@@ -147,23 +147,42 @@ __global__ __launch_bounds__(256) void nll_reduce_kernel(const float* __restrict
     }
 }
 
-// deterministic mode: dst[c] += sum over the partials p = 0 .. nparts-1 (ascending) of part[p * ld + c]
+// deterministic mode: dst[c] += sum over the partials of part[p * ld + c] in a FIXED order: thread (column c, group g of 8) adds the
+// partials g, g + 8, g + 16, ... in ascending order (eight independent chains: the loads pipeline), then the eight group sums are
+// added in group order.  The order depends on nparts only -- never on timing.  (First version: one thread per column walking all
+// partials -- 1024 dependent strided loads: 0.2 ms per call, the fine-tune step 2.1x slower; this one: ~10 us.)
 __global__ __launch_bounds__(256) void det_finalize_kernel(const float* __restrict__ part, int nparts, int width, int ld,
                                                            float* __restrict__ dst) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int q = 0; q < nparts; ++q) s += part[(long)q * ld + c];
-    dst[c] += s;
+    if (c < width) {
+        int q = g;
+        for (; q + 24 < nparts; q += 32) {      // four loads in flight per thread
+            const float a0 = part[(long)q * ld + c], a1 = part[(long)(q + 8) * ld + c];
+            const float a2 = part[(long)(q + 16) * ld + c], a3 = part[(long)(q + 24) * ld + c];
+            s = (((s + a0) + a1) + a2) + a3;
+        }
+        for (; q < nparts; q += 8) s += part[(long)q * ld + c];
+    }
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < width) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][cl];
+        dst[c] += t;
+    }
 }
 
 DetScratch& det_scratch() {
-    static DetScratch d = {nullptr, 0};
+    static DetScratch d = {nullptr, 0, {nullptr, nullptr}, 0};
     return d;
 }
 
 int launch_det_finalize(const float* part, int nparts, int width, int ld, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(det_finalize_kernel, dim3((width + 255) / 256), dim3(256), 0, s, part, nparts, width, ld, dst);
+    hipLaunchKernelGGL(det_finalize_kernel, dim3((width + 31) / 32), dim3(256), 0, s, part, nparts, width, ld, dst);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }

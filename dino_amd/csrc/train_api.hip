@@ -16,7 +16,8 @@
 
 namespace {
 
-constexpr size_t DET_FLOATS = (size_t)1024 * 3 * 1024;      // option deterministic: scratch for per-block partial sums (12 MiB)
+constexpr size_t DET_FLOATS = (size_t)1024 * 3 * 1024;      // option deterministic: scratch for per-block partial sums (12 MiB) ...
+constexpr size_t DET_TN_FLOATS = (size_t)768 * 3072;        // ... and gemm_tn's per-slice bias partials, one region per stream (2 x 9 MiB)
 constexpr int SPLITK_TILES = 768;      // partial 128x128 fp32 tiles of one weight-gradient GEMM (48 MiB): what the workspace holds
 inline int splitk_budget() {
     const int v = dseg::options().splitk_tiles;
@@ -102,7 +103,7 @@ TrainLayout make_train_layout(const dinoseg_handle* h, int B, int r) {
     L.SINK = take((size_t)4 * 1024 * 4);
     L.ACC = take(256);        // nll_loss accumulators {sum of -logp[y], valid rows} (the sticky bad-label flag lives in the handle)
     L.SPLITK = take((size_t)SPLITK_TILES * 128 * 128 * 4);     // split-K partial tiles of the weight gradients
-    L.DET = take((size_t)DET_FLOATS * 4);       // option deterministic: per-block partial sums (the largest user: LayerNorm backward, 1024 blocks x 3 x D)
+    L.DET = take((size_t)(DET_FLOATS + 2 * DET_TN_FLOATS) * 4);       // option deterministic: per-block partial sums (the largest user: LayerNorm backward, 1024 blocks x 3 x D)
     L.total = off;
     return L;
 }
@@ -484,9 +485,11 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
     // option deterministic: the launchers below write per-block partial sums here and add them in a fixed order (train.hip,
     // gemm_tn.hip) instead of fp32 atomics; cleared on every way out
     struct DetGuard {
-        ~DetGuard() { det_scratch() = DetScratch{nullptr, 0}; }
+        ~DetGuard() { det_scratch() = DetScratch{nullptr, 0, {nullptr, nullptr}, 0}; }
     } det_guard;
-    if (options().deterministic) det_scratch() = DetScratch{F32(L.DET), DET_FLOATS};
+    if (options().deterministic)
+        det_scratch() = DetScratch{F32(L.DET), DET_FLOATS, {F32(L.DET) + DET_FLOATS, F32(L.DET) + DET_FLOATS + DET_TN_FLOATS}, DET_TN_FLOATS};
+    const hipStream_t main_stream = s;
     float* Xfin = F32(L.Xfin);
     bf16_t *FEAT = B16(L.FEAT), *H1 = B16(L.H1), *H2 = B16(L.H2), *DZ = B16(L.DZ);
     float* LOGP = F32(L.LOGP);
@@ -512,8 +515,8 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
     // weight-gradient tiles fill.  side_begin(): the side stream waits for everything queued on s so far; side_end() returns an
     // event the caller's stream waits on (side_wait) before it overwrites an operand the side kernels read, and before every
     // gradient-stage event.  Fork and join are events only: the call stays stream-ordered for the caller and capturable.
-    // (deterministic mode: ONE stream -- every [partial sums, ordered pass] pair shares the scratch area in stream order)
-    const bool side = options().train_streams >= 2 && D % 128 == 0 && F % 128 == 0 && !options().deterministic;   // (narrow layers go through T1 / T2: one stream)
+    // (deterministic mode: the side stream's only partial sums are gemm_tn's bias sums: they have their own part of the scratch area)
+    const bool side = options().train_streams >= 2 && D % 128 == 0 && F % 128 == 0;   // (narrow layers go through T1 / T2: one stream)
     hipStream_t ws_ = s;
     size_t bw_i = 0;
     auto bw_event = [&](hipEvent_t* out) -> int {
@@ -609,6 +612,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
             const int per = (nchunks + ks - 1) / ks, used = (nchunks + per - 1) / per;
             g.part = F32(L.SPLITK); g.ld_part = k_pad; g.split_stride = (long)row_tiles * 128 * k_pad; g.ksplit = ks;
             g.colsum = dbias;
+            g.det_region = s != main_stream;
             DSEG_TRY(launch_gemm_tn(g, s));
             if (!dW) return 0;
             return launch_splitk_reduce(g.part, used, g.split_stride, n_rows, k_pad, dW, k_cols, k_cols, s);
@@ -637,6 +641,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
         const int per = (nchunks + ks - 1) / ks, used = (nchunks + per - 1) / per;
         g.part = F32(L.SPLITK); g.ld_part = k_cols; g.split_stride = (long)row_tiles * 128 * k_cols; g.ksplit = ks;
         g.colsum = dbias;
+        g.det_region = s != main_stream;
         DSEG_TRY(launch_gemm_tn(g, s));
         return launch_splitk_reduce(g.part, used, g.split_stride, n_rows, k_cols, dW, k_cols, k_cols, s);
     };

@@ -203,8 +203,8 @@ int dinoseg_profile_read(dinoseg_handle* h, float* ms_sum, int32_t* counts);
  *                beside the input-gradient chain (forked from / joined to the caller's stream by events: stream-ordered, capturable),
  *                1 = everything on the caller's stream (use it when several processes share one GPU);
  *   "deterministic" 0 [default] / 1: the fine-tune step sums the loss, the bias gradients and the LayerNorm gamma / beta gradients from
- *                per-block partials in a FIXED order instead of fp32 atomics and keeps the weight-gradient GEMMs on the caller's stream:
- *                two runs from the same state are bit-identical (SURVEY.md section 8e "fixed reduction tree"; with world_size > 1 the
+ *                per-block partials in a FIXED order instead of fp32 atomics (the side stream's bias sums in their own scratch region):
+ *                two runs from the same state are bit-identical, at 4-5 % of the step (SURVEY.md section 8e "fixed reduction tree"; with world_size > 1 the
  *                all-reduce's own order is RCCL's); one training step at a time per process while it is on;
  *   "op_v_bf16"  0 [default] / 1: dinoseg_op_attention with fp16 hi + lo planes takes V as bf16 hi + lo planes (what the forward hands
  *                the zero-reference kernels at large batch: attention_za.hip);
