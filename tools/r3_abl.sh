@@ -6,6 +6,6 @@ M=$1; V=$2; shift 2
 for r in 1 2; do
   timeout -k 10 120 python tools/bench_mlp.py $M 30 $V 2>&1 | tail -1
   for v in "$@"; do
-    DINOSEG_LIB=build/variants/lib_$v.so timeout -k 10 120 python tools/bench_mlp.py $M 30 $V 2>&1 | tail -1
+    DINOSEG_LIB=dino_amd/lib/variants/lib_$v.so timeout -k 10 120 python tools/bench_mlp.py $M 30 $V 2>&1 | tail -1
   done
 done
