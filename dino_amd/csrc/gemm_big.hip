@@ -65,6 +65,12 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / C::WN, wc = wave % C::WN;
     const int lr = lane & 31, lh = lane >> 5;
+    // the wave's NI = 3 column blocks inside the tile: blocks 0 and 1 are the adjacent halves of 64-column group wc, block 2 is half of
+    // group WN + wc / 2 (the other half: the neighbouring wave's) -- the 16-bit epilogues store whole 64-column groups (see there)
+    // (the fp32 epilogues keep 96 adjacent columns per wave: their row segments are 128 bytes either way, and the residual one has no
+    //  registers to spare for a second set of column offsets)
+    constexpr bool GROUPED = NI == 3 && !(EPI == EPI_PLAIN || EPI == EPI_RESID);
+    auto col_of = [&](int j) { return GROUPED ? (j < 2 ? wc * 64 + j * 32 : C::WN * 64 + wc * 32) : wc * NI * 32 + j * 32; };
 
     const int M = p.M, K = p.K;
     const int nk = K / BK;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
     auto bias_ptr = [&](int ti_c) {
         int bm2, bn2;
         tile_of(ti_c, bm2, bn2);
-        return p.bias + p.n_off + bn2 * BN + wc * NI * 32 + lr;
+        return p.bias + p.n_off + bn2 * BN + lr;
     };
     auto init_acc = [&]() {
 #pragma unroll
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
     {
         const float* bp = bias_ptr(0);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bias_col[j] = bp[j * 32];
+        for (int j = 0; j < NI; ++j) bias_col[j] = bp[col_of(j)];
     }
     init_acc();
 
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
                     af[pl][i] = lds_frag(sa + pl * C::A_PLANE_BYTES + off64(wr * MI * 32 + i * 32 + lr, kk * 2 + lh));
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    wf[pl][j] = lds_frag(sw + pl * C::W_PLANE_BYTES + off64(wc * NI * 32 + j * 32 + lr, kk * 2 + lh));
+                    wf[pl][j] = lds_frag(sw + pl * C::W_PLANE_BYTES + off64(col_of(j) + lr, kk * 2 + lh));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
             tile_of(ti, bm, bn);
             kt = 0;
             ++ti;
-            const int m0 = bm * BM + wr * MI * 32, n0 = p.n_off + bn * BN + wc * NI * 32;
+            const int m0 = bm * BM + wr * MI * 32, n0 = p.n_off + bn * BN;      // (+ col_of(j): the wave's column blocks)
             const bool skip_epi = (p.dbg & 1) && acc[0][0][0] != 12345.678f;   // ablation (keeps accumulators live)
             float* st = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES + wave * 4096);
             constexpr bool F32_OUT = (EPI == EPI_PLAIN || EPI == EPI_RESID);
@@ -241,10 +247,10 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
             if (EPI == EPI_RESID) {
                 // loads the compiler does not count (see below); complete before the last counted wait of the segment ring
 #pragma unroll
-                for (int j = 0; j < NI; ++j) asm volatile("global_load_dword %0, %1, off" : "=v"(bias_next[j]) : "v"(bnext + j * 32) : "memory");
+                for (int j = 0; j < NI; ++j) asm volatile("global_load_dword %0, %1, off" : "=v"(bias_next[j]) : "v"(bnext + col_of(j)) : "memory");
             } else {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) bias_next[j] = bnext[j * 32];
+                for (int j = 0; j < NI; ++j) bias_next[j] = bnext[col_of(j)];
             }
             if (!skip_epi) {
             if (EPI == EPI_RESID) {
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
                     float* tile_base = p.out_f32 + (long)m0 * p.ldo_f32 + n0;
                     auto seg_base = [&](int sg) {
                         const int b = sg >> 2, ps = sg & 3, j = b / MI, i = b % MI;
-                        return tile_base + (long)(i * 32 + 8 * ps) * p.ldo_f32 + j * 32;
+                        return tile_base + (long)(i * 32 + 8 * ps) * p.ldo_f32 + col_of(j);
                     };
                     f32x4 ring[LA];
 #pragma unroll
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
 #pragma unroll
                     for (int b = 0; b < MI * NI; ++b) {
                         const int j = b / MI, i = b % MI;
-                        const int gn = n0 + j * 32 + cg * 4;
+                        const int gn = n0 + col_of(j) + cg * 4;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) st[acc_row(r, lh) * 32 + lr] = acc[i][j][r];
 #pragma unroll
@@ -312,82 +318,121 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) void gemm_big_kernel
                 }
                 asm volatile("" : "+v"(bias_next[0]), "+v"(bias_next[1]), "+v"(bias_next[2]));
                 static_assert(NI == 3, "bias anchor names three registers");
-            } else {
+            } else if constexpr (F32_OUT) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const int cg = F32_OUT ? (lane & 7) : (lane & 3);
-                const int gn = n0 + j * 32 + cg * (F32_OUT ? 4 : 8);
-                int which = 0, hcol = 0;
-                bf16_t* qkv_base = nullptr;
-                if (EPI == EPI_QKV) {
-                    which = gn / p.dmodel;
-                    hcol = gn - which * p.dmodel;
-                    qkv_base = which == 0 ? p.q : (which == 1 ? p.k : p.v);
-                }
+                const int cg = lane & 7;
+                const int gn = n0 + col_of(j) + cg * 4;
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) st[acc_row(r, lh) * 32 + lr] = acc[i][j][r];
-                    if (F32_OUT) {
 #pragma unroll
-                        for (int ps = 0; ps < 4; ++ps) {
-                            const int row = (lane >> 3) + 8 * ps;
-                            int gm = m0 + i * 32 + row;
-                            gm = gm < M ? gm : M - 1;
-                            *reinterpret_cast<f32x4*>(p.out_f32 + (long)gm * p.ldo_f32 + gn) =
-                                *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 4);
-                        }
-                    } else {
-#pragma unroll
-                        for (int ps = 0; ps < 2; ++ps) {
-                            const int row = (lane >> 2) + 16 * ps;
-                            int gm = m0 + i * 32 + row;
-                            gm = gm < M ? gm : M - 1;
-                            const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 8);
-                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 8 + 4);
-                            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                if (EPI == EPI_GELU) v[e] = PL == 1 ? gelu_fast(v[e]) : gelu_erf(v[e]);
-                                if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
-                                if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
-                            }
-                            uint4 o[2];
-                            if (C::FMT == FMT_FP16 && !(EPI == EPI_QKV && which == 2 && (PL == 1 || p.v_bf16))) {      // (one plane, or asked for: V stays bf16)
-                                if (PL == 2) {      // (outputs are unbounded: saturate at the fp16 range)
-                                    split2<C::FMT, true>(v[0], v[1], o[0].x, o[1].x);
-                                    split2<C::FMT, true>(v[2], v[3], o[0].y, o[1].y);
-                                    split2<C::FMT, true>(v[4], v[5], o[0].z, o[1].z);
-                                    split2<C::FMT, true>(v[6], v[7], o[0].w, o[1].w);
-                                } else {
-                                    o[0].x = pack2_sat<C::FMT>(v[0], v[1]);
-                                    o[0].y = pack2_sat<C::FMT>(v[2], v[3]);
-                                    o[0].z = pack2_sat<C::FMT>(v[4], v[5]);
-                                    o[0].w = pack2_sat<C::FMT>(v[6], v[7]);
-                                    o[1] = o[0];
-                                }
-                            } else {
-                                split_bf16x2(v[0], v[1], o[0].x, o[1].x);
-                                split_bf16x2(v[2], v[3], o[0].y, o[1].y);
-                                split_bf16x2(v[4], v[5], o[0].z, o[1].z);
-                                split_bf16x2(v[6], v[7], o[0].w, o[1].w);
-                            }
-                            bf16_t* dst;
-                            long pstride;
-                            if (EPI == EPI_QKV) {
-                                const int bq = gm / p.ntok, tok = gm - bq * p.ntok;
-                                dst = qkv_base + ((long)(bq * p.heads + (hcol >> 6)) * p.npad + tok) * 64 + (hcol & 63);
-                                pstride = p.qkv_plane;
-                            } else {
-                                dst = p.out_bf16 + (long)gm * p.ldo + gn;
-                                pstride = p.out_plane;
-                            }
-                            *reinterpret_cast<uint4*>(dst) = o[0];
-                            if (PL == 2) *reinterpret_cast<uint4*>(dst + pstride) = o[1];
-                        }
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int row = (lane >> 3) + 8 * ps;
+                        int gm = m0 + i * 32 + row;
+                        gm = gm < M ? gm : M - 1;
+                        *reinterpret_cast<f32x4*>(p.out_f32 + (long)gm * p.ldo_f32 + gn) =
+                            *reinterpret_cast<const f32x4*>(st + row * 32 + cg * 4);
                     }
                 }
             }
+            } else {
+                // 16-bit outputs leave as 128-BYTE row segments: 8 lanes x 16 B, 8 rows per store instruction.  (Measured on the fc1 output of
+                // the parity mode -- 708 MB, tools/store_pattern.hip, profiles/r05_gemm_epilogue_stores.md: HBM takes 64-byte row segments at
+                // 3.2 TB/s, 128-byte ones at 5.3, whole 768-byte rows at 6.6; the first version of this epilogue stored one 32-column block
+                // = 64 bytes per row at a time and its stores were 182 of fc1's 534 us.)  A 64-column group goes through the wave's 4 KiB
+                // patch as two halves of [16 rows][64 columns] fp32.  The wave's blocks 0 and 1 are one group; its block 2 shares a group
+                // with the neighbouring wave's block 2 (wc ^ 1, same rows): the two write their halves of rows 0..15 into the even wave's
+                // patch and of rows 16..31 into the odd wave's, and after a workgroup barrier each stores the 16 rows in its own patch.
+                static_assert(NI == 3 && C::WN % 2 == 0, "column groups of the 16-bit epilogue");
+                const int cg = lane & 7, prow = lane >> 3;
+                // patch element (row, col): the two lane halves of an accumulator register write rows 4 apart -- column ^ 32 for odd row / 4
+                auto pidx = [](int row, int col) { return row * 64 + (col ^ (((row >> 2) & 1) << 5)); };
+                auto out64 = [&](const float* patch, int gm_first, int gn) __attribute__((always_inline)) {
+                    int which = 0, hcol = 0;
+                    bf16_t* qkv_base = nullptr;
+                    if (EPI == EPI_QKV) {
+                        which = gn / p.dmodel;
+                        hcol = gn - which * p.dmodel;
+                        qkv_base = which == 0 ? p.q : (which == 1 ? p.k : p.v);
+                    }
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int row = prow + 8 * ps;
+                        int gm = gm_first + row;
+                        gm = gm < M ? gm : M - 1;
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + pidx(row, cg * 8));
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(patch + pidx(row, cg * 8) + 4);
+                        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (EPI == EPI_GELU) v[e] = PL == 1 ? gelu_fast(v[e]) : gelu_erf(v[e]);
+                            if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+                            if (EPI == EPI_QKV && which == 0) v[e] *= p.qscale;
+                        }
+                        uint4 o[2];
+                        if (C::FMT == FMT_FP16 && !(EPI == EPI_QKV && which == 2 && (PL == 1 || p.v_bf16))) {      // (one plane, or asked for: V stays bf16)
+                            if (PL == 2) {      // (outputs are unbounded: saturate at the fp16 range)
+                                split2<C::FMT, true>(v[0], v[1], o[0].x, o[1].x);
+                                split2<C::FMT, true>(v[2], v[3], o[0].y, o[1].y);
+                                split2<C::FMT, true>(v[4], v[5], o[0].z, o[1].z);
+                                split2<C::FMT, true>(v[6], v[7], o[0].w, o[1].w);
+                            } else {
+                                o[0].x = pack2_sat<C::FMT>(v[0], v[1]);
+                                o[0].y = pack2_sat<C::FMT>(v[2], v[3]);
+                                o[0].z = pack2_sat<C::FMT>(v[4], v[5]);
+                                o[0].w = pack2_sat<C::FMT>(v[6], v[7]);
+                                o[1] = o[0];
+                            }
+                        } else {
+                            split_bf16x2(v[0], v[1], o[0].x, o[1].x);
+                            split_bf16x2(v[2], v[3], o[0].y, o[1].y);
+                            split_bf16x2(v[4], v[5], o[0].z, o[1].z);
+                            split_bf16x2(v[6], v[7], o[0].w, o[1].w);
+                        }
+                        bf16_t* dst;
+                        long pstride;
+                        if (EPI == EPI_QKV) {
+                            const int bq = gm / p.ntok, tok = gm - bq * p.ntok;
+                            dst = qkv_base + ((long)(bq * p.heads + (hcol >> 6)) * p.npad + tok) * 64 + cg * 8;
+                            pstride = p.qkv_plane;
+                        } else {
+                            dst = p.out_bf16 + (long)gm * p.ldo + gn + cg * 8;
+                            pstride = p.out_plane;
+                        }
+                        *reinterpret_cast<uint4*>(dst) = o[0];
+                        if (PL == 2) *reinterpret_cast<uint4*>(dst + pstride) = o[1];
+                    }
+                };
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) st[pidx(acc_row(r, lh), jj * 32 + lr)] = acc[i][jj][8 * h + r];
+                        out64(st, m0 + i * 32 + 16 * h, n0 + col_of(0));
+                    }
+                float* const pair_patch = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES + (wave & ~1) * 4096);
+                const int odd = wave & 1;
+                auto wg_barrier = [] {      // (a raw s_barrier is no compiler fence for LDS accesses)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                };
+                wg_barrier();       // the neighbour is done with the patch this wave writes into next
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) pair_patch[h * 1024 + pidx(acc_row(r, lh), odd * 32 + lr)] = acc[i][2][8 * h + r];
+                    wg_barrier();
+                    out64(st, m0 + i * 32 + 16 * odd, n0 + C::WN * 64 + (wc & ~1) * 32);
+                    wg_barrier();
+                }
             }
             }
 #pragma unroll

@@ -170,7 +170,7 @@ def bench_lngemm():
             if os.environ.get("LNGEMM_ONLY_FUSED"):
                 cases = [("fused", fused)]
             else:
-                cases += [("no-epi", ablate(1)), ("no-dma", ablate(2)), ("no-ln", ablate(4)), ("no-epi-ln", ablate(5)),
+                cases += [("no-epi", ablate(1)), ("no-stores", ablate(64)), ("no-dma", ablate(2)), ("no-ln", ablate(4)), ("no-epi-ln", ablate(5)),
                       ("mfma-only", ablate(7)), ("no-mfma", ablate(8)), ("reads+loop only", ablate(15)), ("mfma+loop only", ablate(39)),
                           ("loop only", ablate(47))]
             res = {nm: [] for nm, _ in cases}

@@ -364,14 +364,20 @@ def render():
     out.append("")
     for mq in (1, 2):
         out += operands(mq)
-    for name, op in (("AZA3_BODY_BF16", "v_mfma_f32_32x32x16_bf16"), ("AZA3_BODY_FP16", "v_mfma_f32_32x32x16_f16")):
-        e = generate3(op)
+    for name, op, abl in (("AZA3_BODY_BF16", "v_mfma_f32_32x32x16_bf16", 0), ("AZA3_BODY_FP16", "v_mfma_f32_32x32x16_f16", 0),
+                          ("AZA3_BODY_ABL1", "v_mfma_f32_32x32x16_bf16", 16), ("AZA3_BODY_ABL2", "v_mfma_f32_32x32x16_bf16", 32),
+                          ("AZA3_BODY_ABL3", "v_mfma_f32_32x32x16_bf16", 64), ("AZA3_BODY_ABL4", "v_mfma_f32_32x32x16_bf16", 128)):
+        e = generate3(op, abl)
+        if abl:
+            out.append("#ifdef AZA_ABLATIONS")
         out.append(f"// {e.n_inst} instructions")
         out.append(f"#define {name} \\")
         for i, ln in enumerate(e.lines):
             esc = ln.replace("\\", "\\\\").replace('"', '\\"')
             out.append(f'    "{esc}\\n\\t"{"" if i == len(e.lines) - 1 else " "}\\')
         out[-1] = out[-1].rstrip("\\").rstrip()
+        if abl:
+            out.append("#endif")
         out.append("")
     out.append(f"#define AZA3_FIRST_FREE_VGPR {Regs3().NV}")
     out.append("")
@@ -474,11 +480,15 @@ class Regs3:
 
 
 class Emitter3(Emitter):
-    def __init__(self, qk_op):
+    def __init__(self, qk_op, ablate=0):
         super().__init__(qk_op, 1, 0)
         self.R = Regs3()
+        self.abl3 = ablate            # timing-only builds of the hi + lo body: 16 = no tile barrier, 32 = no LDS-DMA in the loop,
+                                      # 64 = no exp / add / split (the vector work), 128 = no fragment reads
 
     def read_k3(self, i, s, slot, half):
+        if self.abl3 & 128:
+            return
         slot %= NSLOT
         off = (slot & 1) * SLOT3 + half * 4096
         a = vr(self.R.KA[slot >> 1] + s)
@@ -487,6 +497,8 @@ class Emitter3(Emitter):
         self.q += [self.R.KFL[i], self.R.KFH[i]]
 
     def read_v3(self, db, ks, slot):
+        if self.abl3 & 128:
+            return
         slot %= NSLOT
         off = (slot & 1) * SLOT3 + ks * 2048
         a0, a1 = vr(self.R.VA[slot >> 1] + 2 * db), vr(self.R.VA[slot >> 1] + 2 * db + 1)
@@ -534,7 +546,20 @@ def stage3(e, slot, odd, *, qk=True, pv=True, masked=False, barrier=False, prefe
                     pf = (pl_prv if m == 1 else ph_prv) + 4 * ksl
                     e.mfma(e.pv_op, R.O[db], vf, pf)
             # ---- the gap ----
-            if m == 0:
+            vec = not (e.abl3 & 64)
+            if m == 0 and not vec:
+                if barrier and g == 4:
+                    e.raw("s_waitcnt vmcnt(0)")
+                    if not (e.abl3 & 16):
+                        e.raw("s_barrier")
+                    e.raw("s_cmp_lt_u32 %[cnt], 2")
+                    e.branch("s_cbranch_scc1", f"NODMA{slot % NSLOT}")
+                    if not (e.abl3 & 32):
+                        e.dma_tile3(slot + 2)
+                    e.label(f"NODMA{slot % NSLOT}")
+            elif m == 1 and not vec:
+                pass
+            elif m == 0:
                 if masked:
                     e.mask(a, key_in_tile(2 * g, odd))
                     e.mask(b, key_in_tile(2 * g + 1, odd))
@@ -542,10 +567,12 @@ def stage3(e, slot, odd, *, qk=True, pv=True, masked=False, barrier=False, prefe
                 e.exp(b)
                 if barrier and g == 4:
                     e.raw("s_waitcnt vmcnt(0)")
-                    e.raw("s_barrier")
+                    if not (e.abl3 & 16):
+                        e.raw("s_barrier")
                     e.raw("s_cmp_lt_u32 %[cnt], 2")
                     e.branch("s_cbranch_scc1", f"NODMA{slot % NSLOT}")
-                    e.dma_tile3(slot + 2)
+                    if not (e.abl3 & 32):
+                        e.dma_tile3(slot + 2)
                     e.label(f"NODMA{slot % NSLOT}")
                 if g == 0 and not odd:
                     e.add(R.PS, a, b)
@@ -558,9 +585,10 @@ def stage3(e, slot, odd, *, qk=True, pv=True, masked=False, barrier=False, prefe
                 e.raw(f"v_lshlrev_b32_e32 {vr(R.T[0])}, 16, {vr(ph_cur + g)}")
                 e.raw(f"v_and_b32_e32 {vr(R.T[1])}, 0xffff0000, {vr(ph_cur + g)}")
             else:
-                e.raw(f"v_sub_f32_e32 {vr(a)}, {vr(a)}, {vr(R.T[0])}")
-                e.raw(f"v_sub_f32_e32 {vr(b)}, {vr(b)}, {vr(R.T[1])}")
-                e.pack(pl_cur + g, a, b)
+                if vec:
+                    e.raw(f"v_sub_f32_e32 {vr(a)}, {vr(a)}, {vr(R.T[0])}")
+                    e.raw(f"v_sub_f32_e32 {vr(b)}, {vr(b)}, {vr(R.T[1])}")
+                    e.pack(pl_cur + g, a, b)
                 # fragment reads behind the last use of the buffers
                 if g == 0 and qk:
                     e.read_k3(0, 2, k_slot, k_half)
@@ -584,8 +612,8 @@ def stage3(e, slot, odd, *, qk=True, pv=True, masked=False, barrier=False, prefe
         e.add(R.L, R.L, R.PS)
 
 
-def generate3(qk_op):
-    e = Emitter3(qk_op)
+def generate3(qk_op, ablate=0):
+    e = Emitter3(qk_op, ablate)
     R = e.R
     e.comment("GENERATED by tools/gen_attn_asm.py -- do not edit (hi + lo planes)")
     e.raw("s_mov_b32 %[m0s], m0")
