@@ -183,7 +183,7 @@ def bench_lngemm():
                 print(f"{name} planes={planes} {nm:8s}: {t * 1e3:7.1f} us  {fl / (t * 1e-3) / 1e12:7.1f} TFLOP/s", flush=True)
 
 
-ATTN_VARIANTS = [int(v) for v in os.environ.get("ATTN_VARIANTS", "11").split(",")]
+ATTN_VARIANTS = os.environ.get("ATTN_VARIANTS", "11").split(",")        # "<attn_variant>" or "<attn_variant>:<attn_dbg>"
 
 
 def bench_attn():
@@ -192,7 +192,7 @@ def bench_attn():
     B, H, ntok = int(os.environ.get("ATTN_B", "32")), 6, int(os.environ.get("ATTN_NTOK", "3601"))
     npad = (ntok + 63) // 64 * 64
     base = dict(attn_variant=3)
-    variants = [(f"variant {v}", dict(base, attn_variant=v)) for v in ATTN_VARIANTS]
+    variants = [(f"variant {v}", dict(base, attn_variant=int(v.split(":")[0]), attn_dbg=int((v + ":0").split(":")[1]))) for v in ATTN_VARIANTS]
     op_fmt = int(os.environ.get("OP_FMT", "0"))       # 1: fp16 Q / K (single plane), as precision 'fp16' runs the kernel
     capi.check(lib.dinoseg_set_option(b"op_fmt", op_fmt))
     for planes in [int(v) for v in os.environ.get("ATTN_PLANES", "1,2").split(",")]:
@@ -221,6 +221,7 @@ def bench_attn():
                   f"{fl / (t[len(t) // 2] * 1e-3) / 1e12:6.1f} TFLOP/s", flush=True)
     for kk, vv in base.items():
         lib.dinoseg_set_option(kk.encode(), vv)
+    lib.dinoseg_set_option(b"attn_dbg", 0)
     lib.dinoseg_set_option(b"op_fmt", 0)
 
 

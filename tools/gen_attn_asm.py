@@ -68,11 +68,13 @@ def vr(base, n=1):
 
 
 class Emitter:
-    def __init__(self, qk_op, mq=1, ablate=0):
+    def __init__(self, qk_op, mq=1, ablate=0, dma_mq=None):
         self.qk_op = qk_op
         self.pv_op = "v_mfma_f32_32x32x16_bf16"
         self.R = Regs(mq)
         self.mq = mq
+        self.dma_mq = dma_mq or mq     # the workgroup's LDS-DMA split (pieces per wave and slab): a one-block body inside a four-wave
+                                       # workgroup (the wave whose second query block lies past the last row) keeps the four-wave split
         self.ablate = ablate           # timing-only builds (wrong results): bit 0 = no V^T fragment reads, bit 1 = no K fragment reads,
                                        # 4 = V fragments by ONE ds_read_b128 (K's address pattern on the V slab) instead of two transposing
                                        # reads, 8 = V reads as they are but the P.V MFMAs take a constant A operand (the Q fragments)
@@ -176,7 +178,7 @@ class Emitter:
     def dma_tile(self, slot):
         base = (slot % NSLOT) * SLOT
         for slab, src in ((0, "kb"), (8192, "vb")):
-            for j in range(self.mq):
+            for j in range(self.dma_mq):
                 self.raw(f"s_add_u32 m0, %[lds], {base + slab + 4096 * j}")
                 self.raw("s_nop 0")
                 self.raw(f"global_load_lds_dwordx4 {vr(self.R.SOFF)}, %[{src}{'2' if j else ''}]")
@@ -186,7 +188,7 @@ class Emitter:
 
     @property
     def dma_per_tile(self):
-        return 2 * self.mq
+        return 2 * self.dma_mq
 
 
 def key_in_tile(r, odd):
@@ -271,8 +273,8 @@ def stage(e, slot, odd, *, qk=True, pv=True, masked=False, barrier=False, prefet
             e.add(R.L[qb], R.L[qb], R.PS[qb])
 
 
-def generate(qk_op, mq=1, ablate=0):
-    e = Emitter(qk_op, mq, ablate)
+def generate(qk_op, mq=1, ablate=0, dma_mq=None):
+    e = Emitter(qk_op, mq, ablate, dma_mq)
     R = e.R
     e.comment("GENERATED by tools/gen_attn_asm.py -- do not edit")
     e.raw("s_mov_b32 %[m0s], m0")
@@ -337,6 +339,7 @@ def generate(qk_op, mq=1, ablate=0):
 
 BODIES = (("AZA_BODY_BF16", "v_mfma_f32_32x32x16_bf16", 1, 0), ("AZA_BODY_FP16", "v_mfma_f32_32x32x16_f16", 1, 0),
           ("AZA2_BODY_BF16", "v_mfma_f32_32x32x16_bf16", 2, 0), ("AZA2_BODY_FP16", "v_mfma_f32_32x32x16_f16", 2, 0),
+          ("AZA2L_BODY_BF16", "v_mfma_f32_32x32x16_bf16", -1, 0), ("AZA2L_BODY_FP16", "v_mfma_f32_32x32x16_f16", -1, 0),
           ("AZA_BODY_ABL1", "v_mfma_f32_32x32x16_bf16", 1, 1), ("AZA_BODY_ABL2", "v_mfma_f32_32x32x16_bf16", 1, 2),
           ("AZA_BODY_ABL3", "v_mfma_f32_32x32x16_bf16", 1, 4), ("AZA_BODY_ABL4", "v_mfma_f32_32x32x16_bf16", 1, 8))
 
@@ -346,7 +349,7 @@ def render():
            "// The tile loop of attn_fwd_za_kernel (attention_za.hip) as one inline-asm body per (queries per wave, operand format); register",
            "// map, pipeline and the lgkmcnt bookkeeping are described in the generator.  AZA_BODY_ABL*: timing-only ablations (-DAZA_ABLATIONS).", ""]
     for name, op, mq, abl in BODIES:
-        e = generate(op, mq, abl)
+        e = generate(op, mq, abl) if mq > 0 else generate(op, 1, abl, dma_mq=2)      # (-1: the one-block body of a four-wave workgroup)
         if abl:
             out.append("#ifdef AZA_ABLATIONS")
         out.append(f"// {e.n_inst} instructions")
@@ -364,6 +367,7 @@ def render():
     out.append("")
     for mq in (1, 2):
         out += operands(mq)
+    out += operands(1, light=True)
     for name, op, abl in (("AZA3_BODY_BF16", "v_mfma_f32_32x32x16_bf16", 0), ("AZA3_BODY_FP16", "v_mfma_f32_32x32x16_f16", 0),
                           ("AZA3_BODY_ABL1", "v_mfma_f32_32x32x16_bf16", 16), ("AZA3_BODY_ABL2", "v_mfma_f32_32x32x16_bf16", 32),
                           ("AZA3_BODY_ABL3", "v_mfma_f32_32x32x16_bf16", 64), ("AZA3_BODY_ABL4", "v_mfma_f32_32x32x16_bf16", 128)):
@@ -385,7 +389,7 @@ def render():
     return "\n".join(out)
 
 
-def operands(mq):
+def operands(mq, light=False):
     """The asm statement's operand lists for the kernel's variable names (attention_za.hip): o[qb][db], pz[qb] (zeros), soff, l_run[qb],
     cnt, m0s | qf[qb][s], ka_abs[s], va_abs[i], thr, kb (kb2), vb (vb2), lds_piece | clobbers = every scratch register of the map."""
     R = Regs(mq)
@@ -397,7 +401,7 @@ def operands(mq):
     ins = [f'"{pin(R.Q[qb][s], 4)}"(qf[{qb}][{s}])' for qb in range(mq) for s in range(4)]
     ins += [f'"{pin(R.KA + s)}"(ka_abs[{s}])' for s in range(4)] + [f'"{pin(R.VA + i)}"(va_abs[{i}])' for i in range(4)]
     ins += [f'"{pin(R.THR)}"(thr)', '[kb] "s"(kb)', '[vb] "s"(vb)']
-    if mq == 2:
+    if mq == 2 or light:
         ins += ['[kb2] "s"(kb2)', '[vb2] "s"(vb2)']
     ins += ['[lds] "s"(lds_piece)']
     scratch = []
@@ -411,7 +415,7 @@ def operands(mq):
     scratch += R.PS + [R.NINF]
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"v{r}"' for r in sorted(scratch)]
 
-    return _operand_macro(f"AZA{'' if mq == 1 else '2'}_OPERANDS", outs, ins, clob)
+    return _operand_macro("AZA2L_OPERANDS" if light else f"AZA{'' if mq == 1 else '2'}_OPERANDS", outs, ins, clob)
 
 
 def _operand_macro(name, outs, ins, clob):
