@@ -68,13 +68,14 @@ def vr(base, n=1):
 
 
 class Emitter:
-    def __init__(self, qk_op, mq=1, ablate=0, dma_mq=None):
+    def __init__(self, qk_op, mq=1, ablate=0, qbs=None):
         self.qk_op = qk_op
         self.pv_op = "v_mfma_f32_32x32x16_bf16"
         self.R = Regs(mq)
         self.mq = mq
-        self.dma_mq = dma_mq or mq     # the workgroup's LDS-DMA split (pieces per wave and slab): a one-block body inside a four-wave
-                                       # workgroup (the wave whose second query block lies past the last row) keeps the four-wave split
+        self.qbs = list(qbs) if qbs is not None else list(range(mq))       # the query blocks this body computes: (0,) on the two-block map
+                                       # = the body of a wave whose second block lies past the last row -- same registers, same LDS-DMA
+                                       # share, same operand list as the full body (a second pinning would cost the kernel spills)
         self.ablate = ablate           # timing-only builds (wrong results): bit 0 = no V^T fragment reads, bit 1 = no K fragment reads,
                                        # 4 = V fragments by ONE ds_read_b128 (K's address pattern on the V slab) instead of two transposing
                                        # reads, 8 = V reads as they are but the P.V MFMAs take a constant A operand (the Q fragments)
@@ -178,7 +179,7 @@ class Emitter:
     def dma_tile(self, slot):
         base = (slot % NSLOT) * SLOT
         for slab, src in ((0, "kb"), (8192, "vb")):
-            for j in range(self.dma_mq):
+            for j in range(self.mq):
                 self.raw(f"s_add_u32 m0, %[lds], {base + slab + 4096 * j}")
                 self.raw("s_nop 0")
                 self.raw(f"global_load_lds_dwordx4 {vr(self.R.SOFF)}, %[{src}{'2' if j else ''}]")
@@ -188,7 +189,7 @@ class Emitter:
 
     @property
     def dma_per_tile(self):
-        return 2 * self.dma_mq
+        return 2 * self.mq
 
 
 def key_in_tile(r, odd):
@@ -215,8 +216,8 @@ def stage(e, slot, odd, *, qk=True, pv=True, masked=False, barrier=False, prefet
     e.comment(f"---- stage: slot {slot % NSLOT}, {'odd' if odd else 'even'}{' masked' if masked else ''}"
               f"{'' if qk else ' no-QK'}{'' if pv else ' no-PV'}")
     for g in range(8):
-        for qb in range(mq):
-            last = qb == mq - 1
+        for qb in e.qbs:
+            last = qb == e.qbs[-1]
             # ---- the MFMA in front of this gap ----
             if g % 2 == 0:
                 if qk:
@@ -269,12 +270,12 @@ def stage(e, slot, odd, *, qk=True, pv=True, masked=False, barrier=False, prefet
                 e.add(R.PS[qb], R.PS[qb], b)
             e.pack(p_cur[qb] + g, a, b)
     if add_l:
-        for qb in range(mq):
+        for qb in e.qbs:
             e.add(R.L[qb], R.L[qb], R.PS[qb])
 
 
-def generate(qk_op, mq=1, ablate=0, dma_mq=None):
-    e = Emitter(qk_op, mq, ablate, dma_mq)
+def generate(qk_op, mq=1, ablate=0, qbs=None):
+    e = Emitter(qk_op, mq, ablate, qbs)
     R = e.R
     e.comment("GENERATED by tools/gen_attn_asm.py -- do not edit")
     e.raw("s_mov_b32 %[m0s], m0")
@@ -287,7 +288,7 @@ def generate(qk_op, mq=1, ablate=0, dma_mq=None):
     e.read_k(R.KF[0], 0, 0, 0)
     e.read_k(R.KF[1], 1, 0, 0)
     for s in range(4):
-        for qb in range(mq):
+        for qb in e.qbs:
             e.mfma_qk(R.S[0][qb], R.KF[s & 1], qb, s, first=(s == 0))
         if s < 2:
             e.read_k(R.KF[s & 1], s + 2, 0, 0)
@@ -322,7 +323,7 @@ def generate(qk_op, mq=1, ablate=0, dma_mq=None):
         e.comment("---- tail")
         for ksl in range(2):
             for db in range(2):
-                for qb in range(e.mq):
+                for qb in e.qbs:
                     e.mfma_pv(R.O[qb][db], R.VF[db], R.P[1][qb], ksl)
                 if ksl == 0:
                     e.read_v(R.VF[db], db, 3, s)
@@ -349,7 +350,7 @@ def render():
            "// The tile loop of attn_fwd_za_kernel (attention_za.hip) as one inline-asm body per (queries per wave, operand format); register",
            "// map, pipeline and the lgkmcnt bookkeeping are described in the generator.  AZA_BODY_ABL*: timing-only ablations (-DAZA_ABLATIONS).", ""]
     for name, op, mq, abl in BODIES:
-        e = generate(op, mq, abl) if mq > 0 else generate(op, 1, abl, dma_mq=2)      # (-1: the one-block body of a four-wave workgroup)
+        e = generate(op, mq, abl) if mq > 0 else generate(op, 2, abl, qbs=(0,))      # (-1: the one-block body on the two-block map)
         if abl:
             out.append("#ifdef AZA_ABLATIONS")
         out.append(f"// {e.n_inst} instructions")
@@ -367,7 +368,6 @@ def render():
     out.append("")
     for mq in (1, 2):
         out += operands(mq)
-    out += operands(1, light=True)
     for name, op, abl in (("AZA3_BODY_BF16", "v_mfma_f32_32x32x16_bf16", 0), ("AZA3_BODY_FP16", "v_mfma_f32_32x32x16_f16", 0),
                           ("AZA3_BODY_ABL1", "v_mfma_f32_32x32x16_bf16", 16), ("AZA3_BODY_ABL2", "v_mfma_f32_32x32x16_bf16", 32),
                           ("AZA3_BODY_ABL3", "v_mfma_f32_32x32x16_bf16", 64), ("AZA3_BODY_ABL4", "v_mfma_f32_32x32x16_bf16", 128)):
@@ -389,7 +389,7 @@ def render():
     return "\n".join(out)
 
 
-def operands(mq, light=False):
+def operands(mq):
     """The asm statement's operand lists for the kernel's variable names (attention_za.hip): o[qb][db], pz[qb] (zeros), soff, l_run[qb],
     cnt, m0s | qf[qb][s], ka_abs[s], va_abs[i], thr, kb (kb2), vb (vb2), lds_piece | clobbers = every scratch register of the map."""
     R = Regs(mq)
@@ -401,7 +401,7 @@ def operands(mq, light=False):
     ins = [f'"{pin(R.Q[qb][s], 4)}"(qf[{qb}][{s}])' for qb in range(mq) for s in range(4)]
     ins += [f'"{pin(R.KA + s)}"(ka_abs[{s}])' for s in range(4)] + [f'"{pin(R.VA + i)}"(va_abs[{i}])' for i in range(4)]
     ins += [f'"{pin(R.THR)}"(thr)', '[kb] "s"(kb)', '[vb] "s"(vb)']
-    if mq == 2 or light:
+    if mq == 2:
         ins += ['[kb2] "s"(kb2)', '[vb2] "s"(vb2)']
     ins += ['[lds] "s"(lds_piece)']
     scratch = []
@@ -415,7 +415,7 @@ def operands(mq, light=False):
     scratch += R.PS + [R.NINF]
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"v{r}"' for r in sorted(scratch)]
 
-    return _operand_macro("AZA2L_OPERANDS" if light else f"AZA{'' if mq == 1 else '2'}_OPERANDS", outs, ins, clob)
+    return _operand_macro(f"AZA{'' if mq == 1 else '2'}_OPERANDS", outs, ins, clob)
 
 
 def _operand_macro(name, outs, ins, clob):
