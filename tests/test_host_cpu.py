@@ -241,3 +241,13 @@ def test_host_side_under_address_sanitizer():
                         "-k", "exports or lifecycle or no_cpu_fallback"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "AddressSanitizer" not in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]
     assert "3 passed" in r.stdout
+
+
+def test_generated_attention_bodies_are_current():
+    """dino_amd/csrc/attention_za_gen.inc is what tools/gen_attn_asm.py writes (the generator re-derives every body -- register map,
+    pipeline order, counted LDS waits, with its own consistency assertions at every label -- and compares with the committed file)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_attn_asm.py"), "--check"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
