@@ -109,7 +109,8 @@ struct Options {
     int gemm_ln = 1;         // qkv / fc1 through the LayerNorm-fused kernel (gemm_ln.hip): 0 never, 2 wherever it applies, 1 = by measurement (api.hip)
     int gemm_big = 1;        // use gemm_big.hip where it applies
     int gemm_dbg = 0;        // ablation bits copied into GemmParams::dbg (wrong results; timing only)
-    int attn_dbg = 0;        // same for AttnParams::dbg
+    int attn_dbg = 0;        // same for AttnParams::dbg (bits 0-2: attention.hip ablations, wrong results); bit 3: attention_za's one-block body for the
+                             // ragged last q-tile OFF (an A/B switch, results unchanged)
     int mlp_fused = 1;       // the MLP half of a block as one launch (mlp_fused2.hip): 0 never, 1 for >= mlp_fused_min_rows rows, 2 wherever supported
     int mlp_fused_min_rows = 12000;      // (4 frames @480: +3 %; 6 frames: +18 % with the projection inside; 2 frames: even)
     int mlp_stagger = 0;     // experiment: > 0 = one workgroup per CU, those with one item fewer start up to this many x 3.9 us late
