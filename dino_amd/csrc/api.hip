@@ -1058,6 +1058,33 @@ extern "C" int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* 
     return launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
 }
 
+extern "C" int64_t dinoseg_op_mlp3_pack_elems(int32_t D, int32_t F) { return mlp_fused3_pack_elems(D, F); }
+
+extern "C" int dinoseg_op_pack_mlp3(const float* Wproj, const float* W1, const float* W2, int32_t D, int32_t F, int32_t fmt, void* dst,
+                                    void* stream) {
+    if (fmt != FMT_BF16 && fmt != FMT_FP16) {
+        dinoseg_set_error("dinoseg_op_pack_mlp3: bad operand format %d", fmt);
+        return -1;
+    }
+    return launch_pack_mlp3(Wproj, W1, W2, D, F, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), fmt);
+}
+
+extern "C" int dinoseg_op_proj_mlp_fused3(float* X, const void* ctx, int64_t ctx_plane, const float* bproj, const float* gamma,
+                                          const float* beta, float eps, const void* Wp, const float* b1, const float* b2, int32_t M,
+                                          int32_t D, int32_t F, int32_t fmt, void* a_out, int64_t a_plane, const float* gamma1,
+                                          const float* beta1, void* stream) {
+    if (!mlp_fused3_supported(D, F, 2) || (fmt != FMT_BF16 && fmt != FMT_FP16) || (a_out && (!gamma1 || !beta1 || a_plane <= 0))) {
+        dinoseg_set_error("dinoseg_op_proj_mlp_fused3: unsupported shape D=%d F=%d, format %d, or incomplete norm1 output", D, F, fmt);
+        return -1;
+    }
+    MlpFused3Params g = {};
+    g.X = X; g.gamma = gamma; g.beta = beta; g.eps = eps;
+    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
+    g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.ctx_plane = ctx_plane; g.bproj = bproj; g.fmt = fmt;
+    g.a_out = reinterpret_cast<bf16_t*>(a_out); g.a_plane = a_plane; g.gamma1 = gamma1; g.beta1 = beta1;
+    return launch_mlp_fused3(g, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int64_t dinoseg_op_qkv_pack_elems(int32_t D) { return mlp_fused_qkv_pack_elems(D); }
 
 extern "C" int dinoseg_op_pack_qkv(const float* Wsrc, int32_t D, void* dst, void* stream) {

@@ -104,6 +104,25 @@ long mlp_fused_pack_elems(int D, int F);        // bf16 elements of the packed c
 int launch_pack_mlp(const float* W1, const float* W2, int D, int F, bf16_t* dst, hipStream_t s, int fmt = 0);
 int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s);     // role-split wave pairs, two waves per SIMD (mlp_fused2.hip)
 
+// Attention output projection + fused MLP of one block on hi + lo operand planes (mlp_fused3.hip): X += ctx . Wproj^T + bproj (when ctx is
+// given), then X += fc2(gelu(fc1(LayerNorm(X)))), in place, one launch, D = 384
+struct MlpFused3Params {
+    float* X;                                   // residual stream [M, 384] fp32
+    const float* gamma; const float* beta; float eps;      // norm2
+    const bf16_t* Wp;                           // launch_pack_mlp3: proj + fc1 + fc2 as 108 slots of (lo, hi) fragment pairs, in stream order
+    const float* b1; const float* b2;           // [1536], [384]
+    int M;
+    const bf16_t* ctx; long ctx_plane;          // attention output planes [2][M][384] (hi, then lo at + ctx_plane elements); null = MLP only
+    const float* bproj;
+    int fmt;                                    // operand format of ctx, the packed weights and everything in between (FMT_BF16 / FMT_FP16)
+    // optional: LayerNorm1 of the NEXT block on the finished rows, written as operand planes [2][M][384] (what launch_layernorm would write)
+    bf16_t* a_out; long a_plane; const float* gamma1; const float* beta1;
+};
+bool mlp_fused3_supported(int D, int F, int planes);
+long mlp_fused3_pack_elems(int D, int F);       // 16-bit elements of the packed copy (0: unsupported shape)
+int launch_pack_mlp3(const float* Wproj, const float* W1, const float* W2, int D, int F, bf16_t* dst, hipStream_t s, int fmt);
+int launch_mlp_fused3(const MlpFused3Params& p, hipStream_t s);
+
 // tuning knobs (dinoseg_set_option): see api.hip
 struct Options {
     int gemm_ln = 1;         // qkv / fc1 through the LayerNorm-fused kernel (gemm_ln.hip): 0 never, 2 wherever it applies, 1 = by measurement (api.hip)

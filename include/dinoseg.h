@@ -279,6 +279,19 @@ int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* Wproj, cons
                               const float* beta, float eps, const void* Wp, const float* b1, const float* b2, int32_t M,
                               int32_t D, int32_t F, void* stream);
 
+/* The same fusion on hi + lo operand planes (the parity modes; mlp_fused3.hip), one launch for
+ *     X += ctx . Wproj^T + bproj;   X += fc2(gelu(fc1(LayerNorm(X))))      (vision_transformer.py:104-105, :123, :135 -> :59-65)
+ * ctx: the attention output as two planes [2][M][384] (hi, then lo at + ctx_plane elements), or null = the MLP half only (bproj unused).
+ * Wp: Wproj, W1 and W2 re-packed by dinoseg_op_pack_mlp3 (dinoseg_op_mlp3_pack_elems(D, F) 16-bit elements; 0 = unsupported shape;
+ * Wproj is read by the pack even when the launch will run without ctx).  fmt: 0 = bf16 planes, 1 = fp16 planes.
+ * a_out (optional): LayerNorm of the finished rows with gamma1 / beta1 -- norm1 of the NEXT block (vision_transformer.py:122) -- as
+ * operand planes [2][M][384] (lo at + a_plane), what dinoseg_op_layernorm would write from X after this launch. */
+int64_t dinoseg_op_mlp3_pack_elems(int32_t D, int32_t F);
+int dinoseg_op_pack_mlp3(const float* Wproj, const float* W1, const float* W2, int32_t D, int32_t F, int32_t fmt, void* dst, void* stream);
+int dinoseg_op_proj_mlp_fused3(float* X, const void* ctx, int64_t ctx_plane, const float* bproj, const float* gamma, const float* beta,
+                               float eps, const void* Wp, const float* b1, const float* b2, int32_t M, int32_t D, int32_t F, int32_t fmt,
+                               void* a_out, int64_t a_plane, const float* gamma1, const float* beta1, void* stream);
+
 /* ... and with LayerNorm1 + the qkv projection of the NEXT block at its end (Block.forward of block i from `x = x + attn` on, then
  * block i+1 up to `qkv = self.qkv(self.norm1(x))`: vision_transformer.py:123, :135, :122 -> :75): after the launch X holds block i's
  * output and q / k / v ([B, heads, npad, 64] bf16 each, q pre-scaled by qscale = 64^-0.5 * log2(e), rows >= ntok untouched) hold what

@@ -765,6 +765,82 @@ def test_proj_mlp_fused(cuda, M_):
     assert float((got - two).abs().max()) <= 2.0 ** -9 * scale + 1e-3
 
 
+def _split_planes(x: torch.Tensor, fp16: bool):
+    """fp32 -> (int16 planes [2, ...] as the hi + lo kernels read them, the fp32 value the two planes carry)"""
+    dt = torch.float16 if fp16 else torch.bfloat16
+    hi = x.to(dt)
+    lo = (x - hi.float()).to(dt)
+    return torch.stack([hi, lo]).contiguous().view(torch.int16), hi.float() + lo.float()
+
+
+def _mlp3_case(M_, fp16, seed0):
+    D_, F_ = 384, 1536
+    X = seeded((M_, D_), seed0 + 1) * 1.7 + 0.4 + torch.arange(D_, device="cuda", dtype=torch.float32)[None, :] * 1e-3
+    ctx = seeded((M_, D_), seed0 + 8) * 0.8
+    Wpr = seeded((D_, D_), seed0 + 9) * 0.07 + torch.arange(D_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    bpr = seeded((D_,), seed0 + 10) * 0.3
+    gam, bet = 1 + 0.2 * seeded((D_,), seed0 + 2), 0.1 * seeded((D_,), seed0 + 3)
+    W1 = seeded((F_, D_), seed0 + 4) * 0.06 + torch.arange(F_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    b1 = seeded((F_,), seed0 + 5) * 0.5
+    W2 = seeded((D_, F_), seed0 + 6) * 0.04 + torch.arange(D_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    b2 = seeded((D_,), seed0 + 7)
+    lib = capi.lib()
+    n = lib.dinoseg_op_mlp3_pack_elems(D_, F_)
+    assert n == 2 * (D_ * D_ + 2 * D_ * F_)
+    Wp = torch.empty((n,), dtype=torch.int16, device="cuda")
+    capi.check(lib.dinoseg_op_pack_mlp3(Wpr.data_ptr(), W1.data_ptr(), W2.data_ptr(), D_, F_, int(fp16), Wp.data_ptr(), S()))
+    return dict(X=X, ctx=ctx, Wpr=Wpr, bpr=bpr, gam=gam, bet=bet, W1=W1, b1=b1, W2=W2, b2=b2, Wp=Wp)
+
+
+@pytest.mark.parametrize("fp16", [True, False])
+@pytest.mark.parametrize("proj", [True, False])
+@pytest.mark.parametrize("M_", [128, 77, 128 * 5 + 33, 128 * 300 + 19])
+def test_proj_mlp_fused_hi_lo_planes(cuda, M_, proj, fp16):
+    """The attention output projection + the MLP half of a block in ONE launch on hi + lo operand planes (mlp_fused3.hip; what the
+    parity modes fp16x3 / bf16x3 run at large batch):
+        x += ctx . Wproj^T + bproj;   x += fc2(gelu(fc1(LayerNorm(x))))      (vision_transformer.py:104-105, :123, :135 -> :59-65)
+    against fp64 on the operands the kernel sees (two-plane ctx / weights / LayerNorm and GELU outputs) and against fp64 on the
+    UNSPLIT operands (the split must track the fp32 module).  M = 38 419: more items than CUs (the weight ring runs on across the
+    items of the persistent walk); 77 / 673: ragged last item (clamped rows)."""
+    c = _mlp3_case(M_, fp16, 140)
+    lib = capi.lib()
+    D_, F_ = 384, 1536
+    q2 = lambda t: _split_planes(t, fp16)[1]
+    ctx_pl, ctx_q = _split_planes(c["ctx"], fp16)
+    got = c["X"].clone()
+    capi.check(lib.dinoseg_op_proj_mlp_fused3(got.data_ptr(), ctx_pl.data_ptr() if proj else None, M_ * D_, c["bpr"].data_ptr(),
+                                              c["gam"].data_ptr(), c["bet"].data_ptr(), 1e-6, c["Wp"].data_ptr(), c["b1"].data_ptr(),
+                                              c["b2"].data_ptr(), M_, D_, F_, int(fp16), None, 0, None, None, S()))
+    torch.cuda.synchronize()
+
+    def model(quant):
+        xmid = c["X"].double()
+        if proj:
+            xmid = xmid + (quant(c["ctx"]) if quant else c["ctx"]).double() @ (quant(c["Wpr"]) if quant else c["Wpr"]).double().t() + c["bpr"].double()
+        ln = _ln_ref(xmid.float(), c["gam"], c["bet"]).cuda() if quant else \
+            torch.nn.functional.layer_norm(xmid, (D_,), c["gam"].double(), c["bet"].double(), 1e-6)
+        A = quant(ln).double() if quant else ln
+        z = A @ (quant(c["W1"]) if quant else c["W1"]).double().t() + c["b1"].double()
+        g = 0.5 * z * (1.0 + torch.erf(z / math.sqrt(2.0)))
+        Hq = quant(g.float()).double() if quant else g
+        delta = Hq @ (quant(c["W2"]) if quant else c["W2"]).double().t() + c["b2"].double()
+        return xmid, delta
+
+    xmid, delta = model(q2)
+    want = (xmid + delta).float()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    scale = float(delta.abs().max())
+    # left over: fp32 summation order, the dropped lo . lo products (2^-16 / 2^-22 of a product), the erf approximation (1.5e-7), and
+    # rounding points of the LayerNorm / GELU planes that the kernel's own fp32 arithmetic moves by one ulp of the lo plane
+    assert err <= (2.0e-5 if fp16 else 6.0e-5) * scale + 1e-5, (err, scale)
+    assert float((got - c["X"]).abs().max()) > 0.5 * scale
+    xm0, d0 = model(None)
+    err0 = float((got - (xm0 + d0).float()).abs().max())
+    assert err0 <= (3.0e-5 if fp16 else 2.0e-4) * scale + 1e-5, (err0, scale)
+    print(f"mlp3 M={M_} proj={proj} fp16={fp16}: err {err:.3e} err_true {err0:.3e} scale {scale:.3f}")
+
+
 @pytest.mark.parametrize("B,ntok", [(1, 65), (3, 130), (2, 901), (11, 3601)])
 def test_block_tail_fused(cuda, B, ntok):
     """One launch from `x = x + proj(attn)` of block i to `qkv = qkv(norm1(x))` of block i+1 (mlp_fused2.hip, PROJ + QKV):

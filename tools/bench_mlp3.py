@@ -1,0 +1,53 @@
+"""GPU box: time the hi + lo fused projection + MLP launch (mlp_fused3.hip) alone:
+    python tools/bench_mlp3.py [rows] [iters] [fp16: 1|0] [proj: 1|0]
+DINOSEG_LIB selects the build for A/B runs (ablation builds: make EXTRA=-DMF3_ABL=...)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dino_amd import capi  # noqa: E402
+from tests.gpu_util import seeded  # noqa: E402
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 32 * 3601
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+fp16 = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+proj = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+D, F = 384, 1536
+dt = torch.float16 if fp16 else torch.bfloat16
+X = seeded((M, D), 1) * 1.5
+gam, bet = 1 + 0.2 * seeded((D,), 2), 0.1 * seeded((D,), 3)
+W1, b1 = seeded((F, D), 4) * 0.06, seeded((F,), 5) * 0.5
+W2, b2 = seeded((D, F), 6) * 0.002, seeded((D,), 7) * 0.01
+Wpr, bpr = seeded((D, D), 9) * 0.01, seeded((D,), 10) * 0.01
+c = seeded((M, D), 8) * 0.5
+hi = c.to(dt)
+ctx = torch.stack([hi, (c - hi.float()).to(dt)]).contiguous().view(torch.int16)
+lib = capi.lib()
+S = capi.stream_ptr
+Wp = torch.empty((lib.dinoseg_op_mlp3_pack_elems(D, F),), dtype=torch.int16, device="cuda")
+capi.check(lib.dinoseg_op_pack_mlp3(Wpr.data_ptr(), W1.data_ptr(), W2.data_ptr(), D, F, fp16, Wp.data_ptr(), S()))
+
+
+def run():
+    capi.check(lib.dinoseg_op_proj_mlp_fused3(X.data_ptr(), ctx.data_ptr() if proj else None, M * D, bpr.data_ptr(), gam.data_ptr(),
+                                              bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), M, D, F, fp16, None, 0,
+                                              None, None, S()))
+
+
+for rep in range(3):
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / iters * 1e3
+    fl = 2.0 * M * D * (2 * F + (D if proj else 0))
+    print(f"mlp_fused3 fp16={fp16} proj={proj} M={M}: {us:.1f} us  {fl / us / 1e6:.0f} TFLOP/s algorithmic, {3 * fl / us / 1e6:.0f} of MFMA issue"
+          f"  lib={os.path.basename(os.environ.get('DINOSEG_LIB', 'in-tree'))}", flush=True)
+assert torch.isfinite(X).all()
