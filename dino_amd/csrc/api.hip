@@ -198,6 +198,7 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
                 h->packed_mlp.clear();
                 h->packed_proj.clear();
                 h->packed_qkvf.clear();
+                h->packed_mlp3.clear();
                 h->bound.clear();
                 h->grads.clear();
             }
@@ -272,6 +273,8 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     }
     const int Dm = h->cfg.embed_dim, Fh = h->cfg.embed_dim * h->cfg.mlp_ratio;
     const bool mlp_fusable = mlp_fused_supported(Dm, Fh, h->planes);
+    const bool mlp3_fusable = mlp_fused3_supported(Dm, Fh, h->planes);
+    if (mlp3_fusable) total += (size_t)h->cfg.n_blocks * align_up((size_t)mlp_fused3_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
     if (mlp_fusable)
         total += (size_t)h->cfg.n_blocks * (align_up((size_t)mlp_fused_pack_elems(Dm, Fh) * sizeof(bf16_t), 256) +
                                             align_up((size_t)mlp_fused_proj_pack_elems(Dm) * sizeof(bf16_t), 256) +
@@ -312,6 +315,12 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     h->packed_mlp.clear();
     h->packed_proj.clear();
     h->packed_qkvf.clear();
+    h->packed_mlp3.clear();
+    if (mlp3_fusable)
+        for (int i = 0; i < h->cfg.n_blocks; ++i) {
+            h->packed_mlp3["dino.blocks." + std::to_string(i) + "."] = reinterpret_cast<bf16_t*>(h->wbuf + off);
+            off += align_up((size_t)mlp_fused3_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
+        }
     if (mlp_fusable)
         for (int i = 0; i < h->cfg.n_blocks; ++i) {
             const std::string b = "dino.blocks." + std::to_string(i) + ".";
@@ -469,7 +478,8 @@ struct MaskRequest {            // forward_mask / get_last_selfattention(x, cls_
 
 // the fused MLP kernel runs for this many token rows (options mlp_fused / mlp_fused_min_rows)
 static bool mlp_fuse_wanted(const dinoseg_handle* h, long rows) {
-    return !h->packed_mlp.empty() && (options().mlp_fused == 2 || (options().mlp_fused == 1 && rows >= options().mlp_fused_min_rows));
+    return (!h->packed_mlp.empty() || !h->packed_mlp3.empty()) &&
+           (options().mlp_fused == 2 || (options().mlp_fused == 1 && rows >= options().mlp_fused_min_rows));
 }
 // fragment-order MLP weights (mlp_fused2.hip), packed on first use after a weight refresh
 static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s) {
@@ -479,6 +489,9 @@ static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s) {
         DSEG_TRY(launch_pack_mlp(W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc2.weight"), Dm, Fh, kv.second, s, h->fmt));
     for (auto& kv : h->packed_proj) DSEG_TRY(launch_pack_proj(W(h, kv.first + "attn.proj.weight"), Dm, kv.second, s, h->fmt));
     for (auto& kv : h->packed_qkvf) DSEG_TRY(launch_pack_qkv(W(h, kv.first + "attn.qkv.weight"), Dm, kv.second, s, h->fmt));
+    for (auto& kv : h->packed_mlp3)
+        DSEG_TRY(launch_pack_mlp3(W(h, kv.first + "attn.proj.weight"), W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc2.weight"), Dm, Fh,
+                                  kv.second, s, h->fmt));
     h->packed_mlp_stale = false;
     return 0;
 }
@@ -639,9 +652,10 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             a.v_bf16 = v_bf16;
             DSEG_PROF(DINOSEG_PROF_ATTN, DSEG_TRY(launch_attention(a, s)));
         }
-        const bool fuse_mlp = h->packed_mlp.count(b) && mlp_fuse_wanted(h, disp_M);
-        // (the role-split fused MLP kernel takes the attention output projection along: x += proj(ctx) + b, then the MLP, one launch)
-        const bool fuse_proj = fuse_mlp && options().proj_fused && P == 1 && h->packed_proj.count(b);
+        const bool fuse_mlp3 = P == 2 && h->packed_mlp3.count(b) && mlp_fuse_wanted(h, disp_M);      // hi + lo planes: mlp_fused3.hip
+        const bool fuse_mlp = fuse_mlp3 || (h->packed_mlp.count(b) && mlp_fuse_wanted(h, disp_M));
+        // (the fused MLP kernels take the attention output projection along: x += proj(ctx) + b, then the MLP, one launch)
+        const bool fuse_proj = fuse_mlp && options().proj_fused && (fuse_mlp3 || (P == 1 && h->packed_proj.count(b)));
         if (!fuse_proj) {
             const PackedLinear& pk = h->packed.at(b + "attn.proj.weight");
             GemmParams g = {};
@@ -652,7 +666,18 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.out_f32 = X; g.ldo_f32 = D;
             DSEG_PROF(DINOSEG_PROF_PROJ, DSEG_TRY(launch_gemm(g, s)));
         }
-        if (fuse_mlp) {
+        if (fuse_mlp3) {
+            DSEG_TRY(ensure_mlp_packs(h, s));
+            // projection + LN2 + fc1 + GELU + fc2 + residual on hi + lo planes in one launch (mlp_fused3.hip)
+            MlpFused3Params g = {};
+            g.X = X; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
+            g.Wp = h->packed_mlp3.at(b); g.b1 = W(h, b + "mlp.fc1.bias"); g.b2 = W(h, b + "mlp.fc2.bias");
+            g.M = L.M; g.fmt = FM;
+            if (fuse_proj) {
+                g.ctx = CTX; g.ctx_plane = L.ctx_plane; g.bproj = W(h, b + "attn.proj.bias");
+            }
+            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_mlp_fused3(g, s)));
+        } else if (fuse_mlp) {
             DSEG_TRY(ensure_mlp_packs(h, s));      // (a split forward has done this before its fork)
             // LN2 + fc1 + GELU + fc2 + residual in one launch: the hidden activation never reaches HBM (mlp_fused2.hip)
             MlpFusedParams g = {};

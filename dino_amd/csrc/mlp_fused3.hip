@@ -181,49 +181,59 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
         const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
         const uint32_t lane16_i = lane_i * 16, lr_i = lane_i & 31, lh_i = lane_i >> 5;
         const uint32_t frag_rd_i = lds_base + lane16_i;
-        const int row = item * BM + wave * 32 + (int)lr_i;
-        const int row_c = row < M ? row : M - 1;
-        float* const xrow = p.X + (long)row_c * D + lh_i * 8;
+        // this lane's row of item `it` (clamped), from a fresh opaque lane id: the row pointers are recomputed where they are used -- kept
+        // alive across the item they are spilled, and a scratch reload in the store gaps waits for every operation in flight
+        auto lane_row = [&](int it) __attribute__((always_inline)) -> long {
+            uint32_t z = 0;
+            asm volatile("" : "+v"(z));
+            const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+            const int r = it * BM + wave * 32 + (int)(l & 31);
+            return (long)(r < M ? r : M - 1) * D + (l >> 5) * 8;
+        };
 
-        // rows of the item: x (+ b_proj) into the accumulators, the ctx planes into the fragment registers
-        auto load_rows = [&](int rc) __attribute__((always_inline)) {
-            const float* xr = p.X + (long)rc * D + lh_i * 8;
-#pragma unroll
-            for (int k = 0; k < NKS; ++k) {
-                f32x4 a = {1.f, 2.f, 3.f, (float)k}, b = a;
-                if (!(MF3_ABL & 32)) {
-                    a = *reinterpret_cast<const f32x4*>(xr + k * 16);
-                    b = *reinterpret_cast<const f32x4*>(xr + k * 16 + 4);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[k >> 1][(k & 1) * 8 + e] = a[e];
-                    o[k >> 1][(k & 1) * 8 + 4 + e] = b[e];
-                }
+        // rows of an item: x into the accumulators (k-step k = two 16-byte loads), the ctx planes into the fragment registers (one load each)
+        auto load_x = [&](const float* xr, auto k_tag) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_tag)::value;
+            f32x4 a = {1.f, 2.f, 3.f, (float)k}, b = a;
+            if (!(MF3_ABL & 32)) {
+                a = *reinterpret_cast<const f32x4*>(xr + k * 16);
+                b = *reinterpret_cast<const f32x4*>(xr + k * 16 + 4);
             }
-            if (has_proj) {
-                const bf16_t* cr = p.ctx + (long)rc * D + lh_i * 8;
 #pragma unroll
-                for (int k = 0; k < NKS; ++k) {
-                    if (MF3_ABL & 32) {
-                        const uint4 u = {0x3c003c00u, 0x3c003c00u, (uint32_t)k, 0u};
-                        xh[k] = __builtin_bit_cast(bf16x8, u);
-                        xl[k] = xh[k];
-                    } else {
-                        xh[k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(cr + k * 16));
-                        xl[k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(cr + p.ctx_plane + k * 16));
-                    }
-                }
+            for (int e = 0; e < 4; ++e) {
+                o[k >> 1][(k & 1) * 8 + e] = a[e];
+                o[k >> 1][(k & 1) * 8 + 4 + e] = b[e];
             }
         };
-        load_rows(row_c);
+        // ctx fragments of projection k-tile kt: four 16-byte loads (i = 2 s2 + plane) into buffer kt % 3 of the (still unused) fragment
+        // registers: xh / xl[2 (kt % 3) + s2]
+        auto load_ctx = [&](const bf16_t* cr, auto kt_tag, auto i_tag) __attribute__((always_inline)) {
+            constexpr int KT = decltype(kt_tag)::value, I = decltype(i_tag)::value, S2 = I >> 1, PL = I & 1, R = 2 * (KT % 3) + S2;
+            uint4 u = {0x3c003c00u, 0x3c003c00u, (uint32_t)KT, 0u};
+            if (!(MF3_ABL & 32)) u = *reinterpret_cast<const uint4*>(cr + (PL ? p.ctx_plane : 0) + (2 * KT + S2) * 16);
+            if constexpr (PL) xl[R] = __builtin_bit_cast(bf16x8, u);
+            else xh[R] = __builtin_bit_cast(bf16x8, u);
+        };
+        const bool has_next = item + (int)gridDim.x < nitems;
+        if (item == (int)blockIdx.x) {      // (later items: loaded in the gaps of the previous item's last two steps)
+            const long ro = lane_row(item);
+            mf_for(std::make_integer_sequence<int, NKS>{}, [&](auto k_tag) __attribute__((always_inline)) { load_x(p.X + ro, k_tag); });
+            if constexpr (has_proj)
+                mf_for(std::make_integer_sequence<int, 8>{}, [&](auto i_tag) __attribute__((always_inline)) {
+                    constexpr int I = decltype(i_tag)::value;
+                    load_ctx(p.ctx + ro, std::integral_constant<int, I / 4>{}, std::integral_constant<int, I % 4>{});
+                });
+        }
 
         // ---- one step: 72 MFMAs on the slot at ring position rpos; pieces of the slot two steps ahead into the position before it
         // mma(pair tag J, product 0 / 1 / 2, fragment): the product; valu(gap tag G): vector work of MFMA gap G (0 .. 71)
-        auto step = [&](auto order_tag, auto&& mma, auto&& valu) __attribute__((always_inline)) {
+        // VM: vector-memory operations known to have been issued AFTER the pieces this step reads (normally the previous step's twelve pieces;
+        // in the first two steps of an item also at least 48 of the row loads the previous item's last steps issued behind their pieces)
+        auto step = [&](auto order_tag, auto vm_tag, auto&& mma, auto&& valu) __attribute__((always_inline)) {
             constexpr int ORDER = decltype(order_tag)::value;      // 0: pair J reads fragment pair J; 1: s2-major (J -> 2 (J % 12) + J / 12)
-            // what this step reads has landed: every wave's pieces of two steps ago (the youngest twelve operations may stay in flight)
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            constexpr int VM = decltype(vm_tag)::value;
+            // what this step reads has landed: every wave's pieces of two steps ago
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
             __builtin_amdgcn_s_barrier();
             uint64_t gsb[3];
             uint32_t gld[3];
@@ -281,31 +291,38 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
 
         // ---- projection: o^T += Wproj . ctx^T, twelve k-tiles
         if (has_proj) {
-            // (+ b_proj: LayerNorm2 sees x + proj(ctx) + b_proj)
-#pragma unroll
-            for (int k = 0; k < NKS; ++k) {
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(sBp + k * 16 + lh_i * 8);
-                const f32x4 c1 = *reinterpret_cast<const f32x4*>(sBp + k * 16 + lh_i * 8 + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[k >> 1][(k & 1) * 8 + e] += c0[e];
-                    o[k >> 1][(k & 1) * 8 + 4 + e] += c1[e];
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (the ctx fragments of k-tile kt + 2 are loaded in the first gaps of step kt; tiles 0 and 1 came with the rows)
+            const bf16_t* const cr = p.ctx + lane_row(item);
             mf_for(std::make_integer_sequence<int, NPT>{}, [&](auto kt_tag) __attribute__((always_inline)) {
                 constexpr int KT = decltype(kt_tag)::value;
-                step(std::integral_constant<int, 0>{},
+                step(std::integral_constant<int, 0>{}, std::integral_constant<int, (KT < 2 ? 60 : 12)>{},
                      [&](auto j_tag, auto w_tag, const bf16x8& fr) __attribute__((always_inline)) {
-                         constexpr int J = decltype(j_tag)::value, W = decltype(w_tag)::value, DB = J >> 1, KS = 2 * KT + (J & 1);
-                         if (!(MF3_ABL & 8)) o[DB] = mfma32f<FMT>(fr, W == 1 ? xl[KS] : xh[KS], o[DB]);
+                         constexpr int J = decltype(j_tag)::value, W = decltype(w_tag)::value, DB = J >> 1, R = 2 * (KT % 3) + (J & 1);
+                         if (!(MF3_ABL & 8)) o[DB] = mfma32f<FMT>(fr, W == 1 ? xl[R] : xh[R], o[DB]);
                      },
-                     no_valu);
+                     [&](auto g_tag) __attribute__((always_inline)) {
+                         constexpr int G = decltype(g_tag)::value;
+                         if constexpr (KT + 2 < NPT && G >= 2 && G <= 8 && (G & 1) == 0)
+                             load_ctx(cr, std::integral_constant<int, KT + 2>{}, std::integral_constant<int, (G - 2) / 2>{});
+                     });
             });
         }
 
         // ---- LayerNorm2 of the rows in o (register 8 s2 + j of block db = feature 32 db + 16 s2 + 8 lh + j) -> xh / xl; b2 joins the residual
         {
+            if constexpr (has_proj) {      // (+ b_proj: LayerNorm2 sees x + proj(ctx) + b_proj)
+#pragma unroll
+                for (int k = 0; k < NKS; ++k) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(sBp + k * 16 + lh_i * 8);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(sBp + k * 16 + lh_i * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[k >> 1][(k & 1) * 8 + e] += c0[e];
+                        o[k >> 1][(k & 1) * 8 + 4 + e] += c1[e];
+                    }
+                }
+            }
             float sum = 0.f;
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
@@ -427,10 +444,10 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         // F1(t): s_nxt = b1(t) + W1(t) . xn^T, with the first 72 gaps of the GELU of s_cur (GELU = false: none)
-        auto step_f1 = [&](f32x16& s_nxt, const f32x16& s_cur, int t, auto gelu_tag) __attribute__((always_inline)) {
+        auto step_f1 = [&](f32x16& s_nxt, const f32x16& s_cur, int t, auto gelu_tag, auto vm_tag) __attribute__((always_inline)) {
             constexpr bool GELU = decltype(gelu_tag)::value;
             s_bias(s_nxt, t);
-            step(std::integral_constant<int, 0>{},
+            step(std::integral_constant<int, 0>{}, vm_tag,
                  [&](auto j_tag, auto w_tag, const bf16x8& fr) __attribute__((always_inline)) {
                      constexpr int J = decltype(j_tag)::value, W = decltype(w_tag)::value;
                      if (!(MF3_ABL & 4)) s_nxt = mfma32f<FMT>(fr, W == 1 ? xl[J] : xh[J], s_nxt);
@@ -439,9 +456,50 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
                      if constexpr (GELU) gelu_gap(g_tag, s_cur);
                  });
         };
-        // F2(t): o^T += W2(t)^T . P^T, products ordered s2 = 0 first, with the last gaps of the GELU of s_cur = S(t)
-        auto step_f2 = [&](const f32x16& s_cur) __attribute__((always_inline)) {
-            step(std::integral_constant<int, 1>{},
+        // F2(t): o^T += W2(t)^T . P^T, products ordered s2 = 0 first, with the last gaps of the GELU of s_cur = S(t).
+        // TAIL 2 (F2(47)): the next item's ctx fragments of projection k-tiles 0 and 1 into the fragment registers (dead since F1(47)); block db of the accumulators is final after product 12 + db: its rows are stored and the next item's rows loaded in
+        // the gaps behind it (boundary operation b = 3 db + {0, 1: two stores each; 2: four loads} at gap 39 + b; those past gap 71 follow the step)
+        float* xrow = nullptr;            // set by the steps that use them (lane_row)
+        const float* nxr = nullptr;
+        const bf16_t* ncr = nullptr;
+        auto boundary_op = [&](auto b_tag) __attribute__((always_inline)) {
+            constexpr int B_ = decltype(b_tag)::value, DB = B_ / 3, W = B_ % 3;
+            if (MF3_ABL & 32) {
+                if constexpr (W == 2) asm volatile("" ::"v"(o[DB]));
+                if constexpr (W == 2) {
+                    if (has_next) {
+                        load_x(nxr, std::integral_constant<int, 2 * DB>{});
+                        load_x(nxr, std::integral_constant<int, 2 * DB + 1>{});
+                    }
+                }
+                return;
+            }
+            if constexpr (W < 2) {
+                // (no row guard: a lane past the last row works on a copy of row M - 1 -- the clamped loads -- and every output column of
+                // an MFMA is computed alike, so it stores the same bits to the same place as that row's own lane)
+                constexpr int k = 2 * DB + W;
+                f32x4 a, b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = o[DB][W * 8 + e];
+                    b[e] = o[DB][W * 8 + 4 + e];
+                }
+                *reinterpret_cast<f32x4*>(xrow + k * 16) = a;
+                *reinterpret_cast<f32x4*>(xrow + k * 16 + 4) = b;
+            } else if (has_next) {
+                load_x(nxr, std::integral_constant<int, 2 * DB>{});
+                load_x(nxr, std::integral_constant<int, 2 * DB + 1>{});
+            }
+        };
+        auto step_f2 = [&](const f32x16& s_cur, auto tail_tag) __attribute__((always_inline)) {
+            constexpr int TAIL = decltype(tail_tag)::value;
+            if constexpr (TAIL == 2) {
+                xrow = p.X + lane_row(item);
+                const long nro = lane_row(item + (int)gridDim.x);
+                nxr = p.X + nro;
+                if constexpr (has_proj) ncr = p.ctx + nro;
+            }
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 12>{},
                  [&](auto j_tag, auto w_tag, const bf16x8& fr) __attribute__((always_inline)) {
                      constexpr int J = decltype(j_tag)::value, W = decltype(w_tag)::value, DB = J % 12, S2 = J / 12;
                      const uint4 uh = {pdh[4 * S2], pdh[4 * S2 + 1], pdh[4 * S2 + 2], pdh[4 * S2 + 3]};
@@ -452,45 +510,40 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
                  [&](auto g_tag) __attribute__((always_inline)) {
                      constexpr int G = decltype(g_tag)::value;
                      if constexpr (72 + G <= GELU_END) gelu_gap(std::integral_constant<int, 72 + G>{}, s_cur);
+                     if constexpr (TAIL == 2 && has_proj && G >= 24 && G < 32) {
+                         if (has_next) load_ctx(ncr, std::integral_constant<int, (G - 24) / 4>{}, std::integral_constant<int, (G - 24) % 4>{});
+                     }
+                     if constexpr (TAIL == 2 && G >= 39) boundary_op(std::integral_constant<int, G - 39>{});
                  });
+            if constexpr (TAIL == 2)
+                mf_for(std::make_integer_sequence<int, 3 * NDB - (72 - 39)>{}, [&](auto i_tag) __attribute__((always_inline)) {
+                    boundary_op(std::integral_constant<int, 72 - 39 + decltype(i_tag)::value>{});
+                });
         };
 
-        step_f1(S0, S0, 0, std::false_type{});
+        using VM12 = std::integral_constant<int, 12>;
+        using VMB = std::integral_constant<int, has_proj ? 12 : 60>;      // (no projection: F1(0), F1(1) are the item's first two steps)
+        using T0 = std::integral_constant<int, 0>;
+        step_f1(S0, S0, 0, std::false_type{}, VMB{});
+        step_f1(S1, S0, 1, std::true_type{}, VMB{});           // F1(1) + GELU(0)
+        step_f2(S0, T0{});                                     // F2(0)
+        step_f1(S0, S1, 2, std::true_type{}, VM12{});          // F1(2) + GELU(1)
+        step_f2(S1, T0{});                                     // F2(1)
 #pragma unroll 1
-        for (int t = 0; t < NT - 2; t += 2) {
-            step_f1(S1, S0, t + 1, std::true_type{});      // F1(t + 1) + GELU(t)
-            step_f2(S0);                                   // F2(t)
-            step_f1(S0, S1, t + 2, std::true_type{});      // F1(t + 2) + GELU(t + 1)
-            step_f2(S1);                                   // F2(t + 1)
+        for (int t = 2; t < NT - 2; t += 2) {
+            step_f1(S1, S0, t + 1, std::true_type{}, VM12{});  // F1(t + 1) + GELU(t)
+            step_f2(S0, T0{});                                 // F2(t)
+            step_f1(S0, S1, t + 2, std::true_type{}, VM12{});  // F1(t + 2) + GELU(t + 1)
+            step_f2(S1, T0{});                                 // F2(t + 1)
         }
-        step_f1(S1, S0, NT - 1, std::true_type{});         // F1(47) + GELU(46)
-        step_f2(S0);                                       // F2(46)
+        step_f1(S1, S0, NT - 1, std::true_type{}, VM12{});     // F1(47) + GELU(46)
+        step_f2(S0, T0{});                                     // F2(46)
         // GELU(47): its first 72 gaps have no step to ride in
         mf_for(std::make_integer_sequence<int, 72>{}, [&](auto g_tag) __attribute__((always_inline)) {
             __builtin_amdgcn_sched_barrier(0);
             gelu_gap(g_tag, S1);
         });
-        step_f2(S1);                                       // F2(47)
-
-        // ---- epilogue: the rows back to the residual stream; the next item's rows into the registers
-        if (!(MF3_ABL & 32)) {
-            if (row < M) {
-#pragma unroll
-                for (int k = 0; k < NKS; ++k) {
-                    f32x4 a, b;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a[e] = o[k >> 1][(k & 1) * 8 + e];
-                        b[e] = o[k >> 1][(k & 1) * 8 + 4 + e];
-                    }
-                    *reinterpret_cast<f32x4*>(xrow + k * 16) = a;
-                    *reinterpret_cast<f32x4*>(xrow + k * 16 + 4) = b;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int db = 0; db < NDB; ++db) asm volatile("" ::"v"(o[db]));
-        }
+        step_f2(S1, std::integral_constant<int, 2>{});         // F2(47): the rows out, the next item's rows in
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring pieces issued past the last item's end
 }
