@@ -595,18 +595,29 @@ def main():
         # (kernels.h Options::attn_variant: from four rounds of workgroups on, bit 10 = the assembly tile loop, bit 16 = 64 queries per wave)
         av = next((int(kv.split("=")[1]) for kv in a.option if kv.startswith("attn_variant=")), 11 | 1024 | 65536)
         fmt_note = "; fp16 Q.K^T, bf16 P.V" if a.precision == "fp16" else ""
+        f16 = 1 if a.precision in ("fp16", "fp16x3") else 0
+        ncu_ = torch.cuda.get_device_properties(dev).multi_processor_count
         if nw == 8 and (av & 1024) and not (av & 64):
-            z_symbol = (f"dseg::attn_fwd_za_kernel<{1 if a.precision == 'fp16' else 0}, {2 if av & 65536 else 1}, 0> (attention_za.hip: fused "
+            z_symbol = (f"dseg::attn_fwd_za_kernel<{f16}, {2 if av & 65536 else 1}, 0, false> (attention_za.hip: fused "
                         f"QK^T-softmax-PV, head_dim 64, zero-reference softmax, tile loop = generated assembly pipeline, "
                         f"{64 if av & 65536 else 32} queries per wave{fmt_note})")
         else:
-            z_symbol = (f"dseg::attn_fwd_z_kernel<1, 4, {nw}, {1 if a.precision == 'fp16' else 0}> (attention_z.hip: fused QK^T-softmax-PV, "
+            z_symbol = (f"dseg::attn_fwd_z_kernel<1, 4, {nw}, {f16}> (attention_z.hip: fused QK^T-softmax-PV, "
                         f"head_dim 64, zero-reference softmax{fmt_note})")
-        attn_symbol = (z_symbol if a.precision in ("bf16", "fp16") else
-                       f"dseg::attn_fwd_kernel<2, 4, false, 3, {1 if a.precision == 'fp16x3' else 0}> (attention.hip: fused QK^T-softmax-PV, "
-                       f"head_dim 64, hi+lo planes)")
+        # hi + lo planes (attention_z.hip: attention_x3_za): from two rounds of 256-query workgroups on, the assembly body with three
+        # MFMAs per product (attention_za.hip, X3); below that the reference-based kernel of attention.hip
+        wgs256 = (a.batch * heads_ + 7) // 8 * 8 * (((a.res // 8) ** 2 + 1 + 255) // 256)
+        if (av & 1024) and not (av & 64) and ((av & 2048) or wgs256 >= 2 * ncu_):
+            x3_symbol = (f"dseg::attn_fwd_za_kernel<{f16}, 1, 0, true> (attention_za.hip: fused QK^T-softmax-PV, head_dim 64, hi+lo planes = "
+                         f"three MFMAs per product, zero-reference softmax, tile loop = generated assembly pipeline"
+                         f"{'; Q / K / ctx fp16 hi+lo, P and V bf16 hi+lo' if f16 else ''})")
+        else:
+            x3_symbol = (f"dseg::attn_fwd_kernel<2, 4, false, 3, {f16}> (attention.hip: fused QK^T-softmax-PV, head_dim 64, hi+lo planes)")
+        attn_symbol = z_symbol if a.precision in ("bf16", "fp16") else x3_symbol
+        metric_text = (f"frames/sec ({a.res}x{a.res}, ViT-{'S' if a.arch == 'vit_small' else 'B'}/8"
+                       f"{'' if a.blocks == 12 else f' x{a.blocks} blocks'}) DINOSeg inference")
         out = {
-            "metric": "frames/sec (480x480, ViT-S/8) DINOSeg inference",
+            "metric": metric_text,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE[a.precision],
@@ -683,7 +694,11 @@ def main():
             out["bf16_mode"] = sub_mode("bf16")[0]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, a.res)
-        if world == 1 and not a.no_configs and a.config in (None, "headline") and a.arch == "vit_small" and a.res == 480 and a.batch == 32:
+        # (never under a profiler: the children would inherit its preload, write into the same output names and mix their kernels
+        #  into the statistics this line's roofline is read from -- ADVICE r5)
+        profiled = bool(os.environ.get("ROCP_TOOL_LIBRARIES")) or "rocprofiler" in os.environ.get("LD_PRELOAD", "") \
+            or bool(os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD")) or bool(os.environ.get("ROCPROF_OUTPUT_PATH"))
+        if world == 1 and not a.no_configs and not profiled and a.config in (None, "headline") and a.arch == "vit_small" and a.res == 480 and a.batch == 32:
             del model
             torch.cuda.empty_cache()
             out["configs"] = other_configs(a)

@@ -52,7 +52,6 @@ static void add_expected(dinoseg_handle* h) {
     e["dino.pos_embed"] = {1, (int64_t)c.pos_grid * c.pos_grid + 1, D};
     e["dino.patch_embed.proj.weight"] = {D, 3, p, p};
     e["dino.patch_embed.proj.bias"] = {D};
-    bool qkv_ready = false;      // Q / K / V of block i were written by block i-1's fused launch (mlp_fused2.hip, QKV tail)
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
         e[b + "norm1.weight"] = {D};
@@ -228,7 +227,6 @@ static std::vector<LinSpec> linear_specs(const dinoseg_handle* h) {
     std::vector<LinSpec> v;
     // (fp16 mode: the patch embedding runs split like the head -- 0.13 % of the FLOPs, and its operands are raw pixels)
     v.push_back({"dino.patch_embed.proj.weight", "dino.patch_embed.proj.bias", D, 3 * c.patch * c.patch, D, 192, patch_planes(h), patch_fmt(h)});
-    bool qkv_ready = false;      // Q / K / V of block i were written by block i-1's fused launch (mlp_fused2.hip, QKV tail)
     for (int i = 0; i < c.n_blocks; ++i) {
         const std::string b = "dino.blocks." + std::to_string(i) + ".";
         v.push_back({b + "attn.qkv.weight", b + "attn.qkv.bias", 3 * D, D, 3 * D, D, P, FM});

@@ -220,7 +220,13 @@ int launch_gemm_tn(const TnParams& p0, hipStream_t s) {
     TnParams p = p0;
     p.det = nullptr;
     p.det_ld = ((p.N + BN - 1) / BN) * BN;
-    if (p.colsum && det_scratch().ptr && (size_t)p.ksplit * p.det_ld <= det_scratch().tn_floats) p.det = det_scratch().tn[p.det_region ? 1 : 0];
+    if (p.colsum && det_scratch().ptr) {
+        if ((size_t)p.ksplit * p.det_ld > det_scratch().tn_floats) {      // (never a silent fall-back to atomics in the deterministic mode)
+            dinoseg_set_error("gemm_tn: deterministic scratch too small (%d slices x %d columns)", p.ksplit, p.det_ld);
+            return -1;
+        }
+        p.det = det_scratch().tn[p.det_region ? 1 : 0];
+    }
     if (p.M < 1 || p.N < 1 || p.Kc % BKc != 0 || p.ksplit < 1 || (p.planes != 1 && p.planes != 2) || p.ldy % 8 != 0 || p.ldx % 8 != 0) {
         dinoseg_set_error("gemm_tn: bad shape M=%d N=%d Kc=%d ksplit=%d planes=%d", p.M, p.N, p.Kc, p.ksplit, p.planes);
         return -1;

@@ -236,7 +236,9 @@ int launch_attention_bwd(const AttnBwdParams& p, hipStream_t s);
 
 int launch_transpose_planes(const float* src_f32, const bf16_t* src_pl, long src_plane, int ld_src, int M, int C,
                             bf16_t* T, long t_plane, int c_pad, int m_pad, bf16_t* Nout, long n_plane, int ldn,
-                            float* colsum, int planes, int drop_cls, int ntok, hipStream_t s);
+                            float* colsum, int planes, int drop_cls, int ntok, hipStream_t s, int det_region = 0);
+                            // det_region (deterministic mode, colsum given): 0 = the caller's stream, 1 = the weight-gradient side stream,
+                            // whose partial sums go to its own part of the scratch (as TnParams::det_region)
 // labels != null: F.nll_loss (mean over rows whose label is not -100) + d logits; labels == null: d logits from the caller's dlogp
 int launch_nll_loss_grad(const float* logp, const int64_t* labels, const float* dlogp, int M, int C, float* acc, int* flags,
                          float* loss, bf16_t* dz, long dz_plane, int ldz, hipStream_t s);

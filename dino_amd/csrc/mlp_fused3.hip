@@ -179,7 +179,7 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
         uint32_t zero = 0;
         asm volatile("" : "+v"(zero));
         const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
-        const uint32_t lane16_i = lane_i * 16, lr_i = lane_i & 31, lh_i = lane_i >> 5;
+        const uint32_t lane16_i = lane_i * 16, lh_i = lane_i >> 5;
         const uint32_t frag_rd_i = lds_base + lane16_i;
         // this lane's row of item `it` (clamped), from a fresh opaque lane id: the row pointers are recomputed where they are used -- kept
         // alive across the item they are spilled, and a scratch reload in the store gaps waits for every operation in flight
@@ -287,7 +287,6 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
                 gap(std::integral_constant<int, 3 * J + 2>{});
             });
         };
-        auto no_valu = [](auto) __attribute__((always_inline)) {};
 
         // ---- projection: o^T += Wproj . ctx^T, twelve k-tiles
         if (has_proj) {

@@ -84,18 +84,20 @@ __global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __re
 
 int launch_transpose_planes(const float* src_f32, const bf16_t* src_pl, long src_plane, int ld_src, int M, int C,
                             bf16_t* T, long t_plane, int c_pad, int m_pad, bf16_t* Nout, long n_plane, int ldn,
-                            float* colsum, int planes, int drop_cls, int ntok, hipStream_t s) {
+                            float* colsum, int planes, int drop_cls, int ntok, hipStream_t s, int det_region) {
     if (m_pad % 64 != 0 || c_pad % 64 != 0 || m_pad < M || c_pad < C) {
         dinoseg_set_error("transpose_planes: bad padding (M=%d C=%d m_pad=%d c_pad=%d)", M, C, m_pad, c_pad);
         return -1;
     }
     float* det = nullptr;
     if (colsum && det_scratch().ptr) {
-        if ((size_t)(m_pad / 64) * C > det_scratch().floats) {
-            dinoseg_set_error("transpose_planes: deterministic scratch too small");
+        // (a launch on the weight-gradient side stream must not share the caller's stream's region: both streams run at once)
+        const size_t cap = det_region ? det_scratch().tn_floats : det_scratch().floats;
+        if ((size_t)(m_pad / 64) * C > cap) {
+            dinoseg_set_error("transpose_planes: deterministic scratch too small (%d x %d partial sums)", m_pad / 64, C);
             return -1;
         }
-        det = det_scratch().ptr;
+        det = det_region ? det_scratch().tn[1] : det_scratch().ptr;
     }
     hipLaunchKernelGGL(transpose_planes_kernel, dim3(m_pad / 64, c_pad / 64), dim3(256), 0, s, src_f32, src_pl, src_plane,
                        ld_src, M, C, T, t_plane, m_pad, Nout, n_plane, ldn, colsum, planes, drop_cls, ntok, det);
@@ -224,7 +226,10 @@ int launch_nll_loss_grad(const float* logp, const int64_t* labels, const float* 
         DSEG_CHECK_HIP(hipMemsetAsync(acc, 0, 2 * sizeof(float), s));
         float* det = det_scratch().ptr;
         const int nb = (M + 255) / 256;
-        if (det && (size_t)nb * 2 > det_scratch().floats) det = nullptr;
+        if (det && (size_t)nb * 2 > det_scratch().floats) {      // (one policy for every launcher: never a silent fall-back to atomics)
+            dinoseg_set_error("nll_loss: deterministic scratch too small (%d blocks)", nb);
+            return -1;
+        }
         hipLaunchKernelGGL(nll_reduce_kernel, dim3(nb), dim3(256), 0, s, logp, labels, M, C, acc, flags, det);
         if (det) DSEG_TRY_RC(launch_det_finalize(det, nb, 2, 2, acc, s));
     }
@@ -503,7 +508,10 @@ int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, fl
         return -1;
     }
     float* det = det_scratch().ptr;
-    if (det && (size_t)1024 * 3 * D > det_scratch().floats) det = nullptr;
+    if (det && (size_t)1024 * 3 * D > det_scratch().floats) {
+        dinoseg_set_error("layernorm_bwd: deterministic scratch too small (D=%d)", D);
+        return -1;
+    }
     auto finalize = [&](int blocks) -> int {
         if (!det) return 0;
         if (dgamma) DSEG_TRY_RC(launch_det_finalize(det, blocks, D, 3 * D, dgamma, s));

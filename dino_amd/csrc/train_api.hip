@@ -484,11 +484,20 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
     }
     // option deterministic: the launchers below write per-block partial sums here and add them in a fixed order (train.hip,
     // gemm_tn.hip) instead of fp32 atomics; cleared on every way out
+    // The scratch pointer is process-wide state read by the launchers: a second backward entered while it is set (another host thread
+    // stepping another handle) would write its partial sums into THIS handle's workspace -- refused instead.
     struct DetGuard {
-        ~DetGuard() { det_scratch() = DetScratch{nullptr, 0, {nullptr, nullptr}, 0}; }
+        bool mine = false;
+        ~DetGuard() { if (mine) det_scratch() = DetScratch{nullptr, 0, {nullptr, nullptr}, 0}; }
     } det_guard;
-    if (options().deterministic)
+    if (options().deterministic) {
+        if (det_scratch().ptr != nullptr) {
+            dinoseg_set_error("dinoseg_backward: option deterministic allows one backward at a time per process (another one is being queued)");
+            return -1;
+        }
         det_scratch() = DetScratch{F32(L.DET), DET_FLOATS, {F32(L.DET) + DET_FLOATS, F32(L.DET) + DET_FLOATS + DET_TN_FLOATS}, DET_TN_FLOATS};
+        det_guard.mine = true;
+    }
     const hipStream_t main_stream = s;
     float* Xfin = F32(L.Xfin);
     bf16_t *FEAT = B16(L.FEAT), *H1 = B16(L.H1), *H2 = B16(L.H2), *DZ = B16(L.DZ);
@@ -619,7 +628,7 @@ static int train_backward_impl(dinoseg_handle* h, const int64_t* labels, const f
         }
         if (dbias && (!dW || k_cols % 128 != 0))
             DSEG_TRY(launch_transpose_planes(nullptr, Y, y_plane, ldy, m_rows, n_rows, nullptr, 0, pad128(n_rows), L.Mpad, nullptr, 0, 0,
-                                             dbias, planes, 0, 0, s));
+                                             dbias, planes, 0, 0, s, s != main_stream));
         if (!dW) return 0;
         if (k_cols % 128 != 0) {        // narrow layers (embed_dim not a multiple of 128): transposed operands + the NT kernel
             bf16_t* T1f = B16(L.T1);

@@ -683,6 +683,8 @@ class DINOSeg(nn.Module):
     def stream_wait_grad_stage(self, stage: int, stream) -> None:
         """Make `stream` (a torch.cuda.Stream on the model's device) wait for backward stage `stage` of the last step."""
         self._use(True)
+        if self._handle is None:      # (precision 'auto' before any training step: no backward has recorded a stage yet -- nothing to wait for)
+            return
         capi.check(capi.lib().dinoseg_stream_wait_grad_stage(self._handle, int(stage), stream.cuda_stream))
 
     def _sync_grads(self, slot: str = "grad") -> dict:

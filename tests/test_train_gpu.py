@@ -560,3 +560,40 @@ def test_deterministic_option_makes_the_fine_tune_step_bit_reproducible(cuda, pr
     for n in g1:
         den = float(g1[n].abs().max()) + 1e-12
         assert float((ga[n] - g1[n]).abs().max()) <= 2e-5 * den + 1e-9, n
+
+
+def test_deterministic_bias_only_layers_on_the_side_stream(cuda):
+    """ADVICE r5 (train_api.hip: wgrad_tn): a Linear whose weight is frozen but whose bias trains gets its bias gradient from a column-sum
+    pass (transpose_planes) that may be queued on the weight-gradient SIDE stream; in the deterministic mode its partial sums now go to
+    that stream's own region of the scratch, not into the region the caller's stream is using at the same moment (LayerNorm backward,
+    det_finalize).  Every Linear weight of the backbone frozen, biases and norms trainable: two runs bit-identical, and equal to the
+    atomic default up to the summation order."""
+    import dino_amd
+    from dino_amd.weights import synthetic_labels
+    cfg = ViTConfig(n_blocks=3)
+    fr = torch.from_numpy(synthetic_frames(4, 240, seed=15)).cuda()
+    lb = torch.from_numpy(synthetic_labels(4, 900, cfg.n_classes, seed=16)).cuda()
+
+    def run():
+        m = build(cfg, "bf16x3")[0]
+        m.set_resolution(240)
+        m.unfreeze_bb()
+        for n, p in m.named_parameters():
+            if n.startswith("dino.blocks.") and n.endswith(".weight") and p.dim() == 2:
+                p.requires_grad_(False)
+        out = m.fused_training_step((fr, lb), 0)
+        return out["loss"].clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    dino_amd.set_option("deterministic", 1)
+    try:
+        l1, g1 = run()
+        l2, g2 = run()
+    finally:
+        dino_amd.set_option("deterministic", 0)
+    assert torch.equal(l1, l2)
+    assert any(n.endswith("attn.qkv.bias") for n in g1) and not any(n.endswith("attn.qkv.weight") for n in g1)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), f"gradient of {n} differs between two deterministic runs"
+    _, ga = run()
+    for n in g1:
+        den = float(g1[n].abs().max()) + 1e-12
+        assert float((ga[n] - g1[n]).abs().max()) <= 2e-5 * den + 1e-9, n

@@ -26,10 +26,10 @@ export TMPDIR=/tmp
 cd /tmp
 for cfg in "960:--config 960 --steps 3 --warmup 1" "vitb:--config vitb --steps 4 --warmup 1" "finetune:--config finetune --steps 4 --warmup 2" "parity:--config parity --steps 3 --warmup 1"; do
   name=${cfg%%:*}; args=${cfg#*:}
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -o b -- python3 $ROOT/bench.py $args --no-cpu-baseline --no-parity-mode --streams 1 > $OUT/trace_$name.log 2>&1 || tail -3 $OUT/trace_$name.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -o b -- python3 $ROOT/bench.py $args --no-cpu-baseline --no-parity-mode --no-configs --streams 1 > $OUT/trace_$name.log 2>&1 || tail -3 $OUT/trace_$name.log
   find $OUT/trace_$name -name "*kernel_trace.csv" -delete
 done
 cd $ROOT
 bash tools/profile_bench.sh $TAG | tail -3
-bash tools/pmc_cmd.sh clk_$TAG "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --streams 1 > $OUT/clock_kernels.txt 2>&1; grep "dseg::" $OUT/clock_kernels.txt | cut -c1-220
+bash tools/pmc_cmd.sh clk_$TAG "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-configs --streams 1 > $OUT/clock_kernels.txt 2>&1; grep "dseg::" $OUT/clock_kernels.txt | cut -c1-220
 du -sh $OUT $ROOT/gpurun_out/prof_$TAG

@@ -103,7 +103,7 @@ def main():
 
     with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
         f.write(f"# rocprofv3 summary `{tag}`\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 "
-                f"--no-cpu-baseline --no-parity-mode --streams 1` (tools/profile_bench.sh), MI355X, one GPU.  (`--streams 1`: the default "
+                f"--no-cpu-baseline --no-parity-mode --no-configs --streams 1` (tools/profile_bench.sh), MI355X, one GPU.  (`--streams 1`: the default "
                 f"line times two half-batches on two streams, whose launches overlap; here every launch has the chip to itself, like "
                 f"the untimed roofline pass of the default line, so that the per-kernel averages below are those the roofline leg quotes.)\n\n")
         if bench_line:
