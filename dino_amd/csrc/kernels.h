@@ -115,12 +115,17 @@ struct MlpFused3Params {
     const bf16_t* ctx; long ctx_plane;          // attention output planes [2][M][384] (hi, then lo at + ctx_plane elements); null = MLP only
     const float* bproj;
     int fmt;                                    // operand format of ctx, the packed weights and everything in between (FMT_BF16 / FMT_FP16)
-    // optional: LayerNorm1 of the NEXT block on the finished rows, written as operand planes [2][M][384] (what launch_layernorm would write)
-    bf16_t* a_out; long a_plane; const float* gamma1; const float* beta1;
+    // optional (with ctx; q != null): LayerNorm1 + the qkv projection of the NEXT block at the end of the same launch -- Wp then carries the 36
+    // slots of that block's Wqkv behind the 108 of this one (launch_pack_mlp3 with Wqkv_next); Q pre-scaled by qscale
+    const float* bqkv; const float* gamma1; const float* beta1;
+    bf16_t* q; bf16_t* k; bf16_t* v; long qkv_plane;      // each [2][B, heads, npad, 64] (lo plane at + qkv_plane elements; rows >= ntok never written)
+    int ntok, npad, heads; float qscale;
+    int v_bf16;                                 // fmt == FMT_FP16: V as bf16 hi + lo planes (GemmParams::v_bf16)
 };
 bool mlp_fused3_supported(int D, int F, int planes);
-long mlp_fused3_pack_elems(int D, int F);       // 16-bit elements of the packed copy (0: unsupported shape)
-int launch_pack_mlp3(const float* Wproj, const float* W1, const float* W2, int D, int F, bf16_t* dst, hipStream_t s, int fmt);
+long mlp_fused3_pack_elems(int D, int F);       // 16-bit elements of the packed copy, qkv tail slots included (0: unsupported shape)
+int launch_pack_mlp3(const float* Wproj, const float* W1, const float* W2, const float* Wqkv_next /* nullable */, int D, int F, bf16_t* dst,
+                     hipStream_t s, int fmt);
 int launch_mlp_fused3(const MlpFused3Params& p, hipStream_t s);
 
 // tuning knobs (dinoseg_set_option): see api.hip
@@ -136,6 +141,7 @@ struct Options {
     int mlp_grid = 0;        // workgroups of the fused MLP launch (0 = the fewest that need no extra round: mlp_fused2.hip)
     int qkv_fused = 0;       // 1: ... and LayerNorm1 + qkv of the NEXT block at its end (blocks 1.. then have no LN+qkv launch); measured
                              // +1 % on one stream, +-0 on two: the tail is bound by the same HBM write burst as the launch it replaces
+    int qkv_fused3 = 1;      // hi + lo planes (mlp_fused3.hip): 1 = LayerNorm1 + qkv of the NEXT block at the end of the fused projection + MLP launch
     int proj_fused = 1;      // 1: the block's attention output projection runs inside the fused MLP launch
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 8;       // (8 frames @480: +6 %, 12: +16 %, 16: +12 %; 6 frames and fewer: slower split)

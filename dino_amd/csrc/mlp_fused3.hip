@@ -29,6 +29,12 @@
 // across the items of the persistent walk.
 // Item boundary: the rows are stored from the accumulators and the next item's x / ctx rows are loaded into the registers that have just
 // become free.
+//
+// QKV = true: LayerNorm1 + the qkv projection of the NEXT block run at the end of the same launch (vision_transformer.py:122 -> :75): the
+// finished rows are normalised from the accumulators into the fragment registers like LayerNorm2, then 36 more steps of the fc1 kind
+// (slot = 32 rows of the next block's Wqkv: Q tiles 0 .. 11, K 12 .. 23, V 24 .. 35) follow; tile q's 32 x 32 block is scaled (Q: 64^-0.5 log2 e),
+// split into hi + lo planes and stored to Q / K / V [B, heads, npad, 64] in the gaps of step q + 1.  The next block then has no
+// LayerNorm launch, no qkv GEMM launch, and the normalised planes never exist in HBM.
 #include <stdio.h>
 
 #include "mlp_common.h"
@@ -42,10 +48,10 @@ constexpr int SLOT = 2 * W_TILE;                    // 48 KiB: 24 pairs of (lo, 
 constexpr int NPT = D / 32;                         // projection k-tiles
 constexpr int NSLOT = NPT + 2 * NT;                 // slots per item (108)
 constexpr int RING = 3;
+constexpr int NQT = 3 * D / 32;                     // QKV tail: output tiles of 32 features (36)
 constexpr int B1_OFF = RING * SLOT;                 // b1 [F] fp32
-constexpr int BP_OFF = B1_OFF + F * 4;              // b_proj, b2, gamma, beta [D] fp32 each
-constexpr int B2_OFF = BP_OFF + D * 4, G_OFF = B2_OFF + D * 4, BE_OFF = G_OFF + D * 4;
-constexpr int LDS_BYTES = BE_OFF + D * 4;
+constexpr int BQ_OFF = B1_OFF + F * 4;              // QKV tail: the next block's qkv bias [1152] fp32
+constexpr int LDS_BYTES = BQ_OFF + 3 * D * 4;       // (the LayerNorm constants and the two residual biases are read from global memory: twice per item)
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr int PIECES = SLOT / 1024 / NW;            // LDS-DMA pieces per wave and step
 static_assert(PIECES == 12, "three groups of four pieces");
@@ -62,8 +68,9 @@ constexpr int LO = 0, HI = 1024;                    // byte offset of a pair's l
 #endif
 
 // stream slot n (0 .. 107) of a block's packed weights -> which matrix tile it holds
-__host__ __device__ inline void mf3_slot_kind(int n, int& kind, int& t) {      // kind 0 proj (t = k-tile), 1 fc1, 2 fc2 (t = hidden tile)
+__host__ __device__ inline void mf3_slot_kind(int n, int& kind, int& t) {      // kind 0 proj (t = k-tile), 1 fc1, 2 fc2 (t = hidden tile), 3 qkv (t = tile)
     using namespace mf3;
+    if (n >= NSLOT) { kind = 3; t = n - NSLOT; return; }
     if (n < NPT) { kind = 0; t = n; return; }
     const int m = n - NPT;
     if (m == 0) { kind = 1; t = 0; }
@@ -72,11 +79,12 @@ __host__ __device__ inline void mf3_slot_kind(int n, int& kind, int& t) {      /
     else { kind = 2; t = (m - 2) >> 1; }
 }
 
+#if !defined(MF3_PART) || MF3_PART == 0
 // Wproj [384][384], W1 [1536][384], W2 [384][1536] fp32 -> [slot][pair][lo, hi][64 lanes][8] in the operand format
 __global__ __launch_bounds__(256) void pack_mlp3_kernel(const float* __restrict__ Wpr, const float* __restrict__ W1, const float* __restrict__ W2,
-                                                        bf16_t* __restrict__ dst, int fmt) {
+                                                        const float* __restrict__ Wqkv, bf16_t* __restrict__ dst, int fmt) {
     using namespace mf3;
-    const long total = (long)NSLOT * NKS * 512;      // (slot, pair, lane, e) tuples; each writes a lo and a hi element
+    const long total = (long)(NSLOT + (Wqkv ? NQT : 0)) * NKS * 512;      // (slot, pair, lane, e) tuples; each writes a lo and a hi element
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         long q = idx;
         const int e = (int)(q & 7); q >>= 3;
@@ -87,8 +95,8 @@ __global__ __launch_bounds__(256) void pack_mlp3_kernel(const float* __restrict_
         int kind, t;
         mf3_slot_kind(slot, kind, t);
         float v;
-        if (kind == 1) {      // fc1: A row = hidden unit, k = input feature, pair = k-step
-            v = W1[(long)(t * HT + i) * D + pair * 16 + h * 8 + e];
+        if (kind == 1 || kind == 3) {      // fc1 / qkv: A row = hidden unit / output feature, k = input feature, pair = k-step
+            v = (kind == 1 ? W1 : Wqkv)[(long)(t * HT + i) * D + pair * 16 + h * 8 + e];
         } else {              // proj / fc2: A row = output feature, k = the tile's 32 inputs, pair = (db, s2)
             const int db = pair >> 1, s2 = pair & 1;
             v = kind == 0 ? Wpr[(long)(db * 32 + i) * D + t * 32 + s2 * 16 + h * 8 + e] : W2[(long)(db * 32 + i) * F + t * HT + s2 * 16 + h * 8 + e];
@@ -101,21 +109,25 @@ __global__ __launch_bounds__(256) void pack_mlp3_kernel(const float* __restrict_
     }
 }
 
-long mlp_fused3_pack_elems(int Dm, int Fh) { return Dm == mf3::D && Fh == mf3::F ? (long)mf3::NSLOT * mf3::SLOT / 2 : 0; }
+long mlp_fused3_pack_elems(int Dm, int Fh) { return Dm == mf3::D && Fh == mf3::F ? (long)(mf3::NSLOT + mf3::NQT) * mf3::SLOT / 2 : 0; }
 bool mlp_fused3_supported(int Dm, int Fh, int planes) { return Dm == mf3::D && Fh == mf3::F && planes == 2; }
 
-int launch_pack_mlp3(const float* Wproj, const float* W1, const float* W2, int Dm, int Fh, bf16_t* dst, hipStream_t s, int fmt) {
+int launch_pack_mlp3(const float* Wproj, const float* W1, const float* W2, const float* Wqkv_next, int Dm, int Fh, bf16_t* dst, hipStream_t s,
+                     int fmt) {
     if (mlp_fused3_pack_elems(Dm, Fh) <= 0 || !Wproj || !W1 || !W2 || !dst) {
         dinoseg_set_error("pack_mlp3: null pointer or unsupported shape D=%d F=%d", Dm, Fh);
         return -1;
     }
-    hipLaunchKernelGGL(pack_mlp3_kernel, dim3(2048), dim3(256), 0, s, Wproj, W1, W2, dst, fmt);
+    hipLaunchKernelGGL(pack_mlp3_kernel, dim3(2048), dim3(256), 0, s, Wproj, W1, W2, Wqkv_next, dst, fmt);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-template <int FMT, bool PROJ>
+#endif
+
+template <int FMT, bool PROJ, bool QKV, bool VBF>
 __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Params p) {
+    static_assert(PROJ || !QKV, "the qkv tail comes with the projection build");
     using namespace mf3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -125,33 +137,25 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
     if ((int)blockIdx.x >= nitems) return;
     constexpr bool has_proj = PROJ;
 
-    // ---- constants into LDS: b1, b_proj, b2, gamma, beta
+    // ---- constants into LDS: b1 (and the next block's qkv bias)
     for (int i = tid; i < F / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + B1_OFF)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
-    for (int i = tid; i < 4 * D / 4; i += THREADS) {
-        const int which = i / (D / 4), j = i - which * (D / 4);
-        const float* src = which == 0 ? p.bproj : (which == 1 ? p.b2 : (which == 2 ? p.gamma : p.beta));
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (src) v = reinterpret_cast<const f32x4*>(src)[j];
-        reinterpret_cast<f32x4*>(smem + BP_OFF)[i] = v;
-    }
+    if constexpr (QKV)
+        for (int i = tid; i < 3 * D / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + BQ_OFF)[i] = reinterpret_cast<const f32x4*>(p.bqkv)[i];
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
     const float* const sB1 = reinterpret_cast<const float*>(smem + B1_OFF);
-    const float* const sBp = reinterpret_cast<const float*>(smem + BP_OFF);
-    const float* const sB2 = reinterpret_cast<const float*>(smem + B2_OFF);
-    const float* const sG = reinterpret_cast<const float*>(smem + G_OFF);
-    const float* const sBe = reinterpret_cast<const float*>(smem + BE_OFF);
+    const float* const sBq = reinterpret_cast<const float*>(smem + BQ_OFF);
     auto uniform64 = [](uint64_t v) __attribute__((always_inline)) -> uint64_t {
         return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) |
                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
     };
     const uint64_t wp = reinterpret_cast<uint64_t>(p.Wp);
     const uint32_t piece0 = (uint32_t)wave * PIECES * 1024;      // this wave's share of a slot: bytes piece0 .. piece0 + 12 KiB
-    const int first_slot = has_proj ? 0 : NPT;
+    constexpr int first_slot = has_proj ? 0 : NPT, end_slot = QKV ? NSLOT + NQT : NSLOT;
 
     // the weight stream: sn = stream slot the next step issues, ipos = the ring position it goes to, rpos = the position the next step reads
     int sn = first_slot, ipos = 0, rpos = 0;
     auto next_slot = [&]() __attribute__((always_inline)) {
-        sn = sn + 1 == NSLOT ? first_slot : sn + 1;
+        sn = sn + 1 == end_slot ? first_slot : sn + 1;
         ipos = ipos + 1 == RING ? 0 : ipos + 1;
     };
     {
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
             const bf16_t* const cr = p.ctx + lane_row(item);
             mf_for(std::make_integer_sequence<int, NPT>{}, [&](auto kt_tag) __attribute__((always_inline)) {
                 constexpr int KT = decltype(kt_tag)::value;
-                step(std::integral_constant<int, 0>{}, std::integral_constant<int, (KT < 2 ? 60 : 12)>{},
+                step(std::integral_constant<int, 0>{}, std::integral_constant<int, (KT == 0 || (KT == 1 && !QKV) ? 60 : 12)>{},
                      [&](auto j_tag, auto w_tag, const bf16x8& fr) __attribute__((always_inline)) {
                          constexpr int J = decltype(j_tag)::value, W = decltype(w_tag)::value, DB = J >> 1, R = 2 * (KT % 3) + (J & 1);
                          if (!(MF3_ABL & 8)) o[DB] = mfma32f<FMT>(fr, W == 1 ? xl[R] : xh[R], o[DB]);
@@ -307,14 +311,21 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
             });
         }
 
-        // ---- LayerNorm2 of the rows in o (register 8 s2 + j of block db = feature 32 db + 16 s2 + 8 lh + j) -> xh / xl; b2 joins the residual
-        {
-            if constexpr (has_proj) {      // (+ b_proj: LayerNorm2 sees x + proj(ctx) + b_proj)
+        // ---- LayerNorm of the rows in o (register 8 s2 + j of block db = feature 32 db + 16 s2 + 8 lh + j) -> xh / xl as hi + lo fragments.
+        // pre / post (optional, [D] fp32): added to o before the statistics / after the normalised copy has been taken (the two residual
+        // biases); the constants come from global memory (every lane half reads the same 32 bytes: L1 hits after the first wave)
+        auto layer_norm = [&](const float* gam, const float* bet, const float* pre, const float* post, auto pre_tag, auto post_tag) __attribute__((always_inline)) {
+            constexpr bool PRE = decltype(pre_tag)::value, POST = decltype(post_tag)::value;
+            uint32_t zz = 0;
+            asm volatile("" : "+v"(zz));
+            const uint32_t lo8 = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zz)) >> 5) * 8;
+            if constexpr (PRE) {
 #pragma unroll
                 for (int k = 0; k < NKS; ++k) {
+                    asm volatile("" ::: "memory");      // (one k-step of constants in flight: hoisted, the 144 loads of a LayerNorm would need 576 registers)
                     __builtin_amdgcn_sched_barrier(0);
-                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(sBp + k * 16 + lh_i * 8);
-                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(sBp + k * 16 + lh_i * 8 + 4);
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(pre + k * 16 + lo8);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(pre + k * 16 + lo8 + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         o[k >> 1][(k & 1) * 8 + e] += c0[e];
@@ -351,21 +362,27 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
             asm volatile("" : "+v"(mean_n));
 #pragma unroll
             for (int k = 0; k < NKS; ++k) {
+                asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                const float* gp = sG + k * 16 + lh_i * 8;
-                const float* bp = sBe + k * 16 + lh_i * 8;
-                const float* cp = sB2 + k * 16 + lh_i * 8;
+                const float* gp = gam + k * 16 + lo8;
+                const float* bp = bet + k * 16 + lo8;
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
                 const f32x4 e0 = *reinterpret_cast<const f32x4*>(bp), e1 = *reinterpret_cast<const f32x4*>(bp + 4);
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+                if constexpr (POST) {
+                    c0 = *reinterpret_cast<const f32x4*>(post + k * 16 + lo8);
+                    c1 = *reinterpret_cast<const f32x4*>(post + k * 16 + lo8 + 4);
+                }
                 float y[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x0 = o[k >> 1][(k & 1) * 8 + e], x1 = o[k >> 1][(k & 1) * 8 + 4 + e];
                     y[e] = (x0 - mean_n) * rstd * g0[e] + e0[e];
                     y[4 + e] = (x1 - mean_n) * rstd * g1[e] + e1[e];
-                    o[k >> 1][(k & 1) * 8 + e] = x0 + c0[e];
-                    o[k >> 1][(k & 1) * 8 + 4 + e] = x1 + c1[e];
+                    if constexpr (POST) {
+                        o[k >> 1][(k & 1) * 8 + e] = x0 + c0[e];
+                        o[k >> 1][(k & 1) * 8 + 4 + e] = x1 + c1[e];
+                    }
                 }
                 uint4 uh, ul;
                 split2<FMT>(y[0], y[1], uh.x, ul.x);
@@ -375,8 +392,9 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
                 xh[k] = __builtin_bit_cast(bf16x8, uh);
                 xl[k] = __builtin_bit_cast(bf16x8, ul);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+        };
+        // LayerNorm2: sees x + proj(ctx) + b_proj; b2 joins the residual afterwards
+        layer_norm(p.gamma, p.beta, p.bproj, p.b2, std::integral_constant<bool, has_proj>{}, std::true_type{});
 
         // ---- the GELU of a tile's 16 accumulator values per lane, one instruction per MFMA gap and element: element n starts at gap
         // 5 n of its carrier step (F1 of the next tile) and runs on into the first gaps of its own fc2 step (gaps 72 ..); the
@@ -429,8 +447,8 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
             });
         };
         // S = b1 of hidden tile t (register j of lane half h = unit (j & 7) + 8 h + 16 (j >> 3): the sigma23 row order)
-        auto s_bias = [&](f32x16& s, int t) __attribute__((always_inline)) {
-            const float* bp = sB1 + t * HT + lh_i * 8;
+        auto s_bias = [&](f32x16& s, const float* table, int t) __attribute__((always_inline)) {
+            const float* bp = table + t * HT + lh_i * 8;
             const f32x4 c0 = *reinterpret_cast<const f32x4*>(bp), c1 = *reinterpret_cast<const f32x4*>(bp + 4);
             const f32x4 c2 = *reinterpret_cast<const f32x4*>(bp + 16), c3 = *reinterpret_cast<const f32x4*>(bp + 20);
 #pragma unroll
@@ -445,7 +463,7 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
         // F1(t): s_nxt = b1(t) + W1(t) . xn^T, with the first 72 gaps of the GELU of s_cur (GELU = false: none)
         auto step_f1 = [&](f32x16& s_nxt, const f32x16& s_cur, int t, auto gelu_tag, auto vm_tag) __attribute__((always_inline)) {
             constexpr bool GELU = decltype(gelu_tag)::value;
-            s_bias(s_nxt, t);
+            s_bias(s_nxt, sB1, t);
             step(std::integral_constant<int, 0>{}, vm_tag,
                  [&](auto j_tag, auto w_tag, const bf16x8& fr) __attribute__((always_inline)) {
                      constexpr int J = decltype(j_tag)::value, W = decltype(w_tag)::value;
@@ -465,7 +483,7 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
             constexpr int B_ = decltype(b_tag)::value, DB = B_ / 3, W = B_ % 3;
             if (MF3_ABL & 32) {
                 if constexpr (W == 2) asm volatile("" ::"v"(o[DB]));
-                if constexpr (W == 2) {
+                if constexpr (W == 2 && !QKV) {
                     if (has_next) {
                         load_x(nxr, std::integral_constant<int, 2 * DB>{});
                         load_x(nxr, std::integral_constant<int, 2 * DB + 1>{});
@@ -485,7 +503,7 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
                 }
                 *reinterpret_cast<f32x4*>(xrow + k * 16) = a;
                 *reinterpret_cast<f32x4*>(xrow + k * 16 + 4) = b;
-            } else if (has_next) {
+            } else if (!QKV && has_next) {      // (QKV: the accumulators are still needed -- LayerNorm1 -- the next rows come in the last qkv steps)
                 load_x(nxr, std::integral_constant<int, 2 * DB>{});
                 load_x(nxr, std::integral_constant<int, 2 * DB + 1>{});
             }
@@ -509,7 +527,7 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
                  [&](auto g_tag) __attribute__((always_inline)) {
                      constexpr int G = decltype(g_tag)::value;
                      if constexpr (72 + G <= GELU_END) gelu_gap(std::integral_constant<int, 72 + G>{}, s_cur);
-                     if constexpr (TAIL == 2 && has_proj && G >= 24 && G < 32) {
+                     if constexpr (TAIL == 2 && has_proj && !QKV && G >= 24 && G < 32) {
                          if (has_next) load_ctx(ncr, std::integral_constant<int, (G - 24) / 4>{}, std::integral_constant<int, (G - 24) % 4>{});
                      }
                      if constexpr (TAIL == 2 && G >= 39) boundary_op(std::integral_constant<int, G - 39>{});
@@ -543,18 +561,114 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
             gelu_gap(g_tag, S1);
         });
         step_f2(S1, std::integral_constant<int, 2>{});         // F2(47): the rows out, the next item's rows in
+
+        if constexpr (QKV) {
+            // ---- LayerNorm1 of the next block on the finished rows, then Z(q)^T = Wqkv_q . xn^T + b: 36 steps of the fc1 kind; the block of tile
+            // q - 1 is scaled, split and stored in the gaps of step q (behind the step's pieces: stores count in the same vmcnt)
+            layer_norm(p.gamma1, p.beta1, nullptr, nullptr, std::false_type{}, std::false_type{});
+            // destination of this lane's row in each of Q, K, V: ((frame * heads) * npad + token) * 64 (+ 8 elements for the upper lane half)
+            long qrow;
+            {
+                uint32_t z = 0;
+                asm volatile("" : "+v"(z));
+                const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+                const int r = item * BM + wave * 32 + (int)(l & 31);
+                const int rc = r < M ? r : M - 1;
+                const int fr_ = rc / p.ntok, tok_ = rc - fr_ * p.ntok;
+                qrow = ((long)fr_ * p.heads * p.npad + tok_) * 64 + (l >> 5) * 8;
+            }
+            float ez[16];
+            uint32_t zh[8], zl[8];
+            // epilogue program of tile tq (values in z), gap G of the step that carries it.  VCONV: the V planes are bf16 whatever FMT is
+            auto epi_gap = [&](auto g_tag, auto vconv_tag, const f32x16& z, int tq) __attribute__((always_inline)) {
+                constexpr int G = decltype(g_tag)::value;
+                constexpr bool VCONV = decltype(vconv_tag)::value;
+                constexpr int EF = VCONV ? (int)FMT_BF16 : FMT;
+                if constexpr (G >= 24 && G < 40) ez[G - 24] = z[G - 24] * (tq < NDB ? p.qscale : 1.0f);
+                if constexpr (G >= 41 && G < 65) {
+                    constexpr int MM = (G - 41) / 3, W = (G - 41) % 3;
+                    if constexpr (W == 0) {
+                        if constexpr (EF == FMT_FP16) {
+                            ez[2 * MM] = __builtin_amdgcn_fmed3f(ez[2 * MM], -65504.0f, 65504.0f);
+                            ez[2 * MM + 1] = __builtin_amdgcn_fmed3f(ez[2 * MM + 1], -65504.0f, 65504.0f);
+                        }
+                        zh[MM] = pack2<EF>(ez[2 * MM], ez[2 * MM + 1]);
+                    }
+                    if constexpr (W == 1) {
+                        ez[2 * MM] -= lo_to_f32<EF>(zh[MM]);
+                        ez[2 * MM + 1] -= hi_to_f32<EF>(zh[MM]);
+                    }
+                    if constexpr (W == 2) zl[MM] = pack2<EF>(ez[2 * MM], ez[2 * MM + 1]);
+                }
+                if constexpr (G >= 66 && G < 70) {
+                    // (no row guard: duplicates of row M - 1 store the same bits to the same place, as the residual rows above)
+                    constexpr int PL = (G - 66) >> 1, GG = (G - 66) & 1;
+                    const int which = tq / NDB, hb = tq - which * NDB;
+                    bf16_t* base = which == 0 ? p.q : (which == 1 ? p.k : p.v);
+                    bf16_t* dst = base + (PL ? p.qkv_plane : 0) + qrow + (long)(hb >> 1) * p.npad * 64 + (hb & 1) * 32 + GG * 16;
+                    const uint32_t* src = PL ? zl : zh;
+                    const uint4 u = {src[4 * GG], src[4 * GG + 1], src[4 * GG + 2], src[4 * GG + 3]};
+                    if (!(MF3_ABL & 32)) *reinterpret_cast<uint4*>(dst) = u;
+                }
+            };
+            // TQ: 0 plain; 1 (step 34): the next item's rows into the accumulators, one k-step per gap; 2 (step 35): its first ctx fragments
+            auto step_q = [&](f32x16& z_nxt, const f32x16& z_cur, int q, auto epi_tag, auto vconv_tag, auto tq_tag) __attribute__((always_inline)) {
+                constexpr bool EPI = decltype(epi_tag)::value;
+                constexpr int TQ = decltype(tq_tag)::value;
+                s_bias(z_nxt, sBq, q);
+                if constexpr (TQ != 0) {
+                    const long nro = lane_row(item + (int)gridDim.x);
+                    nxr = p.X + nro;
+                    ncr = p.ctx + nro;
+                }
+                step(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{},
+                     [&](auto j_tag, auto w_tag, const bf16x8& fr) __attribute__((always_inline)) {
+                         constexpr int J = decltype(j_tag)::value, W = decltype(w_tag)::value;
+                         if (!(MF3_ABL & 4)) z_nxt = mfma32f<FMT>(fr, W == 1 ? xl[J] : xh[J], z_nxt);
+                     },
+                     [&](auto g_tag) __attribute__((always_inline)) {
+                         constexpr int G = decltype(g_tag)::value;
+                         if constexpr (EPI) epi_gap(g_tag, vconv_tag, z_cur, q - 1);
+                         if constexpr (TQ == 1 && G >= 24 && G < 24 + NKS) {
+                             if (has_next) load_x(nxr, std::integral_constant<int, G - 24>{});
+                         }
+                         if constexpr (TQ == 2 && G >= 12 && G < 20) {      // (fragments 0 .. 3 of xh / xl: last read by pair 3, gaps 9 .. 11)
+                             if (has_next) load_ctx(ncr, std::integral_constant<int, (G - 12) / 4>{}, std::integral_constant<int, (G - 12) % 4>{});
+                         }
+                     });
+            };
+            using VC = std::integral_constant<bool, (VBF && FMT == FMT_FP16)>;
+            step_q(S0, S0, 0, std::false_type{}, std::false_type{}, T0{});
+#pragma unroll 1
+            for (int q = 1; q < 2 * NDB + 1; q += 2) {          // steps 1 .. 24 carry the Q and K tiles 0 .. 23
+                step_q(S1, S0, q, std::true_type{}, std::false_type{}, T0{});
+                step_q(S0, S1, q + 1, std::true_type{}, std::false_type{}, T0{});
+            }
+#pragma unroll 1
+            for (int q = 2 * NDB + 1; q < NQT - 2; q += 2) {    // steps 25 .. 33 (+ 34 below): V tiles 24 .. 32
+                step_q(S1, S0, q, std::true_type{}, VC{}, T0{});
+                if (q + 1 < NQT - 2) step_q(S0, S1, q + 1, std::true_type{}, VC{}, T0{});
+            }
+            step_q(S0, S1, NQT - 2, std::true_type{}, VC{}, std::integral_constant<int, 1>{});      // step 34
+            step_q(S1, S0, NQT - 1, std::true_type{}, VC{}, std::integral_constant<int, 2>{});      // step 35
+            mf_for(std::make_integer_sequence<int, 72>{}, [&](auto g_tag) __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+                epi_gap(g_tag, VC{}, S1, NQT - 1);
+            });
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring pieces issued past the last item's end
 }
 
 template <int FMT>
-static int launch_mlp_fused3_fmt(const MlpFused3Params& p, hipStream_t s) {
+int launch_mlp_fused3_fmt(const MlpFused3Params& p, hipStream_t s) {
     static PerDeviceOnce once;
     if (once.first()) {
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused3_kernel<FMT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           mf3::LDS_BYTES));
-        DSEG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused3_kernel<FMT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           mf3::LDS_BYTES));
+        auto opt_in = [](const void* fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mf3::LDS_BYTES); };
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&mlp_fused3_kernel<FMT, false, false, false>)));
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&mlp_fused3_kernel<FMT, true, false, false>)));
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&mlp_fused3_kernel<FMT, true, true, false>)));
+        if (FMT == FMT_FP16) DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&mlp_fused3_kernel<FMT, true, true, FMT == FMT_FP16>)));
         once.mark();
     }
     const int ncu = device_cu_count();
@@ -569,18 +683,41 @@ static int launch_mlp_fused3_fmt(const MlpFused3Params& p, hipStream_t s) {
         const int rounds = (nitems + ncu - 1) / ncu;
         grid = (nitems + rounds - 1) / rounds;
     }
-    if (p.ctx) hipLaunchKernelGGL((mlp_fused3_kernel<FMT, true>), dim3(grid), dim3(mf3::THREADS), mf3::LDS_BYTES, s, p);
-    else hipLaunchKernelGGL((mlp_fused3_kernel<FMT, false>), dim3(grid), dim3(mf3::THREADS), mf3::LDS_BYTES, s, p);
+    const dim3 g(grid), b(mf3::THREADS);
+    if (p.q) {
+        if (FMT == FMT_FP16 && p.v_bf16) hipLaunchKernelGGL((mlp_fused3_kernel<FMT, true, true, FMT == FMT_FP16>), g, b, mf3::LDS_BYTES, s, p);
+        else hipLaunchKernelGGL((mlp_fused3_kernel<FMT, true, true, false>), g, b, mf3::LDS_BYTES, s, p);
+    } else if (p.ctx) {
+        hipLaunchKernelGGL((mlp_fused3_kernel<FMT, true, false, false>), g, b, mf3::LDS_BYTES, s, p);
+    } else {
+        hipLaunchKernelGGL((mlp_fused3_kernel<FMT, false, false, false>), g, b, mf3::LDS_BYTES, s, p);
+    }
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+// two translation units (the seven instantiations take minutes to compile): MF3_PART 0 = everything above + the fp16 kernels, 1 = the bf16 kernels
+#ifndef MF3_PART
+#define MF3_PART 0
+#endif
+#if MF3_PART == 0
+template int launch_mlp_fused3_fmt<FMT_FP16>(const MlpFused3Params&, hipStream_t);
+extern template int launch_mlp_fused3_fmt<FMT_BF16>(const MlpFused3Params&, hipStream_t);
 
 int launch_mlp_fused3(const MlpFused3Params& p, hipStream_t s) {
     if (p.M <= 0 || !p.X || !p.gamma || !p.beta || !p.Wp || !p.b1 || !p.b2 || (p.ctx && (!p.bproj || p.ctx_plane <= 0))) {
         dinoseg_set_error("mlp_fused3: null pointer or bad shape (M=%d)", p.M);
         return -1;
     }
+    if (p.q && (!p.ctx || !p.k || !p.v || !p.bqkv || !p.gamma1 || !p.beta1 || p.qkv_plane <= 0 || p.ntok <= 0 || p.npad < p.ntok ||
+                p.heads * 64 != mf3::D || p.M % p.ntok != 0)) {
+        dinoseg_set_error("mlp_fused3: incomplete qkv tail (needs ctx, bias / norm1 / q / k / v, whole frames of ntok rows)");
+        return -1;
+    }
     return p.fmt == FMT_FP16 ? launch_mlp_fused3_fmt<FMT_FP16>(p, s) : launch_mlp_fused3_fmt<FMT_BF16>(p, s);
 }
+#else
+template int launch_mlp_fused3_fmt<FMT_BF16>(const MlpFused3Params&, hipStream_t);
+#endif
 
 }  // namespace dseg

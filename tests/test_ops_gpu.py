@@ -773,7 +773,7 @@ def _split_planes(x: torch.Tensor, fp16: bool):
     return torch.stack([hi, lo]).contiguous().view(torch.int16), hi.float() + lo.float()
 
 
-def _mlp3_case(M_, fp16, seed0):
+def _mlp3_case(M_, fp16, seed0, tail=False):
     D_, F_ = 384, 1536
     X = seeded((M_, D_), seed0 + 1) * 1.7 + 0.4 + torch.arange(D_, device="cuda", dtype=torch.float32)[None, :] * 1e-3
     ctx = seeded((M_, D_), seed0 + 8) * 0.8
@@ -785,11 +785,15 @@ def _mlp3_case(M_, fp16, seed0):
     W2 = seeded((D_, F_), seed0 + 6) * 0.04 + torch.arange(D_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
     b2 = seeded((D_,), seed0 + 7)
     lib = capi.lib()
+    Wqkv = seeded((3 * D_, D_), seed0 + 11) * 0.05 + torch.arange(3 * D_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    bq = seeded((3 * D_,), seed0 + 12) * 0.4
+    gam1, bet1 = 1 + 0.2 * seeded((D_,), seed0 + 13), 0.1 * seeded((D_,), seed0 + 14)
     n = lib.dinoseg_op_mlp3_pack_elems(D_, F_)
-    assert n == 2 * (D_ * D_ + 2 * D_ * F_)
-    Wp = torch.empty((n,), dtype=torch.int16, device="cuda")
-    capi.check(lib.dinoseg_op_pack_mlp3(Wpr.data_ptr(), W1.data_ptr(), W2.data_ptr(), D_, F_, int(fp16), Wp.data_ptr(), S()))
-    return dict(X=X, ctx=ctx, Wpr=Wpr, bpr=bpr, gam=gam, bet=bet, W1=W1, b1=b1, W2=W2, b2=b2, Wp=Wp)
+    assert n == 2 * (D_ * D_ + 2 * D_ * F_ + 3 * D_ * D_)
+    Wp = torch.zeros((n,), dtype=torch.int16, device="cuda")
+    capi.check(lib.dinoseg_op_pack_mlp3(Wpr.data_ptr(), W1.data_ptr(), W2.data_ptr(), Wqkv.data_ptr() if tail else None, D_, F_, int(fp16),
+                                        Wp.data_ptr(), S()))
+    return dict(X=X, ctx=ctx, Wpr=Wpr, bpr=bpr, gam=gam, bet=bet, W1=W1, b1=b1, W2=W2, b2=b2, Wp=Wp, Wqkv=Wqkv, bq=bq, gam1=gam1, bet1=bet1)
 
 
 @pytest.mark.parametrize("fp16", [True, False])
@@ -810,7 +814,7 @@ def test_proj_mlp_fused_hi_lo_planes(cuda, M_, proj, fp16):
     got = c["X"].clone()
     capi.check(lib.dinoseg_op_proj_mlp_fused3(got.data_ptr(), ctx_pl.data_ptr() if proj else None, M_ * D_, c["bpr"].data_ptr(),
                                               c["gam"].data_ptr(), c["bet"].data_ptr(), 1e-6, c["Wp"].data_ptr(), c["b1"].data_ptr(),
-                                              c["b2"].data_ptr(), M_, D_, F_, int(fp16), None, 0, None, None, S()))
+                                              c["b2"].data_ptr(), M_, D_, F_, int(fp16), S()))
     torch.cuda.synchronize()
 
     def model(quant):
@@ -839,6 +843,49 @@ def test_proj_mlp_fused_hi_lo_planes(cuda, M_, proj, fp16):
     err0 = float((got - (xm0 + d0).float()).abs().max())
     assert err0 <= (3.0e-5 if fp16 else 2.0e-4) * scale + 1e-5, (err0, scale)
     print(f"mlp3 M={M_} proj={proj} fp16={fp16}: err {err:.3e} err_true {err0:.3e} scale {scale:.3f}")
+
+
+@pytest.mark.parametrize("fp16,v_bf16", [(True, 1), (True, 0), (False, 0)])
+@pytest.mark.parametrize("B,ntok", [(1, 65), (3, 130), (2, 901), (11, 3601)])
+def test_block_tail_fused_hi_lo_planes(cuda, B, ntok, fp16, v_bf16):
+    """mlp_fused3.hip with the qkv tail: projection + MLP of block i, then LayerNorm1 + qkv of block i + 1 in the same launch
+    (vision_transformer.py:123, :135, then :122 -> :75 / :82).  X must equal the launch without the tail bit for bit; Q / K / V against fp64
+    on the operands the kernel sees (two-plane LayerNorm output and weights), in the [B, heads, npad, 64] layout with Q pre-scaled and the
+    pad rows untouched; v_bf16: V as bf16 planes next to fp16 Q / K (what the zero-reference hi + lo attention reads).  (11, 3601): 39 611
+    rows = more items than CUs, ragged last item."""
+    D_, F_, H = 384, 1536, 6
+    M_ = B * ntok
+    npad = (ntok + 63) // 64 * 64
+    c = _mlp3_case(M_, fp16, 170, tail=True)
+    lib = capi.lib()
+    q2 = lambda t: _split_planes(t, fp16)[1]
+    ctx_pl, _ = _split_planes(c["ctx"], fp16)
+    ref = c["X"].clone()
+    capi.check(lib.dinoseg_op_proj_mlp_fused3(ref.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), c["gam"].data_ptr(),
+                                              c["bet"].data_ptr(), 1e-6, c["Wp"].data_ptr(), c["b1"].data_ptr(), c["b2"].data_ptr(), M_, D_, F_,
+                                              int(fp16), S()))
+    got = c["X"].clone()
+    plane = B * H * npad * 64
+    q = torch.zeros((2, B, H, npad, 64), dtype=torch.int16, device="cuda")
+    k, v = torch.zeros_like(q), torch.zeros_like(q)
+    qscale = 0.125 * LOG2E
+    capi.check(lib.dinoseg_op_block_tail_fused3(got.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), c["gam"].data_ptr(),
+                                                c["bet"].data_ptr(), 1e-6, c["Wp"].data_ptr(), c["b1"].data_ptr(), c["b2"].data_ptr(),
+                                                c["bq"].data_ptr(), c["gam1"].data_ptr(), c["bet1"].data_ptr(), q.data_ptr(), k.data_ptr(),
+                                                v.data_ptr(), plane, B, ntok, npad, H, qscale, v_bf16, D_, F_, int(fp16), S()))
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    A = q2(_ln_ref(got, c["gam1"], c["bet1"]).cuda()).double()
+    z = (A @ q2(c["Wqkv"]).double().t() + c["bq"].double()).float().reshape(B, ntok, 3, H, 64).permute(2, 0, 3, 1, 4)
+    dt = torch.float16 if fp16 else torch.bfloat16
+    un = lambda t, d: t.view(d).to(torch.float32).sum(dim=0)
+    gq, gk, gv = un(q, dt), un(k, dt), un(v, torch.bfloat16 if (v_bf16 or not fp16) else torch.float16)
+    # (the kernel's own LayerNorm differs from the oracle's by fp32 rounding, which can move a rounding point of the lo plane)
+    tol = (2.0 ** -18 if fp16 else 2.0 ** -14) * float(z.abs().max()) + 2e-5
+    eq, ek, ev = (float((g[:, :, :ntok] - r).abs().max()) for g, r in ((gq, z[0] * qscale), (gk, z[1]), (gv, z[2])))
+    print(f"tail3 B={B} ntok={ntok} fp16={fp16} v_bf16={v_bf16}: dq {eq:.2e} dk {ek:.2e} dv {ev:.2e} tol {tol:.2e}")
+    assert eq <= tol and ek <= tol and ev <= (tol if (fp16 and not v_bf16) else 2.0 ** -14 * float(z.abs().max()) + 2e-5)
+    assert torch.all(q[:, :, :, ntok:] == 0) and torch.all(k[:, :, :, ntok:] == 0) and torch.all(v[:, :, :, ntok:] == 0)
 
 
 @pytest.mark.parametrize("B,ntok", [(1, 65), (3, 130), (2, 901), (11, 3601)])
