@@ -198,6 +198,7 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
                 h->packed_proj.clear();
                 h->packed_qkvf.clear();
                 h->packed_mlp3.clear();
+                h->packed_rs.clear();
                 h->bound.clear();
                 h->grads.clear();
             }
@@ -272,6 +273,15 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     const int Dm = h->cfg.embed_dim, Fh = h->cfg.embed_dim * h->cfg.mlp_ratio;
     const bool mlp_fusable = mlp_fused_supported(Dm, Fh, h->planes);
     const bool mlp3_fusable = mlp_fused3_supported(Dm, Fh, h->planes);
+    // one-plane modes of the wide model: fragment-order copies of the four block linears for the row-stationary GEMMs (gemm_rs.hip)
+    auto rs_kind = [&](const LinSpec& sp) -> int {
+        if (!options().gemm_rs || h->planes != 1 || Dm != 768 || sp.wname.rfind("dino.blocks.", 0) != 0) return -1;      // (read at refresh time)
+        if (sp.K == 768 && (sp.wname.find("attn.qkv.weight") != std::string::npos || sp.wname.find("mlp.fc1.weight") != std::string::npos)) return 0;
+        if (sp.N == 768 && sp.K % 192 == 0 && (sp.wname.find("attn.proj.weight") != std::string::npos || sp.wname.find("mlp.fc2.weight") != std::string::npos)) return 1;
+        return -1;
+    };
+    for (const LinSpec& sp : specs)
+        if (rs_kind(sp) >= 0) total += align_up((size_t)sp.N * sp.K * sizeof(bf16_t), 256) + align_up((size_t)sp.N * 16 * sizeof(bf16_t), 256);
     if (mlp3_fusable) total += (size_t)h->cfg.n_blocks * align_up((size_t)mlp_fused3_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
     if (mlp_fusable)
         total += (size_t)h->cfg.n_blocks * (align_up((size_t)mlp_fused_pack_elems(Dm, Fh) * sizeof(bf16_t), 256) +
@@ -314,6 +324,18 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     h->packed_proj.clear();
     h->packed_qkvf.clear();
     h->packed_mlp3.clear();
+    h->packed_rs.clear();
+    for (const LinSpec& sp : specs)
+        if (rs_kind(sp) >= 0) {
+            bf16_t* dst = reinterpret_cast<bf16_t*>(h->wbuf + off);
+            off += align_up((size_t)sp.N * sp.K * sizeof(bf16_t), 256);
+            DSEG_TRY(launch_pack_rs(W(h, sp.wname), sp.N, sp.K, rs_kind(sp), dst, s, sp.fmt));
+            h->packed_rs[sp.wname] = dst;
+            bf16_t* bdst = reinterpret_cast<bf16_t*>(h->wbuf + off);      // the bias as MFMA fragments (the operand-stationary kernel's accumulator init)
+            off += align_up((size_t)sp.N * 16 * sizeof(bf16_t), 256);
+            DSEG_TRY(launch_pack_rs_bias(W(h, sp.bname), sp.N, bdst, s, sp.fmt));
+            h->packed_rs[sp.bname] = bdst;
+        }
     if (mlp3_fusable)
         for (int i = 0; i < h->cfg.n_blocks; ++i) {
             h->packed_mlp3["dino.blocks." + std::to_string(i) + "."] = reinterpret_cast<bf16_t*>(h->wbuf + off);
@@ -529,6 +551,17 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     // the call's batch) then take the routes -- and the summation order -- the unsplit batch takes, so the split changes no bit
     const int dB = disp_B > 0 ? disp_B : B;
     const int disp_M = dB * L.ntok, disp_Mp = dB * L.n;
+    // a block linear through the row-stationary streaming kernels (gemm_rs.hip) where a fragment-order copy exists and the batch fills the chip
+    auto gemm_any = [&](GemmParams& g, const std::string& wname) -> int {
+        if (options().gemm_rs && disp_M >= options().gemm_rs_min_rows && h->packed_rs.count(wname)) {
+            GemmParams r = g;
+            r.W = h->packed_rs.at(wname);
+            const std::string bname = wname.substr(0, wname.size() - 6) + "bias";
+            r.bias_frag = h->packed_rs.count(bname) ? h->packed_rs.at(bname) : nullptr;
+            if (gemm_rs_supported(r)) return launch_gemm_rs(r, s);
+        }
+        return launch_gemm(g, s);
+    };
     char* ws = slot ? h->ws2 : h->ws;
     float* X = reinterpret_cast<float*>(ws + L.X);
     bf16_t* A = reinterpret_cast<bf16_t*>(ws + L.A);
@@ -608,7 +641,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.bias = W(h, b + "attn.qkv.bias");
             g.q = Q; g.k = Kb; g.v = V; g.qkv_plane = L.qkv_plane;
             g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale;
-            DSEG_PROF(DINOSEG_PROF_QKV, DSEG_TRY(launch_gemm(g, s)));
+            DSEG_PROF(DINOSEG_PROF_QKV, DSEG_TRY(gemm_any(g, b + "attn.qkv.weight")));
         }
         }
         if (attn_out && i == c.n_blocks - 1)      // get_last_selfattention: probabilities of the last block, then stop
@@ -665,7 +698,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.M = L.M; g.N = D; g.K = D; g.planes = P; g.fmt = FM; g.epi = EPI_RESID; g.dispatch_rows = disp_M;
             g.bias = W(h, b + "attn.proj.bias");
             g.out_f32 = X; g.ldo_f32 = D;
-            DSEG_PROF(DINOSEG_PROF_PROJ, DSEG_TRY(launch_gemm(g, s)));
+            DSEG_PROF(DINOSEG_PROF_PROJ, DSEG_TRY(gemm_any(g, b + "attn.proj.weight")));
         }
         if (fuse_mlp3) {
             DSEG_TRY(ensure_mlp_packs(h, s));
@@ -724,7 +757,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.M = L.M; g.N = F; g.K = D; g.planes = P; g.fmt = FM; g.epi = EPI_GELU; g.dispatch_rows = disp_M;
             g.bias = W(h, b + "mlp.fc1.bias");
             g.out_bf16 = HB; g.out_plane = L.hb_plane; g.ldo = F;
-            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_gemm(g, s)));
+            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(gemm_any(g, b + "mlp.fc1.weight")));
         }
         }
         {
@@ -735,7 +768,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.M = L.M; g.N = D; g.K = F; g.planes = P; g.fmt = FM; g.epi = EPI_RESID; g.dispatch_rows = disp_M;
             g.bias = W(h, b + "mlp.fc2.bias");
             g.out_f32 = X; g.ldo_f32 = D;
-            DSEG_PROF(DINOSEG_PROF_FC2, DSEG_TRY(launch_gemm(g, s)));
+            DSEG_PROF(DINOSEG_PROF_FC2, DSEG_TRY(gemm_any(g, b + "mlp.fc2.weight")));
         }
         }
         if (tap_block == i + 1 && tap_out) DSEG_CHECK_HIP(hipMemcpyAsync(tap_out, X, xbytes, hipMemcpyDeviceToDevice, s));
@@ -945,6 +978,14 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         return 0;
     }
     if (strcmp(key, "mlp_variant") == 0) return 0;      // (accepted and ignored: the one-wave-per-SIMD build was removed in round 4)
+    if (strcmp(key, "gemm_rs") == 0) {
+        dseg::options().gemm_rs = value ? 1 : 0;
+        return 0;
+    }
+    if (strcmp(key, "gemm_rs_min_rows") == 0) {
+        dseg::options().gemm_rs_min_rows = value;
+        return 0;
+    }
     if (strcmp(key, "qkv_fused3") == 0) {
         dseg::options().qkv_fused3 = value ? 1 : 0;
         return 0;
@@ -1094,6 +1135,27 @@ extern "C" int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* 
     g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.Wproj = reinterpret_cast<const bf16_t*>(Wproj); g.bproj = bproj;
     g.fmt = options().op_fmt;
     return launch_mlp_fused2(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_pack_rs(const float* W, int32_t N, int32_t K, int32_t kind, void* dst, void* stream) {
+    return launch_pack_rs(W, N, K, kind, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), options().op_fmt);
+}
+
+extern "C" int dinoseg_op_pack_rs_bias(const float* bias, int32_t N, void* dst, void* stream) {
+    return launch_pack_rs_bias(bias, N, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), options().op_fmt);
+}
+
+extern "C" int dinoseg_op_gemm_rs(const void* A, int32_t lda, const void* Wp, const float* bias, const void* bias_frag, int32_t M, int32_t N,
+                                  int32_t K, int32_t epi, float* x_inout, void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok,
+                                  int32_t npad, int32_t heads, float qscale, void* stream) {
+    GemmParams g = {};
+    g.A = reinterpret_cast<const bf16_t*>(A); g.lda = lda; g.W = reinterpret_cast<const bf16_t*>(Wp); g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.planes = 1; g.fmt = options().op_fmt; g.epi = epi;
+    g.out_f32 = x_inout; g.ldo_f32 = N; g.out_bf16 = reinterpret_cast<bf16_t*>(out16); g.ldo = ldo;
+    g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
+    g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = heads * 64; g.qscale = qscale;
+    g.bias_frag = reinterpret_cast<const bf16_t*>(bias_frag);
+    return launch_gemm_rs(g, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t dinoseg_op_mlp3_pack_elems(int32_t D, int32_t F) { return mlp_fused3_pack_elems(D, F); }

@@ -1,0 +1,597 @@
+// Row-stationary streaming GEMMs, one operand plane, for the wide model (ViT-B/8: embed_dim 768):   C[M, N] = A[M, K] . W[N, K]^T
+//
+// gemm_big.hip's 256 x 384 tiles run ViT-B's four linears at ~0.32 of the MFMA peak (profiles/r05_vitb_kernel_stats.csv): its epilogue
+// (LDS transposition, GELU, 350-MB stores) has the chip to itself once per tile, and the multiply stops every wave at one barrier per 24 MFMAs.
+// These two kernels take the structure that mlp_fused3.hip runs at the power limit: a workgroup is FOUR waves, one per SIMD with the whole
+// 512-register file; a wave owns 32 rows for a whole item (128 rows per workgroup) and keeps ITS operand in registers; the weights stream
+// through a three-slot LDS ring (48-KiB slots packed in MFMA fragment order: a fragment = one linear 1-KiB LDS-DMA piece = one conflict-free
+// ds_read_b128), one barrier per 48 MFMAs, every load / store / epilogue instruction placed in an MFMA gap.
+//   gemm_bstat (K <= 768: qkv, fc1)   the A rows are the stationary B operand: xn[K / 16] fragments loaded straight from A[M][K] (16 bytes of a
+//                                     row per lane = one fragment).  Step n: Z^T[32 features][32 rows] = bias + W_n . xn^T (K / 16 MFMAs); the
+//                                     epilogue of tile n - 1 (GELU / the Q scale, pack, two 16-byte stores) rides in the gaps; the next item's
+//                                     fragments are prefetched one load per step.
+//   gemm_cstat (N <= 768: proj, fc2)  the output rows are the stationary accumulators: o^T[N][32 rows] = x + W . a^T in N / 32 blocks
+//                                     (384 registers at N = 768).  Step kt: the 32-wide k-tile kt of W against two B fragments loaded just in
+//                                     time from A (three rotating buffers); the last step stores each finished block (+ bias) and loads
+//                                     the next item's residual rows in its place.
+// Single-plane modes only (bf16 / fp16); the weights are re-packed once per refresh (launch_pack_rs).
+#include <type_traits>
+
+#include "mlp_common.h"
+
+namespace dseg {
+
+namespace rs {
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // (a native vector: HIP's uint4 is a struct, which an asm register operand cannot be)
+constexpr int NW = 4, BM = NW * 32, THREADS = NW * 64;
+constexpr int RING = 3;
+#ifndef RS_RA
+#define RS_RA 4
+#endif
+constexpr int RA = RS_RA, NFR = RA + 1;      // fragment read-ahead; fragment registers
+}  // namespace rs
+
+#ifndef RS_ST_SC1
+#define RS_ST_SC1 1
+#endif
+#ifndef RS_VM
+#define RS_VM 17      // gemm_bstat: operations younger than the pieces a step waits for: the previous step's twelve pieces + its bias fragment load + the four
+                      // row-group stores that one of the two steps in between has issued behind its pieces (odd steps store)
+#endif
+#ifndef RS_ABL
+#define RS_ABL 0      // timing ablations (wrong results): 1 no epilogue math, 2 no W DMA, 4 no MFMAs, 16 no fragment reads, 32 no global loads, 64 no global stores
+#endif
+
+// W [N][K] fp32 -> kind 0 (bstat): [tile n = N / 32][fragment ks = K / 16][64 lanes][8]: A row = output feature 32 n + sigma23(lane & 31),
+//                                  k = 16 ks + 8 (lane >> 5) + e
+//               -> kind 1 (cstat, N = 768): [half nh of N][pair k2 of k-tiles = K / 64][fragment 24 kk + 2 db + s2][64 lanes][8]: A row = output
+//                                  feature 384 nh + 32 db + sigma23(lane & 31), k = 64 k2 + 32 kk + 16 s2 + 8 (lane >> 5) + e
+__global__ __launch_bounds__(256) void pack_rs_kernel(const float* __restrict__ W, int N, int K, int kind, bf16_t* __restrict__ dst, int fmt) {
+    const long total = (long)N * K;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long q = idx;
+        const int e = (int)(q & 7); q >>= 3;
+        const int lane = (int)(q & 63); q >>= 6;
+        const int i = attn::sigma23(lane & 31), h = lane >> 5;
+        float v;
+        if (kind == 0) {
+            const int ks = (int)(q % (K / 16)), n = (int)(q / (K / 16));
+            v = W[(long)(n * 32 + i) * K + ks * 16 + h * 8 + e];
+        } else {      // [half of N][pair of k-tiles][fragment 24 kk + 2 db + s2]
+            const int fr = (int)(q % 48); q /= 48;
+            const int k2 = (int)(q % (K / 64)), nh = (int)(q / (K / 64));
+            const int kk = fr / 24, db = (fr % 24) >> 1, s2 = fr & 1;
+            v = W[(long)(nh * (N / 2) + db * 32 + i) * K + (2 * k2 + kk) * 32 + s2 * 16 + h * 8 + e];
+        }
+        dst[idx] = pack1(v, fmt);
+    }
+}
+
+// bias [N] fp32 -> A fragments [tile n][64 lanes][8]: lane (i, h = 0) carries bias[32 n + sigma23(i)] as three 16-bit terms (hi, mid, lo: their
+// sum is the fp32 value exactly) at k = 0, 1, 2; everything else zero
+__global__ __launch_bounds__(256) void pack_rs_bias_kernel(const float* __restrict__ bias, int N, bf16_t* __restrict__ dst, int fmt) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (N / 32) * 512; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, n = idx >> 9;
+        bf16_t v = 0;
+        if ((lane >> 5) == 0 && e < 3) {
+            const float b = bias[n * 32 + attn::sigma23(lane & 31)];
+            const bf16_t hi = pack1(b, fmt);
+            const float r1 = b - unpack1(hi, fmt);
+            const bf16_t mid = pack1(r1, fmt);
+            const bf16_t lo = pack1(r1 - unpack1(mid, fmt), fmt);
+            v = e == 0 ? hi : (e == 1 ? mid : lo);
+        }
+        dst[idx] = v;
+    }
+}
+
+int launch_pack_rs_bias(const float* bias, int N, bf16_t* dst, hipStream_t s, int fmt) {
+    if (!bias || !dst || N % 32 != 0) {
+        dinoseg_set_error("pack_rs_bias: null pointer or N=%d not a multiple of 32", N);
+        return -1;
+    }
+    hipLaunchKernelGGL(pack_rs_bias_kernel, dim3(64), dim3(256), 0, s, bias, N, dst, fmt);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_pack_rs(const float* W, int N, int K, int kind, bf16_t* dst, hipStream_t s, int fmt) {
+    if (!W || !dst || N % 32 != 0 || K % 64 != 0 || (kind != 0 && kind != 1) || (kind == 1 && N != 768)) {
+        dinoseg_set_error("pack_rs: null pointer or unsupported shape N=%d K=%d kind=%d", N, K, kind);
+        return -1;
+    }
+    hipLaunchKernelGGL(pack_rs_kernel, dim3(1024), dim3(256), 0, s, W, N, K, kind, dst, fmt);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- shared: one step = NG MFMAs on the NG fragments of the slot at ring position rpos; this wave's NG / 4 pieces of the slot two steps
+// ahead go out in the odd gaps; mma(gap tag, fragment) / valu(gap tag) as in mlp_fused3.hip
+template <int NG, int VM, class Stream, class Pre, class Mma, class Valu>
+__device__ __forceinline__ void rs_step(Stream& st, uint32_t frag_rd, uint32_t lane16, Pre&& pre, Mma&& mma, Valu&& valu) {
+    using namespace rs;
+    constexpr int SLOTB = NG * 1024, PW = NG / NW;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");      // this slot's pieces (issued two steps ago) have landed ...
+    __builtin_amdgcn_s_barrier();                                   // ... every wave's; and every wave has left the slot refilled below
+    pre();                                                          // (what needs the wait above: operands loaded by uncounted instructions)
+    constexpr int NGRP = (PW + 3) / 4;
+    uint64_t gsb[NGRP];
+    uint32_t gld[NGRP];
+    {
+        const uint64_t sb = st.wp + (uint64_t)st.sn * SLOTB + st.piece0;
+        const uint32_t ld = st.lds_base + (uint32_t)st.ipos * SLOTB + st.piece0;
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+            const uint64_t v = sb + g * 4096;
+            gsb[g] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) |
+                     ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
+            gld[g] = __builtin_amdgcn_readfirstlane(ld + g * 4096);
+        }
+        st.sn = st.sn + 1 == st.nslots ? 0 : st.sn + 1;
+        st.ipos = st.ipos + 1 == RING ? 0 : st.ipos + 1;
+    }
+    const uint32_t a = frag_rd + (uint32_t)st.rpos * SLOTB;
+    st.rpos = st.rpos + 1 == RING ? 0 : st.rpos + 1;
+    bf16x8 fr[NFR];
+    auto issue_read = [&](auto j_tag) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_tag)::value;
+        if (RS_ABL & 16) return;
+        mf_rd<J * 1024>(fr[J % NFR], a);
+    };
+    mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
+    mf_for(std::make_integer_sequence<int, NG>{}, [&](auto j_tag) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_tag)::value;
+        if constexpr (J + RA < NG) issue_read(std::integral_constant<int, J + RA>{});
+        if (RS_ABL & 16) asm volatile("" : "=v"(fr[J % NFR]));
+        else mf_wait<(NG - 1 - J < RA ? NG - 1 - J : RA)>();
+        mma(j_tag, fr[J % NFR]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((J & 1) == 1 && J < 2 * PW) {
+            constexpr int Q = J >> 1;
+            if (!(RS_ABL & 2)) mf_dma1<(Q & 3) * 1024>(lane16, gsb[Q >> 2], gld[Q >> 2]);
+        }
+        valu(j_tag);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+struct RsStream {
+    uint64_t wp;
+    uint32_t lds_base, piece0;
+    int sn, ipos, rpos, nslots;
+};
+
+template <int NG>
+__device__ __forceinline__ void rs_prologue(RsStream& st, uint32_t lane16) {
+    using namespace rs;
+    constexpr int SLOTB = NG * 1024, PW = NG / NW;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {      // what the two steps before the first one would have issued
+        const uint64_t sb = st.wp + (uint64_t)st.sn * SLOTB + st.piece0;
+        const uint32_t ld = __builtin_amdgcn_readfirstlane(st.lds_base + (uint32_t)st.ipos * SLOTB + st.piece0);
+        const uint64_t sbu = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb) |
+                             ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32);
+        if (!(RS_ABL & 2))
+#pragma unroll
+            for (int g = 0; g < PW / 4; ++g) mf_dma4(lane16, sbu + g * 4096, ld + g * 4096);
+        st.sn = st.sn + 1 == st.nslots ? 0 : st.sn + 1;
+        st.ipos = st.ipos + 1 == RING ? 0 : st.ipos + 1;
+    }
+}
+
+// ================================================================================================ gemm_bstat: qkv / fc1
+// EPI_GELU: out16[M][N] = gelu_fast(A W^T + b) (one plane, FMT);  EPI_QKV: Q (pre-scaled) / K / V [B, heads, npad, 64], V bf16 whatever FMT is.
+// The bias of tile n arrives as an A fragment (its fp32 value split exactly into three 16-bit terms at k = 0, 1, 2: launch_pack_rs_bias) that
+// one MFMA against a ones fragment turns into the accumulators' initial value -- no bias table in LDS, no VALU adds.
+// Output: the packed 64-byte rows of two consecutive tiles (= 64 features = 128 bytes per row: one head of Q / K / V, or 64 hidden units) meet in a
+// wave-private 4-KiB LDS patch ([32 rows][8 chunks of 16 bytes], chunk ^ (row & 7)) and leave as whole 128-byte row segments, 8 rows per store
+// instruction: 32-byte segments (what the accumulator layout gives directly) write at 2.4 TB/s against 5.3 (profiles/r05_gemm_epilogue_stores.md),
+// and a 350-MB store stream at that rate stalls the weight ring behind it (one in-order vmcnt for stores and LDS-DMA).
+template <int FMT, int EPI, int KS>
+__global__ __launch_bounds__(rs::THREADS, 1) void gemm_bstat_kernel(GemmParams p) {
+    using namespace rs;
+    static_assert(KS == 48, "the gap programs below are written for 48-gap steps (K = 768)");
+    constexpr int SLOTB = KS * 1024, PATCH_OFF = RING * SLOTB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.M, ntiles = p.N / 32;
+    const int nitems = (M + BM - 1) / BM;
+    if ((int)blockIdx.x >= nitems) return;
+    RsStream st;
+    st.wp = reinterpret_cast<uint64_t>(p.W);
+    st.lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    st.piece0 = (uint32_t)wave * (KS / NW) * 1024;
+    st.sn = 0; st.ipos = 0; st.rpos = 0; st.nslots = ntiles;
+    rs_prologue<KS>(st, (uint32_t)(tid & 63) * 16);
+    const uint64_t bfr = reinterpret_cast<uint64_t>(p.bias_frag);
+    // bias fragment of tile t: 16 bytes per lane, by an instruction the compiler does not count (it rides in the ring's vmcnt order: issued in
+    // gap 0 of step t - 1, it is older than everything the wait at the start of step t leaves in flight)
+    auto load_bias_frag = [&](bf16x8& dst, int t, uint32_t lane16) __attribute__((always_inline)) {
+        const uint64_t v = bfr + (uint64_t)t * 1024;
+        const uint64_t sb = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) |
+                            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
+        // (s_nop 4: the base comes from v_readfirstlane -- a VALU write of an SGPR read by a VMEM instruction needs five wait states, and hipcc
+        //  pads nothing in front of an asm statement's operands)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane16), "s"(sb) : "memory");
+    };
+    bf16x8 bf0, bf1;      // bias fragments of the even / odd tile in flight
+    load_bias_frag(bf0, 0, (uint32_t)(tid & 63) * 16);
+
+    bf16x8 xn[KS];
+    f32x16 Z0, Z1;
+    u32x4 rb0, rb1, rb2, rb3;      // a finished pair of tiles on its way from the patch to memory (scalars: asm operands cannot be array elements reached through a reference)
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        uint32_t zero = 0;
+        asm volatile("" : "+v"(zero));
+        const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+        const uint32_t lane16_i = lane_i * 16, lh_i = lane_i >> 5, lr_i = lane_i & 31;
+        const uint32_t frag_rd_i = st.lds_base + lane16_i;
+        // this lane's row as the B operand
+        {
+            const int r = item * BM + wave * 32 + (int)lr_i;
+            const bf16_t* ar = p.A + (long)(r < M ? r : M - 1) * p.lda + lh_i * 8;
+            mf_for(std::make_integer_sequence<int, KS>{}, [&](auto k_tag) __attribute__((always_inline)) {
+                constexpr int k = decltype(k_tag)::value;
+                uint4 u = {0x3c003c00u, 0x3c003c00u, (uint32_t)k, 0u};
+                if (!(RS_ABL & 32)) u = *reinterpret_cast<const uint4*>(ar + k * 16);
+                xn[k] = __builtin_bit_cast(bf16x8, u);
+            });
+        }
+        // patch addresses: this lane writes row lr, chunk (4 parity + 2 g + lh) ^ (lr & 7); it reads back row 8 i + (lane >> 3), chunk
+        // (lane & 7) ^ (row & 7), and stores that row's 16 bytes
+        const uint32_t patch = st.lds_base + PATCH_OFF + (uint32_t)wave * 4096;
+        auto aw_of = [&](uint32_t c) __attribute__((always_inline)) { return patch + lr_i * 128 + ((2 * c + lh_i) ^ (lr_i & 7)) * 16; };      // c = 2 parity + g
+        const uint32_t aw0 = aw_of(0), aw1 = aw_of(1), aw2 = aw_of(2), aw3 = aw_of(3);
+        const uint32_t ard = patch + (lane_i >> 3) * 128 + ((lane_i & 7) ^ ((lane_i >> 3) & 7)) * 16;                // + 1024 i
+        // the four rows this lane stores (clamped: rows past the end are copies of row M - 1 and rewrite its bytes)
+        long orow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = item * BM + wave * 32 + 8 * i + (int)(lane_i >> 3);
+            const int rc = r < M ? r : M - 1;
+            if constexpr (EPI == EPI_QKV) {
+                const int fr_ = rc / p.ntok, tok_ = rc - fr_ * p.ntok;
+                orow[i] = ((long)fr_ * p.heads * p.npad + tok_) * 64 + (lane_i & 7) * 8;
+            } else {
+                orow[i] = (long)rc * p.ldo + (lane_i & 7) * 8;
+            }
+        }
+        constexpr uint32_t ONE = FMT == FMT_FP16 ? 0x3C00u : 0x3F80u;
+        const uint4 ones_u = {lh_i == 0 ? (ONE << 16 | ONE) : 0u, lh_i == 0 ? ONE : 0u, 0u, 0u};     // k = 0, 1, 2 are 1.0
+
+        float ez[16], eu[16], eq[16];
+        uint32_t zp[8];
+        auto gelu_op = [&](auto n_tag, auto i_tag, const f32x16& z) __attribute__((always_inline)) {
+            constexpr int N = decltype(n_tag)::value, I = decltype(i_tag)::value;
+            if (RS_ABL & 1) {
+                if constexpr (I == 0) ez[N] = z[N];
+                return;
+            }
+            if constexpr (I == 0) eu[N] = __builtin_amdgcn_fmed3f(z[N], -8.0f, 8.0f);
+            if constexpr (I == 1) eq[N] = eu[N] * eu[N];
+            if constexpr (I == 2) ez[N] = fmaf(1.01537542e-3f, eq[N], -1.06782573e-1f);
+            if constexpr (I == 3) ez[N] = fmaf(ez[N], eq[N], -2.30111381f);
+            if constexpr (I == 4) ez[N] = ez[N] * eu[N];
+            if constexpr (I == 5) ez[N] = __builtin_amdgcn_exp2f(ez[N]);
+            if constexpr (I == 6) ez[N] = 1.0f + ez[N];
+            if constexpr (I == 7) ez[N] = __builtin_amdgcn_rcpf(ez[N]);
+            if constexpr (I == 8) ez[N] = z[N] * ez[N];
+        };
+        // the epilogue of tile tq (values in z; PAR = tq & 1), gap G of the step that carries it: element n's instruction i at gap START(n) + i, a
+        // pair packed one gap after its odd element; the packed row halves into the patch at gaps 42 / 43; an odd tile completes a pair: its four
+        // 1-KiB groups of rows come back at gaps 44 .. 47
+        auto epilogue_gap = [&](auto g_tag, auto par_tag, const f32x16& z, int tq) __attribute__((always_inline)) {
+            constexpr int G = decltype(g_tag)::value, PAR = decltype(par_tag)::value;
+            constexpr int NOPS = EPI == EPI_GELU ? 9 : 1;
+            // (named here: clang does not capture a variable whose only use is an asm operand inside `if constexpr`)
+            const uint32_t ard_ = ard, aw0_ = aw0, aw1_ = aw1, aw2_ = aw2, aw3_ = aw3;
+            u32x4 &r0_ = rb0, &r1_ = rb1, &r2_ = rb2, &r3_ = rb3;
+            mf_for(std::make_integer_sequence<int, 16>{}, [&](auto n_tag) __attribute__((always_inline)) {
+                constexpr int N = decltype(n_tag)::value;
+                constexpr int START = EPI == EPI_GELU ? 2 * N + 1 : 2 * N + 4;
+                if constexpr (G >= START && G < START + NOPS) {
+                    if constexpr (EPI == EPI_GELU) gelu_op(n_tag, std::integral_constant<int, G - START>{}, z);
+                    else ez[N] = z[N] * (tq < p.dmodel / 32 ? p.qscale : 1.0f);
+                }
+                if constexpr ((N & 1) == 1 && G == START + NOPS) {
+                    if constexpr (EPI == EPI_QKV) {
+                        // (V stays bf16 in the fp16 mode: the zero-reference attention's P.V product; Q / K saturate like gemm_big.hip)
+                        if (FMT == FMT_BF16 || tq >= 2 * (p.dmodel / 32)) zp[N >> 1] = pack_bf16x2(ez[N - 1], ez[N]);
+                        else zp[N >> 1] = pack2_sat<FMT>(ez[N - 1], ez[N]);
+                    } else {
+                        zp[N >> 1] = pack2_sat<FMT>(ez[N - 1], ez[N]);
+                    }
+                }
+            });
+            if constexpr (G == 42 || G == 43) {
+                constexpr int GG = G - 42;
+                const u32x4 u = {zp[4 * GG], zp[4 * GG + 1], zp[4 * GG + 2], zp[4 * GG + 3]};
+                constexpr int C = 2 * PAR + GG;
+                const uint32_t awc = C == 0 ? aw0_ : (C == 1 ? aw1_ : (C == 2 ? aw2_ : aw3_));
+                asm volatile("ds_write_b128 %0, %1" ::"v"(awc), "v"(u) : "memory");
+            }
+            if constexpr (PAR == 1 && G >= 44) {
+                constexpr int I = G - 44;
+                if constexpr (I == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(r0_) : "v"(ard_));
+                if constexpr (I == 1) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(r1_) : "v"(ard_));
+                if constexpr (I == 2) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(r2_) : "v"(ard_));
+                if constexpr (I == 3) asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(r3_) : "v"(ard_));
+            }
+        };
+        // the finished pair pp (tiles 2 pp, 2 pp + 1) from rb to memory: group i = rows 8 i .. 8 i + 7 of the wave, 128 bytes each
+        auto store_group = [&](auto i_tag, int pp) __attribute__((always_inline)) {
+            constexpr int I = decltype(i_tag)::value;
+            bf16_t* dst;
+            if constexpr (EPI == EPI_QKV) {
+                const int which = pp / p.heads, head = pp - which * p.heads;
+                dst = (which == 0 ? p.q : (which == 1 ? p.k : p.v)) + orow[I] + (long)head * p.npad * 64;
+            } else {
+                dst = p.out_bf16 + orow[I] + pp * 64;
+            }
+            const u32x4 v = I == 0 ? rb0 : (I == 1 ? rb1 : (I == 2 ? rb2 : rb3));
+            // sc1: a write-through store that does not keep its line in the XCD's L2 (MI355X_MICROARCH.md, stores of each flavour) -- the 350-MB
+            // output stream would otherwise push the weight tiles every CU re-reads out of the 4-MiB L2 (served by the Infinity Cache at half the rate)
+            if (RS_ABL & 64) asm volatile("" ::"v"(v), "v"(dst));
+            else if (RS_ST_SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+            else *reinterpret_cast<u32x4*>(dst) = v;
+        };
+        // step n (PAR = n & 1): z_nxt = bias(n) + W_n . xn^T; in the gaps: the bias fragment of tile n + 1, the epilogue of tile n - 1 (z_cur), and --
+        // odd steps -- the stores of the pair the previous step read back
+        auto step = [&](f32x16& z_nxt, const f32x16& z_cur, int n, auto par_tag, auto epi_tag) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value;
+            constexpr bool EPI_ON = decltype(epi_tag)::value;
+            rs_step<KS, RS_VM>(
+                st, frag_rd_i, lane16_i,
+                [&]() __attribute__((always_inline)) {
+                    // the bias fragment was loaded in gap 0 of the previous step (or ahead of the item's row loads): older than the twelve
+                    // operations the step's wait leaves in flight -- it has landed
+                    f32x16 zz;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zz[r] = 0.f;
+                    if (!(RS_ABL & 4)) z_nxt = mfma32f<FMT>(PAR ? bf1 : bf0, __builtin_bit_cast(bf16x8, ones_u), zz);
+                    else z_nxt = zz;
+                    __builtin_amdgcn_sched_barrier(0);
+                },
+                [&](auto j_tag, const bf16x8& fr) __attribute__((always_inline)) {
+                    constexpr int J = decltype(j_tag)::value;
+                    if (!(RS_ABL & 4)) z_nxt = mfma32f<FMT>(fr, xn[J], z_nxt);
+                },
+                [&](auto g_tag) __attribute__((always_inline)) {
+                    constexpr int G = decltype(g_tag)::value;
+                    if constexpr (G == 0) load_bias_frag(PAR ? bf0 : bf1, n + 1 < ntiles ? n + 1 : 0, lane16_i);
+                    if constexpr (EPI_ON) epilogue_gap(g_tag, std::integral_constant<int, 1 - PAR>{}, z_cur, n - 1);
+                    if constexpr (EPI_ON && PAR == 1 && G >= 24 && G < 28) {
+                        if (n >= 3) store_group(std::integral_constant<int, G - 24>{}, (n - 3) >> 1);
+                    }
+                });
+        };
+        using E0 = std::integral_constant<int, 0>;
+        using E1 = std::integral_constant<int, 1>;
+        // (ntiles is even: qkv 72 / fc1 96 tiles)
+        step(Z0, Z0, 0, E0{}, std::false_type{});
+#pragma unroll 1
+        for (int n = 1; n + 1 < ntiles; n += 2) {
+            step(Z1, Z0, n, E1{}, std::true_type{});
+            step(Z0, Z1, n + 1, E0{}, std::true_type{});
+        }
+        step(Z1, Z0, ntiles - 1, E1{}, std::true_type{});
+        // the last tile's epilogue and the last pair's stores have no step to ride in
+        mf_for(std::make_integer_sequence<int, KS>{}, [&](auto g_tag) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_gap(g_tag, E1{}, Z1, ntiles - 1);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mf_for(std::make_integer_sequence<int, 4>{}, [&](auto i_tag) __attribute__((always_inline)) { store_group(i_tag, (ntiles - 2) >> 1); });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ================================================================================================ gemm_cstat: proj / fc2 (+ residual)
+// X[M][768] += A[M][K] . W^T + bias, in place.  An item = 128 rows x ONE HALF of the 768 output features (12 accumulator blocks = 192
+// registers: MFMA accumulators live in the 256 AGPRs); a step = two 32-wide k-tiles of that half of W (48 fragments); items 2 r and 2 r + 1
+// are the two halves of row block r and run on neighbouring workgroups at the same time (the second read of the A rows is an L2 hit); the
+// grid is even, so a workgroup keeps its half -- and its weight stream -- for the whole launch.
+template <int FMT>
+__global__ __launch_bounds__(rs::THREADS, 1) void gemm_cstat_kernel(GemmParams p) {
+    using namespace rs;
+    constexpr int NB = 12, NG = 48, SLOTB = NG * 1024, NH = NB * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.M, nk2 = p.K / 64;
+    const int nitems = 2 * ((M + BM - 1) / BM);
+    if ((int)blockIdx.x >= nitems) return;
+    const int nh = blockIdx.x & 1;
+    float* const sBias = reinterpret_cast<float*>(smem + RING * SLOTB);
+    for (int i = tid; i < NH / 4; i += THREADS) reinterpret_cast<f32x4*>(sBias)[i] = reinterpret_cast<const f32x4*>(p.bias + nh * NH)[i];
+    RsStream st;
+    st.wp = reinterpret_cast<uint64_t>(p.W) + (uint64_t)nh * nk2 * SLOTB;
+    st.lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    st.piece0 = (uint32_t)wave * (NG / NW) * 1024;
+    st.sn = 0; st.ipos = 0; st.rpos = 0; st.nslots = nk2;
+    rs_prologue<NG>(st, (uint32_t)(tid & 63) * 16);
+    __syncthreads();
+
+    f32x16 o[NB];
+    bf16x8 bq[3][4];      // [buffer][2 (k-tile of the pair) + s2]
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        uint32_t zero = 0;
+        asm volatile("" : "+v"(zero));
+        const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+        const uint32_t lane16_i = lane_i * 16, lh_i = lane_i >> 5;
+        const uint32_t frag_rd_i = st.lds_base + lane16_i;
+        auto lane_row = [&](int it) __attribute__((always_inline)) -> int {      // this lane's row of item `it` (row block it >> 1), clamped
+            uint32_t z = 0;
+            asm volatile("" : "+v"(z));
+            const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+            const int r = (it >> 1) * BM + wave * 32 + (int)(l & 31);
+            return r < M ? r : M - 1;
+        };
+        auto lane_half8 = [&]() __attribute__((always_inline)) -> uint32_t {
+            uint32_t z = 0;
+            asm volatile("" : "+v"(z));
+            return (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)) >> 5) * 8;
+        };
+        // residual block db: features 32 db + 16 s2 + 8 lh + (0 .. 7) = registers 8 s2 + (0 .. 7): four 16-byte loads / stores
+        auto load_x = [&](const float* xr, auto db_tag) __attribute__((always_inline)) {
+            constexpr int DB = decltype(db_tag)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 a = {1.f, 2.f, 3.f, (float)q};
+                if (!(RS_ABL & 32)) a = *reinterpret_cast<const f32x4*>(xr + DB * 32 + (q >> 1) * 16 + (q & 1) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[DB][q * 4 + e] = a[e];
+            }
+        };
+        // B fragment i = 2 kk + s2 of k-tile pair k2: 16 bytes of the A row at k = 64 k2 + 32 kk + 16 s2 + 8 lh
+        auto load_b = [&](const bf16_t* ar, int k2, auto buf_tag, auto i_tag) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(buf_tag)::value, I = decltype(i_tag)::value;
+            uint4 u = {0x3c003c00u, 0x3c003c00u, (uint32_t)k2, 0u};
+            if (!(RS_ABL & 32)) u = *reinterpret_cast<const uint4*>(ar + k2 * 64 + I * 16);
+            bq[BUF][I] = __builtin_bit_cast(bf16x8, u);
+        };
+        auto load_b4 = [&](const bf16_t* ar, int k2, auto buf_tag) __attribute__((always_inline)) {
+            mf_for(std::make_integer_sequence<int, 4>{}, [&](auto i_tag) __attribute__((always_inline)) { load_b(ar, k2, buf_tag, i_tag); });
+        };
+        const bool has_next = item + (int)gridDim.x < nitems;
+        const bf16_t* const ar = p.A + (long)lane_row(item) * p.lda + lane_half8();
+        if (item == (int)blockIdx.x) {
+            const float* xr = p.out_f32 + (long)lane_row(item) * p.ldo_f32 + nh * NH + lane_half8();
+            mf_for(std::make_integer_sequence<int, NB>{}, [&](auto db_tag) __attribute__((always_inline)) { load_x(xr, db_tag); });
+        }
+        // (the first two fragment pairs at the item's start, in flight beside the bias pass below: prefetched from the previous item's last steps
+        //  they are loop-carried values, which hipcc parks in scratch across the item boundary)
+        load_b4(ar, 0, std::integral_constant<int, 0>{});
+        load_b4(ar, 1, std::integral_constant<int, 1>{});
+        // the bias joins the residual rows (an LDS read inside a step would be waited for with the compiler's lgkmcnt count, which knows nothing of
+        // the fragment reads in flight: here nothing is)
+#pragma unroll
+        for (int db = 0; db < NB; ++db) {
+            __builtin_amdgcn_sched_barrier(0);
+            const float* bp = sBias + db * 32 + lh_i * 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(bp + (q >> 1) * 16 + (q & 1) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[db][q * 4 + e] += c[e];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float* xrow = nullptr;
+        const float* nxr = nullptr;
+        // step k2 (buffer BUF = k2 % 3): o[db] += W(kk, db, s2) . b(kk, s2) for the pair's two k-tiles; the fragments of pair k2 + 2 are
+        // loaded in gaps 2 .. 8.  LAST: block db is final after gap 25 + 2 db: stored two gaps later, the next item's rows loaded in its place
+        auto step = [&](int k2, auto buf_tag, auto vm_tag, auto last_tag) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;
+            if constexpr (LAST) {
+                const uint32_t h8 = lane_half8();
+                xrow = p.out_f32 + (long)lane_row(item) * p.ldo_f32 + nh * NH + h8;
+                nxr = p.out_f32 + (long)lane_row(item + (int)gridDim.x) * p.ldo_f32 + nh * NH + h8;
+            }
+
+            auto finish = [&](auto db_tag) __attribute__((always_inline)) {
+                constexpr int DB = decltype(db_tag)::value;
+                // (no row guard: a lane past the last row works on a copy of row M - 1 and stores the same bits to the same place)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = o[DB][q * 4 + e];
+                    if (!(RS_ABL & 64)) *reinterpret_cast<f32x4*>(xrow + DB * 32 + (q >> 1) * 16 + (q & 1) * 4) = a;
+                    else asm volatile("" ::"v"(a));
+                }
+                if (has_next) load_x(nxr, db_tag);
+            };
+            rs_step<NG, decltype(vm_tag)::value>(
+                st, frag_rd_i, lane16_i, []() __attribute__((always_inline)) {},
+                [&](auto j_tag, const bf16x8& fr) __attribute__((always_inline)) {
+                    constexpr int J = decltype(j_tag)::value, KK = J / 24, JJ = J % 24;
+                    if (!(RS_ABL & 4)) o[JJ >> 1] = mfma32f<FMT>(fr, bq[BUF][2 * KK + (JJ & 1)], o[JJ >> 1]);
+                },
+                [&](auto g_tag) __attribute__((always_inline)) {
+                    constexpr int G = decltype(g_tag)::value;
+                    if constexpr (!LAST && G >= 2 && G <= 8 && (G & 1) == 0) {
+                        if (k2 + 2 < nk2) load_b(ar, k2 + 2, std::integral_constant<int, (BUF + 2) % 3>{}, std::integral_constant<int, (G - 2) / 2>{});
+                    }
+                    if constexpr (LAST && G >= 27 && (G & 1) == 1) finish(std::integral_constant<int, (G - 27) / 2>{});
+                });
+            if constexpr (LAST) {
+                finish(std::integral_constant<int, NB - 1>{});      // (blocks 0 .. NB - 2: gaps 27 .. 47)
+            }
+        };
+        using VM = std::integral_constant<int, NG / NW>;
+        using VMB = std::integral_constant<int, 48>;      // an item's first two steps: >= 48 row loads were issued behind the pieces they wait for
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        using B2 = std::integral_constant<int, 2>;
+        step(0, B0{}, VMB{}, std::false_type{});
+        step(1, B1{}, VMB{}, std::false_type{});
+        step(2, B2{}, VM{}, std::false_type{});
+#pragma unroll 1
+        for (int k2 = 3; k2 + 3 < nk2; k2 += 3) {
+            step(k2, B0{}, VM{}, std::false_type{});
+            step(k2 + 1, B1{}, VM{}, std::false_type{});
+            step(k2 + 2, B2{}, VM{}, std::false_type{});
+        }
+        step(nk2 - 3, B0{}, VM{}, std::false_type{});
+        step(nk2 - 2, B1{}, VM{}, std::false_type{});
+        step(nk2 - 1, B2{}, VM{}, std::true_type{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------ host
+bool gemm_rs_supported(const GemmParams& p) {
+    if (p.planes != 1 || p.bias == nullptr || p.M < 1 || p.lda % 8 != 0 || p.resid != nullptr || p.aux_out != nullptr || p.ksplit > 1) return false;
+    if (p.epi == EPI_RESID) return p.N == 768 && p.K % 192 == 0 && p.K >= 576 && p.ldo_f32 == p.N && p.out_f32 != nullptr;
+    if (p.epi == EPI_GELU) return p.K == 768 && p.N % 64 == 0 && p.N >= 128 && p.ldo % 8 == 0 && p.bias_frag != nullptr && p.out_bf16 != nullptr;
+    if (p.epi == EPI_QKV) return p.K == 768 && p.dmodel == 768 && p.N == 3 * p.dmodel && p.heads * 64 == p.dmodel && p.bias_frag != nullptr && p.q && p.k && p.v;
+    return false;
+}
+
+template <int FMT>
+static int launch_gemm_rs_fmt(const GemmParams& p, hipStream_t s) {
+    using namespace rs;
+    constexpr int LDS_B = RING * 48 * 1024 + NW * 4096, LDS_C = RING * 48 * 1024 + 4 * 1024;
+    static PerDeviceOnce once;
+    if (once.first()) {
+        auto opt_in = [](const void* fn, int bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&gemm_bstat_kernel<FMT, EPI_GELU, 48>), LDS_B));
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&gemm_bstat_kernel<FMT, EPI_QKV, 48>), LDS_B));
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&gemm_cstat_kernel<FMT>), LDS_C));
+        once.mark();
+    }
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return -2;
+    const int nitems = (p.M + BM - 1) / BM;
+    const int rounds = (nitems + ncu - 1) / ncu;
+    const int grid = (nitems + rounds - 1) / rounds;
+    const dim3 b(THREADS);
+    if (p.epi == EPI_RESID) {      // two items per row block (the halves of N); an even grid keeps every workgroup on one half
+        const int n2 = 2 * nitems, r2 = (n2 + ncu - 1) / ncu;
+        int g2 = (n2 + r2 - 1) / r2;
+        g2 += g2 & 1;
+        if (g2 > ncu) g2 = ncu & ~1;
+        hipLaunchKernelGGL((gemm_cstat_kernel<FMT>), dim3(g2), b, LDS_C, s, p);
+        DSEG_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    const dim3 g(grid);
+    if (p.epi == EPI_GELU) hipLaunchKernelGGL((gemm_bstat_kernel<FMT, EPI_GELU, 48>), g, b, LDS_B, s, p);
+    else hipLaunchKernelGGL((gemm_bstat_kernel<FMT, EPI_QKV, 48>), g, b, LDS_B, s, p);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// p.W: the weight re-packed by launch_pack_rs (kind 0 for GELU / QKV, kind 1 for RESID)
+int launch_gemm_rs(const GemmParams& p, hipStream_t s) {
+    if (!gemm_rs_supported(p)) {
+        dinoseg_set_error("gemm_rs: unsupported shape / epilogue (M=%d N=%d K=%d epi=%d planes=%d)", p.M, p.N, p.K, p.epi, p.planes);
+        return -1;
+    }
+    return p.fmt == FMT_FP16 ? launch_gemm_rs_fmt<FMT_FP16>(p, s) : launch_gemm_rs_fmt<FMT_BF16>(p, s);
+}
+
+}  // namespace dseg

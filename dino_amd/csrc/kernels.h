@@ -46,6 +46,7 @@ struct GemmParams {
     int v_bf16;                                 // EPI_QKV with fp16 hi + lo planes: write V as bf16 hi + lo planes (AttnParams::v_bf16)
     int dispatch_rows;                          // launch_gemm's kernel choice is made for this many rows instead of M when > 0: the two
                                                 // half-batches of a split forward take the route of the whole batch (same summation order)
+    const bf16_t* bias_frag;                    // gemm_rs.hip (EPI_GELU / EPI_QKV): the bias as MFMA A fragments (launch_pack_rs_bias), [N / 32][64][8]
     int ksplit;                                 // >1: split the K loop over grid.y (EPI_ATOMIC, or EPI_PLAIN partial tiles)
     long split_stride;                          // EPI_PLAIN with ksplit > 1: slice y writes out_f32 + y * split_stride (floats)
 };
@@ -53,6 +54,13 @@ int launch_gemm(const GemmParams& p, hipStream_t s);       // dispatches between
 int launch_gemm_small(const GemmParams& p, hipStream_t s); // 128x128 tile, bf16 or bf16x3 (gemm.hip)
 bool gemm_big_supported(const GemmParams& p);
 int launch_gemm_big(const GemmParams& p, hipStream_t s);   // 256x384 persistent tile, bf16 only (gemm_big.hip)
+
+// Row-stationary streaming GEMMs for the wide model (gemm_rs.hip; one plane, embed_dim 768): p.W = the weight re-packed by launch_pack_rs
+// (kind 0 for EPI_GELU / EPI_QKV: K = 768; kind 1 for EPI_RESID: N = 768, in place on out_f32)
+bool gemm_rs_supported(const GemmParams& p);
+int launch_pack_rs(const float* W, int N, int K, int kind, bf16_t* dst, hipStream_t s, int fmt);
+int launch_pack_rs_bias(const float* bias, int N, bf16_t* dst, hipStream_t s, int fmt);      // N * 16 elements
+int launch_gemm_rs(const GemmParams& p, hipStream_t s);
 
 // LayerNorm-fused A-stationary GEMM for qkv / fc1 (gemm_ln.hip): X fp32 rows are normalised in the prologue, W streams
 struct LnGemmParams {
@@ -142,6 +150,10 @@ struct Options {
     int qkv_fused = 0;       // 1: ... and LayerNorm1 + qkv of the NEXT block at its end (blocks 1.. then have no LN+qkv launch); measured
                              // +1 % on one stream, +-0 on two: the tail is bound by the same HBM write burst as the launch it replaces
     int qkv_fused3 = 1;      // hi + lo planes (mlp_fused3.hip): 1 = LayerNorm1 + qkv of the NEXT block at the end of the fused projection + MLP launch
+    int gemm_rs = 0;         // 1: the row-stationary streaming GEMMs (gemm_rs.hip) where they apply (embed_dim 768, one plane, >= gemm_rs_min_rows rows).
+                             // Off: measured EQUAL to gemm_big.hip on qkv / fc1 (261 / 334 us against 252 / 352 at 57 616 rows) and slower on proj / fc2 --
+                             // with its output stores masked off the same main loop runs at 2.0 PFLOP/s (105 / 118 us): profiles/r06_gemm_rs.md
+    int gemm_rs_min_rows = 24000;
     int proj_fused = 1;      // 1: the block's attention output projection runs inside the fused MLP launch
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 8;       // (8 frames @480: +6 %, 12: +16 %, 16: +12 %; 6 frames and fewer: slower split)

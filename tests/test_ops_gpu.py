@@ -949,3 +949,117 @@ def test_block_tail_fused(cuda, B, ntok):
     torch.cuda.synchronize()
     for a, b_ in ((gq, unpack(q2)), (gk, unpack(k2)), (gv, unpack(v2))):
         assert float((a - b_).abs().max()) <= tol
+
+
+def _one_plane(x: torch.Tensor, fp16: bool):
+    """fp32 -> (int16 [rows, cols] as the one-plane kernels read it, the fp32 value it carries)"""
+    dt = torch.float16 if fp16 else torch.bfloat16
+    q = x.to(dt)
+    return q.contiguous().view(torch.int16), q.float()
+
+
+def _pack_rs(W: torch.Tensor, kind: int) -> torch.Tensor:
+    N, K = W.shape
+    out = torch.empty((N * K,), dtype=torch.int16, device="cuda")
+    capi.check(capi.lib().dinoseg_op_pack_rs(W.contiguous().data_ptr(), N, K, kind, out.data_ptr(), S()))
+    return out
+
+
+def _pack_rs_bias(bias: torch.Tensor) -> torch.Tensor:
+    out = torch.empty((bias.numel() * 16,), dtype=torch.int16, device="cuda")
+    capi.check(capi.lib().dinoseg_op_pack_rs_bias(bias.data_ptr(), bias.numel(), out.data_ptr(), S()))
+    return out
+
+
+@pytest.mark.parametrize("fp16", [True, False])
+@pytest.mark.parametrize("M_,K", [(128, 768), (77, 768), (128 * 5 + 33, 3072), (128 * 300 + 19, 768), (128 * 260 + 1, 3072)])
+def test_gemm_rs_residual(cuda, M_, K, fp16):
+    """gemm_rs.hip, accumulator-stationary kernel: x += A W^T + bias at N = 768 (ViT-B's attn.proj and mlp.fc2 with the residual add:
+    vision_transformer.py:105 + :123, :63 + :135), against fp64 on the one-plane operands.  38 419 / 33 281 rows: more items than CUs (the
+    weight ring runs on across the items of the persistent walk), ragged last item (clamped rows)."""
+    N = 768
+    lib = capi.lib()
+    capi.check(lib.dinoseg_set_option(b"op_fmt", int(fp16)))
+    try:
+        A = seeded((M_, K), 201) + torch.arange(K, device="cuda", dtype=torch.float32)[None, :] * 1e-4
+        W = seeded((N, K), 202) * 0.05 + torch.arange(N, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+        bias = seeded((N,), 203)
+        X = seeded((M_, N), 204) * 2.0
+        Ap, Aq = _one_plane(A, fp16)
+        Wq = _one_plane(W, fp16)[1]
+        got = X.clone()
+        Wp = _pack_rs(W, 1)
+        capi.check(lib.dinoseg_op_gemm_rs(Ap.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), None, M_, N, K, capi.EPI_RESID,
+                                          got.data_ptr(), None, 0, None, None, None, 0, 0, 0, 0.0, S()))
+        torch.cuda.synchronize()
+    finally:
+        capi.check(lib.dinoseg_set_option(b"op_fmt", 0))
+    delta = Aq.double() @ Wq.double().t() + bias.double()
+    want = (X.double() + delta).float()
+    scale = float(delta.abs().max())
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) <= 2e-6 * scale * math.sqrt(K / 64) + 1e-5
+    assert float((got - X).abs().max()) > 0.5 * scale
+
+
+@pytest.mark.parametrize("fp16", [True, False])
+@pytest.mark.parametrize("M_", [128, 77, 128 * 5 + 33, 128 * 270 + 19])
+def test_gemm_rs_gelu(cuda, M_, fp16):
+    """gemm_rs.hip, operand-stationary kernel with the GELU epilogue: H = gelu(A W^T + b), K = 768, N = 3072 (ViT-B's mlp.fc1 + act:
+    vision_transformer.py:60-61), one 16-bit plane out, against fp64 + the exact GELU on the one-plane operands (the fitted logistic form
+    of the one-plane modes: |error| <= 2.6e-5, below the rounding of the stored activation)."""
+    N, K = 3072, 768
+    lib = capi.lib()
+    capi.check(lib.dinoseg_set_option(b"op_fmt", int(fp16)))
+    try:
+        A = seeded((M_, K), 211) + torch.arange(K, device="cuda", dtype=torch.float32)[None, :] * 1e-4
+        W = seeded((N, K), 212) * 0.04 + torch.arange(N, device="cuda", dtype=torch.float32)[:, None] * 1e-6
+        bias = seeded((N,), 213) * 0.5
+        Ap, Aq = _one_plane(A, fp16)
+        Wq = _one_plane(W, fp16)[1]
+        out = torch.zeros((M_, N), dtype=torch.int16, device="cuda")
+        Wp, bfr = _pack_rs(W, 0), _pack_rs_bias(bias)
+        capi.check(lib.dinoseg_op_gemm_rs(Ap.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), bfr.data_ptr(), M_, N, K, capi.EPI_GELU, None,
+                                          out.data_ptr(), N, None, None, None, 0, 0, 0, 0.0, S()))
+        torch.cuda.synchronize()
+    finally:
+        capi.check(lib.dinoseg_set_option(b"op_fmt", 0))
+    z = Aq.double() @ Wq.double().t() + bias.double()
+    want = (0.5 * z * (1.0 + torch.erf(z / math.sqrt(2.0)))).float()
+    got = out.view(torch.float16 if fp16 else torch.bfloat16).float()
+    assert torch.isfinite(got).all()
+    rel = 2.0 ** -11 if fp16 else 2.0 ** -8
+    assert float(((got - want).abs() - rel * want.abs()).max()) <= 1e-4
+    assert float(got.abs().max()) > 1.0
+
+
+@pytest.mark.parametrize("fp16", [True, False])
+@pytest.mark.parametrize("B,ntok", [(1, 65), (3, 130), (10, 3601)])
+def test_gemm_rs_qkv_layout(cuda, B, ntok, fp16):
+    """gemm_rs.hip, operand-stationary kernel with the Q / K / V scatter at embed_dim 768 (12 heads): the [B, H, npad, 64] layout of
+    vision_transformer.py:82, Q pre-scaled, V as bf16 in either format (the one-plane attention's P.V product), pad rows untouched."""
+    H, D = 12, 768
+    M_, npad = B * ntok, (ntok + 63) // 64 * 64
+    lib = capi.lib()
+    capi.check(lib.dinoseg_set_option(b"op_fmt", int(fp16)))
+    try:
+        A, W, bias = seeded((M_, D), 221), seeded((3 * D, D), 222) * 0.05, seeded((3 * D,), 223)
+        Ap, Aq = _one_plane(A, fp16)
+        Wq = _one_plane(W, fp16)[1]
+        q = torch.zeros((B, H, npad, 64), dtype=torch.int16, device="cuda")
+        k, v = torch.zeros_like(q), torch.zeros_like(q)
+        qscale = 0.125 * LOG2E
+        Wp, bfr = _pack_rs(W, 0), _pack_rs_bias(bias)
+        capi.check(lib.dinoseg_op_gemm_rs(Ap.data_ptr(), D, Wp.data_ptr(), bias.data_ptr(), bfr.data_ptr(), M_, 3 * D, D, 4, None, None,
+                                          0, q.data_ptr(), k.data_ptr(), v.data_ptr(), ntok, npad, H, qscale, S()))
+        torch.cuda.synchronize()
+    finally:
+        capi.check(lib.dinoseg_set_option(b"op_fmt", 0))
+    ref = (Aq.double() @ Wq.double().t() + bias.double()).float().reshape(B, ntok, 3, H, 64).permute(2, 0, 3, 1, 4)
+    dt = torch.float16 if fp16 else torch.bfloat16
+    gq, gk, gv = q.view(dt).float(), k.view(dt).float(), v.view(torch.bfloat16).float()
+    tol = lambda r, d: (2.0 ** -11 if d == torch.float16 else 2.0 ** -8) * float(r.abs().max()) + 1e-4
+    assert float((gq[:, :, :ntok] - ref[0] * qscale).abs().max()) <= tol(ref[0] * qscale, dt)
+    assert float((gk[:, :, :ntok] - ref[1]).abs().max()) <= tol(ref[1], dt)
+    assert float((gv[:, :, :ntok] - ref[2]).abs().max()) <= tol(ref[2], torch.bfloat16)
+    assert torch.all(q[:, :, ntok:] == 0) and torch.all(k[:, :, ntok:] == 0) and torch.all(v[:, :, ntok:] == 0)
