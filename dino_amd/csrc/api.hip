@@ -281,7 +281,7 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
         return -1;
     };
     for (const LinSpec& sp : specs)
-        if (rs_kind(sp) >= 0) total += align_up((size_t)sp.N * sp.K * sizeof(bf16_t), 256) + align_up((size_t)sp.N * 16 * sizeof(bf16_t), 256);
+        if (rs_kind(sp) >= 0) total += align_up((size_t)sp.N * sp.K * sizeof(bf16_t), 256);
     if (mlp3_fusable) total += (size_t)h->cfg.n_blocks * align_up((size_t)mlp_fused3_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
     if (mlp_fusable)
         total += (size_t)h->cfg.n_blocks * (align_up((size_t)mlp_fused_pack_elems(Dm, Fh) * sizeof(bf16_t), 256) +
@@ -331,10 +331,6 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
             off += align_up((size_t)sp.N * sp.K * sizeof(bf16_t), 256);
             DSEG_TRY(launch_pack_rs(W(h, sp.wname), sp.N, sp.K, rs_kind(sp), dst, s, sp.fmt));
             h->packed_rs[sp.wname] = dst;
-            bf16_t* bdst = reinterpret_cast<bf16_t*>(h->wbuf + off);      // the bias as MFMA fragments (the operand-stationary kernel's accumulator init)
-            off += align_up((size_t)sp.N * 16 * sizeof(bf16_t), 256);
-            DSEG_TRY(launch_pack_rs_bias(W(h, sp.bname), sp.N, bdst, s, sp.fmt));
-            h->packed_rs[sp.bname] = bdst;
         }
     if (mlp3_fusable)
         for (int i = 0; i < h->cfg.n_blocks; ++i) {
@@ -556,8 +552,6 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
         if (options().gemm_rs && disp_M >= options().gemm_rs_min_rows && h->packed_rs.count(wname)) {
             GemmParams r = g;
             r.W = h->packed_rs.at(wname);
-            const std::string bname = wname.substr(0, wname.size() - 6) + "bias";
-            r.bias_frag = h->packed_rs.count(bname) ? h->packed_rs.at(bname) : nullptr;
             if (gemm_rs_supported(r)) return launch_gemm_rs(r, s);
         }
         return launch_gemm(g, s);
@@ -686,7 +680,8 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             a.v_bf16 = v_bf16;
             DSEG_PROF(DINOSEG_PROF_ATTN, DSEG_TRY(launch_attention(a, s)));
         }
-        const bool fuse_mlp3 = P == 2 && h->packed_mlp3.count(b) && mlp_fuse_wanted(h, disp_M);      // hi + lo planes: mlp_fused3.hip
+        const bool fuse_mlp3 = P == 2 && h->packed_mlp3.count(b) &&      // hi + lo planes: mlp_fused3.hip
+                               (options().mlp_fused == 2 || (options().mlp_fused == 1 && disp_M >= options().mlp_fused3_min_rows));
         const bool fuse_mlp = fuse_mlp3 || (h->packed_mlp.count(b) && mlp_fuse_wanted(h, disp_M));
         // (the fused MLP kernels take the attention output projection along: x += proj(ctx) + b, then the MLP, one launch)
         const bool fuse_proj = fuse_mlp && options().proj_fused && (fuse_mlp3 || (P == 1 && h->packed_proj.count(b)));
@@ -990,6 +985,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().qkv_fused3 = value ? 1 : 0;
         return 0;
     }
+    if (strcmp(key, "mlp_fused3_min_rows") == 0) {
+        dseg::options().mlp_fused3_min_rows = value;
+        return 0;
+    }
     if (strcmp(key, "mlp_fused_min_rows") == 0) {
         dseg::options().mlp_fused_min_rows = value;
         return 0;
@@ -1141,20 +1140,15 @@ extern "C" int dinoseg_op_pack_rs(const float* W, int32_t N, int32_t K, int32_t 
     return launch_pack_rs(W, N, K, kind, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), options().op_fmt);
 }
 
-extern "C" int dinoseg_op_pack_rs_bias(const float* bias, int32_t N, void* dst, void* stream) {
-    return launch_pack_rs_bias(bias, N, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), options().op_fmt);
-}
-
-extern "C" int dinoseg_op_gemm_rs(const void* A, int32_t lda, const void* Wp, const float* bias, const void* bias_frag, int32_t M, int32_t N,
-                                  int32_t K, int32_t epi, float* x_inout, void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok,
-                                  int32_t npad, int32_t heads, float qscale, void* stream) {
+extern "C" int dinoseg_op_gemm_rs(const void* A, int32_t lda, const void* Wp, const float* bias, int32_t M, int32_t N, int32_t K, int32_t epi,
+                                  float* x_inout, void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok, int32_t npad,
+                                  int32_t heads, float qscale, void* stream) {
     GemmParams g = {};
     g.A = reinterpret_cast<const bf16_t*>(A); g.lda = lda; g.W = reinterpret_cast<const bf16_t*>(Wp); g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.planes = 1; g.fmt = options().op_fmt; g.epi = epi;
     g.out_f32 = x_inout; g.ldo_f32 = N; g.out_bf16 = reinterpret_cast<bf16_t*>(out16); g.ldo = ldo;
     g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
     g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = heads * 64; g.qscale = qscale;
-    g.bias_frag = reinterpret_cast<const bf16_t*>(bias_frag);
     return launch_gemm_rs(g, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -15,32 +15,10 @@
 //                                     time from A (three rotating buffers); the last step stores each finished block (+ bias) and loads
 //                                     the next item's residual rows in its place.
 // Single-plane modes only (bf16 / fp16); the weights are re-packed once per refresh (launch_pack_rs).
-#include <type_traits>
-
-#include "mlp_common.h"
+#include "rs_common.h"
 
 namespace dseg {
 
-namespace rs {
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // (a native vector: HIP's uint4 is a struct, which an asm register operand cannot be)
-constexpr int NW = 4, BM = NW * 32, THREADS = NW * 64;
-constexpr int RING = 3;
-#ifndef RS_RA
-#define RS_RA 4
-#endif
-constexpr int RA = RS_RA, NFR = RA + 1;      // fragment read-ahead; fragment registers
-}  // namespace rs
-
-#ifndef RS_ST_SC1
-#define RS_ST_SC1 1
-#endif
-#ifndef RS_VM
-#define RS_VM 17      // gemm_bstat: operations younger than the pieces a step waits for: the previous step's twelve pieces + its bias fragment load + the four
-                      // row-group stores that one of the two steps in between has issued behind its pieces (odd steps store)
-#endif
-#ifndef RS_ABL
-#define RS_ABL 0      // timing ablations (wrong results): 1 no epilogue math, 2 no W DMA, 4 no MFMAs, 16 no fragment reads, 32 no global loads, 64 no global stores
-#endif
 
 // W [N][K] fp32 -> kind 0 (bstat): [tile n = N / 32][fragment ks = K / 16][64 lanes][8]: A row = output feature 32 n + sigma23(lane & 31),
 //                                  k = 16 ks + 8 (lane >> 5) + e
@@ -67,34 +45,6 @@ __global__ __launch_bounds__(256) void pack_rs_kernel(const float* __restrict__ 
     }
 }
 
-// bias [N] fp32 -> A fragments [tile n][64 lanes][8]: lane (i, h = 0) carries bias[32 n + sigma23(i)] as three 16-bit terms (hi, mid, lo: their
-// sum is the fp32 value exactly) at k = 0, 1, 2; everything else zero
-__global__ __launch_bounds__(256) void pack_rs_bias_kernel(const float* __restrict__ bias, int N, bf16_t* __restrict__ dst, int fmt) {
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (N / 32) * 512; idx += gridDim.x * blockDim.x) {
-        const int e = idx & 7, lane = (idx >> 3) & 63, n = idx >> 9;
-        bf16_t v = 0;
-        if ((lane >> 5) == 0 && e < 3) {
-            const float b = bias[n * 32 + attn::sigma23(lane & 31)];
-            const bf16_t hi = pack1(b, fmt);
-            const float r1 = b - unpack1(hi, fmt);
-            const bf16_t mid = pack1(r1, fmt);
-            const bf16_t lo = pack1(r1 - unpack1(mid, fmt), fmt);
-            v = e == 0 ? hi : (e == 1 ? mid : lo);
-        }
-        dst[idx] = v;
-    }
-}
-
-int launch_pack_rs_bias(const float* bias, int N, bf16_t* dst, hipStream_t s, int fmt) {
-    if (!bias || !dst || N % 32 != 0) {
-        dinoseg_set_error("pack_rs_bias: null pointer or N=%d not a multiple of 32", N);
-        return -1;
-    }
-    hipLaunchKernelGGL(pack_rs_bias_kernel, dim3(64), dim3(256), 0, s, bias, N, dst, fmt);
-    DSEG_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 int launch_pack_rs(const float* W, int N, int K, int kind, bf16_t* dst, hipStream_t s, int fmt) {
     if (!W || !dst || N % 32 != 0 || K % 64 != 0 || (kind != 0 && kind != 1) || (kind == 1 && N != 768)) {
         dinoseg_set_error("pack_rs: null pointer or unsupported shape N=%d K=%d kind=%d", N, K, kind);
@@ -105,132 +55,46 @@ int launch_pack_rs(const float* W, int N, int K, int kind, bf16_t* dst, hipStrea
     return 0;
 }
 
-// ---- shared: one step = NG MFMAs on the NG fragments of the slot at ring position rpos; this wave's NG / 4 pieces of the slot two steps
-// ahead go out in the odd gaps; mma(gap tag, fragment) / valu(gap tag) as in mlp_fused3.hip
-template <int NG, int VM, class Stream, class Pre, class Mma, class Valu>
-__device__ __forceinline__ void rs_step(Stream& st, uint32_t frag_rd, uint32_t lane16, Pre&& pre, Mma&& mma, Valu&& valu) {
-    using namespace rs;
-    constexpr int SLOTB = NG * 1024, PW = NG / NW;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");      // this slot's pieces (issued two steps ago) have landed ...
-    __builtin_amdgcn_s_barrier();                                   // ... every wave's; and every wave has left the slot refilled below
-    pre();                                                          // (what needs the wait above: operands loaded by uncounted instructions)
-    constexpr int NGRP = (PW + 3) / 4;
-    uint64_t gsb[NGRP];
-    uint32_t gld[NGRP];
-    {
-        const uint64_t sb = st.wp + (uint64_t)st.sn * SLOTB + st.piece0;
-        const uint32_t ld = st.lds_base + (uint32_t)st.ipos * SLOTB + st.piece0;
-#pragma unroll
-        for (int g = 0; g < NGRP; ++g) {
-            const uint64_t v = sb + g * 4096;
-            gsb[g] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) |
-                     ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
-            gld[g] = __builtin_amdgcn_readfirstlane(ld + g * 4096);
-        }
-        st.sn = st.sn + 1 == st.nslots ? 0 : st.sn + 1;
-        st.ipos = st.ipos + 1 == RING ? 0 : st.ipos + 1;
-    }
-    const uint32_t a = frag_rd + (uint32_t)st.rpos * SLOTB;
-    st.rpos = st.rpos + 1 == RING ? 0 : st.rpos + 1;
-    bf16x8 fr[NFR];
-    auto issue_read = [&](auto j_tag) __attribute__((always_inline)) {
-        constexpr int J = decltype(j_tag)::value;
-        if (RS_ABL & 16) return;
-        mf_rd<J * 1024>(fr[J % NFR], a);
-    };
-    mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
-    mf_for(std::make_integer_sequence<int, NG>{}, [&](auto j_tag) __attribute__((always_inline)) {
-        constexpr int J = decltype(j_tag)::value;
-        if constexpr (J + RA < NG) issue_read(std::integral_constant<int, J + RA>{});
-        if (RS_ABL & 16) asm volatile("" : "=v"(fr[J % NFR]));
-        else mf_wait<(NG - 1 - J < RA ? NG - 1 - J : RA)>();
-        mma(j_tag, fr[J % NFR]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr ((J & 1) == 1 && J < 2 * PW) {
-            constexpr int Q = J >> 1;
-            if (!(RS_ABL & 2)) mf_dma1<(Q & 3) * 1024>(lane16, gsb[Q >> 2], gld[Q >> 2]);
-        }
-        valu(j_tag);
-        __builtin_amdgcn_sched_barrier(0);
-    });
-}
-
-struct RsStream {
-    uint64_t wp;
-    uint32_t lds_base, piece0;
-    int sn, ipos, rpos, nslots;
-};
-
-template <int NG>
-__device__ __forceinline__ void rs_prologue(RsStream& st, uint32_t lane16) {
-    using namespace rs;
-    constexpr int SLOTB = NG * 1024, PW = NG / NW;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {      // what the two steps before the first one would have issued
-        const uint64_t sb = st.wp + (uint64_t)st.sn * SLOTB + st.piece0;
-        const uint32_t ld = __builtin_amdgcn_readfirstlane(st.lds_base + (uint32_t)st.ipos * SLOTB + st.piece0);
-        const uint64_t sbu = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb) |
-                             ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32);
-        if (!(RS_ABL & 2))
-#pragma unroll
-            for (int g = 0; g < PW / 4; ++g) mf_dma4(lane16, sbu + g * 4096, ld + g * 4096);
-        st.sn = st.sn + 1 == st.nslots ? 0 : st.sn + 1;
-        st.ipos = st.ipos + 1 == RING ? 0 : st.ipos + 1;
-    }
-}
-
 // ================================================================================================ gemm_bstat: qkv / fc1
 // EPI_GELU: out16[M][N] = gelu_fast(A W^T + b) (one plane, FMT);  EPI_QKV: Q (pre-scaled) / K / V [B, heads, npad, 64], V bf16 whatever FMT is.
-// The bias of tile n arrives as an A fragment (its fp32 value split exactly into three 16-bit terms at k = 0, 1, 2: launch_pack_rs_bias) that
-// one MFMA against a ones fragment turns into the accumulators' initial value -- no bias table in LDS, no VALU adds.
-// Output: the packed 64-byte rows of two consecutive tiles (= 64 features = 128 bytes per row: one head of Q / K / V, or 64 hidden units) meet in a
-// wave-private 4-KiB LDS patch ([32 rows][8 chunks of 16 bytes], chunk ^ (row & 7)) and leave as whole 128-byte row segments, 8 rows per store
-// instruction: 32-byte segments (what the accumulator layout gives directly) write at 2.4 TB/s against 5.3 (profiles/r05_gemm_epilogue_stores.md),
-// and a 350-MB store stream at that rate stalls the weight ring behind it (one in-order vmcnt for stores and LDS-DMA).
+// The epilogue stores 16 bytes per lane straight from the packed accumulator values (a lane holds 8 consecutive features of its row twice).
+// (Round 6 also built the output through a wave-private LDS patch -- whole 128-byte row segments -- with the bias as an MFMA fragment loaded by
+//  an uncounted asm instruction: the same time, launch for launch (profiles/r06_gemm_rs.md), and two hazards hipcc does not pad around inline asm
+//  on the way: a VALU-written SGPR pair read by an asm VMEM instruction needs `s_nop 4` in front, an asm store's data registers two wait states
+//  behind.  The plain form below has neither.)
 template <int FMT, int EPI, int KS>
 __global__ __launch_bounds__(rs::THREADS, 1) void gemm_bstat_kernel(GemmParams p) {
     using namespace rs;
     static_assert(KS == 48, "the gap programs below are written for 48-gap steps (K = 768)");
-    constexpr int SLOTB = KS * 1024, PATCH_OFF = RING * SLOTB;
+    constexpr int SLOTB = KS * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = p.M, ntiles = p.N / 32;
     const int nitems = (M + BM - 1) / BM;
     if ((int)blockIdx.x >= nitems) return;
+    float* const sBias = reinterpret_cast<float*>(smem + RING * SLOTB);
+    for (int i = tid; i < p.N / 4; i += THREADS) reinterpret_cast<f32x4*>(sBias)[i] = reinterpret_cast<const f32x4*>(p.bias)[i];
     RsStream st;
     st.wp = reinterpret_cast<uint64_t>(p.W);
     st.lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
     st.piece0 = (uint32_t)wave * (KS / NW) * 1024;
     st.sn = 0; st.ipos = 0; st.rpos = 0; st.nslots = ntiles;
     rs_prologue<KS>(st, (uint32_t)(tid & 63) * 16);
-    const uint64_t bfr = reinterpret_cast<uint64_t>(p.bias_frag);
-    // bias fragment of tile t: 16 bytes per lane, by an instruction the compiler does not count (it rides in the ring's vmcnt order: issued in
-    // gap 0 of step t - 1, it is older than everything the wait at the start of step t leaves in flight)
-    auto load_bias_frag = [&](bf16x8& dst, int t, uint32_t lane16) __attribute__((always_inline)) {
-        const uint64_t v = bfr + (uint64_t)t * 1024;
-        const uint64_t sb = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) |
-                            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
-        // (s_nop 4: the base comes from v_readfirstlane -- a VALU write of an SGPR read by a VMEM instruction needs five wait states, and hipcc
-        //  pads nothing in front of an asm statement's operands)
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane16), "s"(sb) : "memory");
-    };
-    bf16x8 bf0, bf1;      // bias fragments of the even / odd tile in flight
-    load_bias_frag(bf0, 0, (uint32_t)(tid & 63) * 16);
+    __syncthreads();
 
     bf16x8 xn[KS];
     f32x16 Z0, Z1;
-    u32x4 rb0, rb1, rb2, rb3;      // a finished pair of tiles on its way from the patch to memory (scalars: asm operands cannot be array elements reached through a reference)
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         uint32_t zero = 0;
         asm volatile("" : "+v"(zero));
         const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
         const uint32_t lane16_i = lane_i * 16, lh_i = lane_i >> 5, lr_i = lane_i & 31;
         const uint32_t frag_rd_i = st.lds_base + lane16_i;
-        // this lane's row as the B operand
+        const int r_ = item * BM + wave * 32 + (int)lr_i;
+        const int rc = r_ < M ? r_ : M - 1;      // (clamped: a row past the end is a copy of row M - 1 and rewrites its bytes)
         {
-            const int r = item * BM + wave * 32 + (int)lr_i;
-            const bf16_t* ar = p.A + (long)(r < M ? r : M - 1) * p.lda + lh_i * 8;
+            const bf16_t* ar = p.A + (long)rc * p.lda + lh_i * 8;
             mf_for(std::make_integer_sequence<int, KS>{}, [&](auto k_tag) __attribute__((always_inline)) {
                 constexpr int k = decltype(k_tag)::value;
                 uint4 u = {0x3c003c00u, 0x3c003c00u, (uint32_t)k, 0u};
@@ -238,27 +102,13 @@ __global__ __launch_bounds__(rs::THREADS, 1) void gemm_bstat_kernel(GemmParams p
                 xn[k] = __builtin_bit_cast(bf16x8, u);
             });
         }
-        // patch addresses: this lane writes row lr, chunk (4 parity + 2 g + lh) ^ (lr & 7); it reads back row 8 i + (lane >> 3), chunk
-        // (lane & 7) ^ (row & 7), and stores that row's 16 bytes
-        const uint32_t patch = st.lds_base + PATCH_OFF + (uint32_t)wave * 4096;
-        auto aw_of = [&](uint32_t c) __attribute__((always_inline)) { return patch + lr_i * 128 + ((2 * c + lh_i) ^ (lr_i & 7)) * 16; };      // c = 2 parity + g
-        const uint32_t aw0 = aw_of(0), aw1 = aw_of(1), aw2 = aw_of(2), aw3 = aw_of(3);
-        const uint32_t ard = patch + (lane_i >> 3) * 128 + ((lane_i & 7) ^ ((lane_i >> 3) & 7)) * 16;                // + 1024 i
-        // the four rows this lane stores (clamped: rows past the end are copies of row M - 1 and rewrite its bytes)
-        long orow[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = item * BM + wave * 32 + 8 * i + (int)(lane_i >> 3);
-            const int rc = r < M ? r : M - 1;
-            if constexpr (EPI == EPI_QKV) {
-                const int fr_ = rc / p.ntok, tok_ = rc - fr_ * p.ntok;
-                orow[i] = ((long)fr_ * p.heads * p.npad + tok_) * 64 + (lane_i & 7) * 8;
-            } else {
-                orow[i] = (long)rc * p.ldo + (lane_i & 7) * 8;
-            }
+        long orow;      // destination of this lane's row
+        if constexpr (EPI == EPI_QKV) {
+            const int fr_ = rc / p.ntok, tok_ = rc - fr_ * p.ntok;
+            orow = ((long)fr_ * p.heads * p.npad + tok_) * 64 + lh_i * 8;
+        } else {
+            orow = (long)rc * p.ldo + lh_i * 8;
         }
-        constexpr uint32_t ONE = FMT == FMT_FP16 ? 0x3C00u : 0x3F80u;
-        const uint4 ones_u = {lh_i == 0 ? (ONE << 16 | ONE) : 0u, lh_i == 0 ? ONE : 0u, 0u, 0u};     // k = 0, 1, 2 are 1.0
 
         float ez[16], eu[16], eq[16];
         uint32_t zp[8];
@@ -278,18 +128,14 @@ __global__ __launch_bounds__(rs::THREADS, 1) void gemm_bstat_kernel(GemmParams p
             if constexpr (I == 7) ez[N] = __builtin_amdgcn_rcpf(ez[N]);
             if constexpr (I == 8) ez[N] = z[N] * ez[N];
         };
-        // the epilogue of tile tq (values in z; PAR = tq & 1), gap G of the step that carries it: element n's instruction i at gap START(n) + i, a
-        // pair packed one gap after its odd element; the packed row halves into the patch at gaps 42 / 43; an odd tile completes a pair: its four
-        // 1-KiB groups of rows come back at gaps 44 .. 47
-        auto epilogue_gap = [&](auto g_tag, auto par_tag, const f32x16& z, int tq) __attribute__((always_inline)) {
-            constexpr int G = decltype(g_tag)::value, PAR = decltype(par_tag)::value;
+        // the epilogue of tile tq (values in z), gap G of the step that carries it: element n's instruction i at gap START(n) + i, a pair packed one
+        // gap after its odd element, the two 16-byte stores in the last two gaps (behind the step's pieces)
+        auto epilogue_gap = [&](auto g_tag, const f32x16& z, int tq) __attribute__((always_inline)) {
+            constexpr int G = decltype(g_tag)::value;
             constexpr int NOPS = EPI == EPI_GELU ? 9 : 1;
-            // (named here: clang does not capture a variable whose only use is an asm operand inside `if constexpr`)
-            const uint32_t ard_ = ard, aw0_ = aw0, aw1_ = aw1, aw2_ = aw2, aw3_ = aw3;
-            u32x4 &r0_ = rb0, &r1_ = rb1, &r2_ = rb2, &r3_ = rb3;
             mf_for(std::make_integer_sequence<int, 16>{}, [&](auto n_tag) __attribute__((always_inline)) {
                 constexpr int N = decltype(n_tag)::value;
-                constexpr int START = EPI == EPI_GELU ? 2 * N + 1 : 2 * N + 4;
+                constexpr int START = EPI == EPI_GELU ? (5 * N) / 2 + 1 : 2 * N + 8;
                 if constexpr (G >= START && G < START + NOPS) {
                     if constexpr (EPI == EPI_GELU) gelu_op(n_tag, std::integral_constant<int, G - START>{}, z);
                     else ez[N] = z[N] * (tq < p.dmodel / 32 ? p.qscale : 1.0f);
@@ -304,85 +150,60 @@ __global__ __launch_bounds__(rs::THREADS, 1) void gemm_bstat_kernel(GemmParams p
                     }
                 }
             });
-            if constexpr (G == 42 || G == 43) {
-                constexpr int GG = G - 42;
-                const u32x4 u = {zp[4 * GG], zp[4 * GG + 1], zp[4 * GG + 2], zp[4 * GG + 3]};
-                constexpr int C = 2 * PAR + GG;
-                const uint32_t awc = C == 0 ? aw0_ : (C == 1 ? aw1_ : (C == 2 ? aw2_ : aw3_));
-                asm volatile("ds_write_b128 %0, %1" ::"v"(awc), "v"(u) : "memory");
-            }
-            if constexpr (PAR == 1 && G >= 44) {
-                constexpr int I = G - 44;
-                if constexpr (I == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(r0_) : "v"(ard_));
-                if constexpr (I == 1) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(r1_) : "v"(ard_));
-                if constexpr (I == 2) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(r2_) : "v"(ard_));
-                if constexpr (I == 3) asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(r3_) : "v"(ard_));
+            if constexpr (G >= KS - 2) {
+                constexpr int GG = G - (KS - 2);
+                bf16_t* dst;
+                if constexpr (EPI == EPI_QKV) {
+                    const int nd = p.dmodel / 32, which = tq / nd, hb = tq - which * nd;
+                    dst = (which == 0 ? p.q : (which == 1 ? p.k : p.v)) + orow + (long)(hb >> 1) * p.npad * 64 + (hb & 1) * 32 + GG * 16;
+                } else {
+                    dst = p.out_bf16 + orow + tq * 32 + GG * 16;
+                }
+                const uint4 u = {zp[4 * GG], zp[4 * GG + 1], zp[4 * GG + 2], zp[4 * GG + 3]};
+                if (!(RS_ABL & 64)) *reinterpret_cast<uint4*>(dst) = u;
+                else asm volatile("" ::"v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w), "v"(dst));
             }
         };
-        // the finished pair pp (tiles 2 pp, 2 pp + 1) from rb to memory: group i = rows 8 i .. 8 i + 7 of the wave, 128 bytes each
-        auto store_group = [&](auto i_tag, int pp) __attribute__((always_inline)) {
-            constexpr int I = decltype(i_tag)::value;
-            bf16_t* dst;
-            if constexpr (EPI == EPI_QKV) {
-                const int which = pp / p.heads, head = pp - which * p.heads;
-                dst = (which == 0 ? p.q : (which == 1 ? p.k : p.v)) + orow[I] + (long)head * p.npad * 64;
-            } else {
-                dst = p.out_bf16 + orow[I] + pp * 64;
-            }
-            const u32x4 v = I == 0 ? rb0 : (I == 1 ? rb1 : (I == 2 ? rb2 : rb3));
-            // sc1: a write-through store that does not keep its line in the XCD's L2 (MI355X_MICROARCH.md, stores of each flavour) -- the 350-MB
-            // output stream would otherwise push the weight tiles every CU re-reads out of the 4-MiB L2 (served by the Infinity Cache at half the rate)
-            if (RS_ABL & 64) asm volatile("" ::"v"(v), "v"(dst));
-            else if (RS_ST_SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-            else *reinterpret_cast<u32x4*>(dst) = v;
-        };
-        // step n (PAR = n & 1): z_nxt = bias(n) + W_n . xn^T; in the gaps: the bias fragment of tile n + 1, the epilogue of tile n - 1 (z_cur), and --
-        // odd steps -- the stores of the pair the previous step read back
-        auto step = [&](f32x16& z_nxt, const f32x16& z_cur, int n, auto par_tag, auto epi_tag) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par_tag)::value;
-            constexpr bool EPI_ON = decltype(epi_tag)::value;
-            rs_step<KS, RS_VM>(
-                st, frag_rd_i, lane16_i,
-                [&]() __attribute__((always_inline)) {
-                    // the bias fragment was loaded in gap 0 of the previous step (or ahead of the item's row loads): older than the twelve
-                    // operations the step's wait leaves in flight -- it has landed
-                    f32x16 zz;
+        auto z_bias = [&](f32x16& z, int n) __attribute__((always_inline)) {
+            const float* bp = sBias + n * 32 + lh_i * 8;
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(bp), c1 = *reinterpret_cast<const f32x4*>(bp + 4);
+            const f32x4 c2 = *reinterpret_cast<const f32x4*>(bp + 16), c3 = *reinterpret_cast<const f32x4*>(bp + 20);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) zz[r] = 0.f;
-                    if (!(RS_ABL & 4)) z_nxt = mfma32f<FMT>(PAR ? bf1 : bf0, __builtin_bit_cast(bf16x8, ones_u), zz);
-                    else z_nxt = zz;
-                    __builtin_amdgcn_sched_barrier(0);
-                },
+            for (int e = 0; e < 4; ++e) {
+                z[e] = c0[e];
+                z[4 + e] = c1[e];
+                z[8 + e] = c2[e];
+                z[12 + e] = c3[e];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        // step n: z_nxt = bias(n) + W_n . xn^T; the epilogue of tile n - 1 (z_cur) in the gaps
+        auto step = [&](f32x16& z_nxt, const f32x16& z_cur, int n, auto epi_tag) __attribute__((always_inline)) {
+            constexpr bool EPI_ON = decltype(epi_tag)::value;
+            z_bias(z_nxt, n);
+            // (vmcnt 12: the previous step's pieces may stay in flight; its two stores, younger still, then count among the twelve -- a conservative wait)
+            rs_step<KS, KS / NW>(
+                st, frag_rd_i, lane16_i, []() __attribute__((always_inline)) {},
                 [&](auto j_tag, const bf16x8& fr) __attribute__((always_inline)) {
                     constexpr int J = decltype(j_tag)::value;
                     if (!(RS_ABL & 4)) z_nxt = mfma32f<FMT>(fr, xn[J], z_nxt);
                 },
                 [&](auto g_tag) __attribute__((always_inline)) {
-                    constexpr int G = decltype(g_tag)::value;
-                    if constexpr (G == 0) load_bias_frag(PAR ? bf0 : bf1, n + 1 < ntiles ? n + 1 : 0, lane16_i);
-                    if constexpr (EPI_ON) epilogue_gap(g_tag, std::integral_constant<int, 1 - PAR>{}, z_cur, n - 1);
-                    if constexpr (EPI_ON && PAR == 1 && G >= 24 && G < 28) {
-                        if (n >= 3) store_group(std::integral_constant<int, G - 24>{}, (n - 3) >> 1);
-                    }
+                    if constexpr (EPI_ON) epilogue_gap(g_tag, z_cur, n - 1);
                 });
         };
-        using E0 = std::integral_constant<int, 0>;
-        using E1 = std::integral_constant<int, 1>;
         // (ntiles is even: qkv 72 / fc1 96 tiles)
-        step(Z0, Z0, 0, E0{}, std::false_type{});
+        step(Z0, Z0, 0, std::false_type{});
 #pragma unroll 1
         for (int n = 1; n + 1 < ntiles; n += 2) {
-            step(Z1, Z0, n, E1{}, std::true_type{});
-            step(Z0, Z1, n + 1, E0{}, std::true_type{});
+            step(Z1, Z0, n, std::true_type{});
+            step(Z0, Z1, n + 1, std::true_type{});
         }
-        step(Z1, Z0, ntiles - 1, E1{}, std::true_type{});
-        // the last tile's epilogue and the last pair's stores have no step to ride in
+        step(Z1, Z0, ntiles - 1, std::true_type{});
         mf_for(std::make_integer_sequence<int, KS>{}, [&](auto g_tag) __attribute__((always_inline)) {
             __builtin_amdgcn_sched_barrier(0);
-            epilogue_gap(g_tag, E1{}, Z1, ntiles - 1);
+            epilogue_gap(g_tag, Z1, ntiles - 1);
         });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mf_for(std::make_integer_sequence<int, 4>{}, [&](auto i_tag) __attribute__((always_inline)) { store_group(i_tag, (ntiles - 2) >> 1); });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -546,15 +367,15 @@ __global__ __launch_bounds__(rs::THREADS, 1) void gemm_cstat_kernel(GemmParams p
 bool gemm_rs_supported(const GemmParams& p) {
     if (p.planes != 1 || p.bias == nullptr || p.M < 1 || p.lda % 8 != 0 || p.resid != nullptr || p.aux_out != nullptr || p.ksplit > 1) return false;
     if (p.epi == EPI_RESID) return p.N == 768 && p.K % 192 == 0 && p.K >= 576 && p.ldo_f32 == p.N && p.out_f32 != nullptr;
-    if (p.epi == EPI_GELU) return p.K == 768 && p.N % 64 == 0 && p.N >= 128 && p.ldo % 8 == 0 && p.bias_frag != nullptr && p.out_bf16 != nullptr;
-    if (p.epi == EPI_QKV) return p.K == 768 && p.dmodel == 768 && p.N == 3 * p.dmodel && p.heads * 64 == p.dmodel && p.bias_frag != nullptr && p.q && p.k && p.v;
+    if (p.epi == EPI_GELU) return p.K == 768 && p.N % 64 == 0 && p.N >= 128 && p.ldo % 8 == 0 && p.N * 4 <= 16 * 1024 && p.out_bf16 != nullptr;
+    if (p.epi == EPI_QKV) return p.K == 768 && p.dmodel == 768 && p.N == 3 * p.dmodel && p.heads * 64 == p.dmodel && p.q && p.k && p.v;
     return false;
 }
 
 template <int FMT>
 static int launch_gemm_rs_fmt(const GemmParams& p, hipStream_t s) {
     using namespace rs;
-    constexpr int LDS_B = RING * 48 * 1024 + NW * 4096, LDS_C = RING * 48 * 1024 + 4 * 1024;
+    constexpr int LDS_B = RING * 48 * 1024 + 16 * 1024, LDS_C = RING * 48 * 1024 + 4 * 1024;
     static PerDeviceOnce once;
     if (once.first()) {
         auto opt_in = [](const void* fn, int bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };

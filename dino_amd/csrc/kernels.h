@@ -46,7 +46,6 @@ struct GemmParams {
     int v_bf16;                                 // EPI_QKV with fp16 hi + lo planes: write V as bf16 hi + lo planes (AttnParams::v_bf16)
     int dispatch_rows;                          // launch_gemm's kernel choice is made for this many rows instead of M when > 0: the two
                                                 // half-batches of a split forward take the route of the whole batch (same summation order)
-    const bf16_t* bias_frag;                    // gemm_rs.hip (EPI_GELU / EPI_QKV): the bias as MFMA A fragments (launch_pack_rs_bias), [N / 32][64][8]
     int ksplit;                                 // >1: split the K loop over grid.y (EPI_ATOMIC, or EPI_PLAIN partial tiles)
     long split_stride;                          // EPI_PLAIN with ksplit > 1: slice y writes out_f32 + y * split_stride (floats)
 };
@@ -59,7 +58,6 @@ int launch_gemm_big(const GemmParams& p, hipStream_t s);   // 256x384 persistent
 // (kind 0 for EPI_GELU / EPI_QKV: K = 768; kind 1 for EPI_RESID: N = 768, in place on out_f32)
 bool gemm_rs_supported(const GemmParams& p);
 int launch_pack_rs(const float* W, int N, int K, int kind, bf16_t* dst, hipStream_t s, int fmt);
-int launch_pack_rs_bias(const float* bias, int N, bf16_t* dst, hipStream_t s, int fmt);      // N * 16 elements
 int launch_gemm_rs(const GemmParams& p, hipStream_t s);
 
 // LayerNorm-fused A-stationary GEMM for qkv / fc1 (gemm_ln.hip): X fp32 rows are normalised in the prologue, W streams
@@ -145,6 +143,7 @@ struct Options {
                              // ragged last q-tile OFF (an A/B switch, results unchanged)
     int mlp_fused = 1;       // the MLP half of a block as one launch (mlp_fused2.hip): 0 never, 1 for >= mlp_fused_min_rows rows, 2 wherever supported
     int mlp_fused_min_rows = 12000;      // (4 frames @480: +3 %; 6 frames: +18 % with the projection inside; 2 frames: even)
+    int mlp_fused3_min_rows = 10000;     // hi + lo planes (mlp_fused3.hip): 3 frames @480 +10 %, 4: +16 %, 8: +19 %; 2 frames -17 %, 1: -36 % (tools/m3_thresh.sh)
     int mlp_stagger = 0;     // experiment: > 0 = one workgroup per CU, those with one item fewer start up to this many x 3.9 us late
     int mlp_grid = 0;        // workgroups of the fused MLP launch (0 = the fewest that need no extra round: mlp_fused2.hip)
     int qkv_fused = 0;       // 1: ... and LayerNorm1 + qkv of the NEXT block at its end (blocks 1.. then have no LN+qkv launch); measured

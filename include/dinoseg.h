@@ -285,10 +285,9 @@ int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* Wproj, cons
  * :63 + :123 / :135.  Wp: the fp32 weight [N][K] re-packed by dinoseg_op_pack_rs (N * K 16-bit elements; kind 0 for epi 2 / 4, kind 1 for epi 1).
  * dinoseg_forward uses them for ViT-B/8 batches of >= option "gemm_rs_min_rows" rows (option "gemm_rs", default 1). */
 int dinoseg_op_pack_rs(const float* W, int32_t N, int32_t K, int32_t kind, void* dst, void* stream);
-int dinoseg_op_pack_rs_bias(const float* bias, int32_t N, void* dst, void* stream);      /* N * 16 16-bit elements: the bias as MFMA fragments (epi 2 / 4) */
-int dinoseg_op_gemm_rs(const void* A, int32_t lda, const void* Wp, const float* bias, const void* bias_frag, int32_t M, int32_t N, int32_t K,
-                       int32_t epi, float* x_inout, void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok, int32_t npad,
-                       int32_t heads, float qscale, void* stream);
+int dinoseg_op_gemm_rs(const void* A, int32_t lda, const void* Wp, const float* bias, int32_t M, int32_t N, int32_t K, int32_t epi,
+                       float* x_inout, void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok, int32_t npad, int32_t heads,
+                       float qscale, void* stream);
 
 /* The same fusion on hi + lo operand planes (the parity modes; mlp_fused3.hip), one launch for
  *     X += ctx . Wproj^T + bproj;   X += fc2(gelu(fc1(LayerNorm(X))))      (vision_transformer.py:104-105, :123, :135 -> :59-65)

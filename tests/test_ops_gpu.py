@@ -965,12 +965,6 @@ def _pack_rs(W: torch.Tensor, kind: int) -> torch.Tensor:
     return out
 
 
-def _pack_rs_bias(bias: torch.Tensor) -> torch.Tensor:
-    out = torch.empty((bias.numel() * 16,), dtype=torch.int16, device="cuda")
-    capi.check(capi.lib().dinoseg_op_pack_rs_bias(bias.data_ptr(), bias.numel(), out.data_ptr(), S()))
-    return out
-
-
 @pytest.mark.parametrize("fp16", [True, False])
 @pytest.mark.parametrize("M_,K", [(128, 768), (77, 768), (128 * 5 + 33, 3072), (128 * 300 + 19, 768), (128 * 260 + 1, 3072)])
 def test_gemm_rs_residual(cuda, M_, K, fp16):
@@ -989,7 +983,7 @@ def test_gemm_rs_residual(cuda, M_, K, fp16):
         Wq = _one_plane(W, fp16)[1]
         got = X.clone()
         Wp = _pack_rs(W, 1)
-        capi.check(lib.dinoseg_op_gemm_rs(Ap.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), None, M_, N, K, capi.EPI_RESID,
+        capi.check(lib.dinoseg_op_gemm_rs(Ap.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), M_, N, K, capi.EPI_RESID,
                                           got.data_ptr(), None, 0, None, None, None, 0, 0, 0, 0.0, S()))
         torch.cuda.synchronize()
     finally:
@@ -1018,8 +1012,8 @@ def test_gemm_rs_gelu(cuda, M_, fp16):
         Ap, Aq = _one_plane(A, fp16)
         Wq = _one_plane(W, fp16)[1]
         out = torch.zeros((M_, N), dtype=torch.int16, device="cuda")
-        Wp, bfr = _pack_rs(W, 0), _pack_rs_bias(bias)
-        capi.check(lib.dinoseg_op_gemm_rs(Ap.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), bfr.data_ptr(), M_, N, K, capi.EPI_GELU, None,
+        Wp = _pack_rs(W, 0)
+        capi.check(lib.dinoseg_op_gemm_rs(Ap.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), M_, N, K, capi.EPI_GELU, None,
                                           out.data_ptr(), N, None, None, None, 0, 0, 0, 0.0, S()))
         torch.cuda.synchronize()
     finally:
@@ -1049,8 +1043,8 @@ def test_gemm_rs_qkv_layout(cuda, B, ntok, fp16):
         q = torch.zeros((B, H, npad, 64), dtype=torch.int16, device="cuda")
         k, v = torch.zeros_like(q), torch.zeros_like(q)
         qscale = 0.125 * LOG2E
-        Wp, bfr = _pack_rs(W, 0), _pack_rs_bias(bias)
-        capi.check(lib.dinoseg_op_gemm_rs(Ap.data_ptr(), D, Wp.data_ptr(), bias.data_ptr(), bfr.data_ptr(), M_, 3 * D, D, 4, None, None,
+        Wp = _pack_rs(W, 0)
+        capi.check(lib.dinoseg_op_gemm_rs(Ap.data_ptr(), D, Wp.data_ptr(), bias.data_ptr(), M_, 3 * D, D, 4, None, None,
                                           0, q.data_ptr(), k.data_ptr(), v.data_ptr(), ntok, npad, H, qscale, S()))
         torch.cuda.synchronize()
     finally:

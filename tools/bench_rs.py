@@ -39,15 +39,13 @@ for name, N, K, epi in (("qkv", 3 * D, D, 4), ("proj", D, D, capi.EPI_RESID), ("
     bias = seeded((N,), 3) * 0.1
     Wp = torch.empty((N * K,), dtype=torch.int16, device="cuda")
     capi.check(lib.dinoseg_op_pack_rs(W.data_ptr(), N, K, 1 if epi == capi.EPI_RESID else 0, Wp.data_ptr(), S()))
-    bfr = torch.empty((N * 16,), dtype=torch.int16, device="cuda")
-    capi.check(lib.dinoseg_op_pack_rs_bias(bias.data_ptr(), N, bfr.data_ptr(), S()))
     X = torch.zeros((M, N), device="cuda") if epi == capi.EPI_RESID else None
     O = torch.zeros((M, N), dtype=torch.int16, device="cuda") if epi == capi.EPI_GELU else None
     q = torch.zeros((B, H, npad, 64), dtype=torch.int16, device="cuda")
     k, v = torch.zeros_like(q), torch.zeros_like(q)
 
     def run_rs():
-        capi.check(lib.dinoseg_op_gemm_rs(A.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), bfr.data_ptr(), M, N, K, epi, capi.ptr(X), capi.ptr(O), N,
+        capi.check(lib.dinoseg_op_gemm_rs(A.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), M, N, K, epi, capi.ptr(X), capi.ptr(O), N,
                                           q.data_ptr(), k.data_ptr(), v.data_ptr(), ntok, npad, H, 0.18, S()))
 
     def run_big():
