@@ -276,6 +276,8 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     // one-plane modes of the wide model: fragment-order copies of the four block linears for the row-stationary GEMMs (gemm_rs.hip)
     auto rs_kind = [&](const LinSpec& sp) -> int {
         if (!options().gemm_rs || h->planes != 1 || Dm != 768 || sp.wname.rfind("dino.blocks.", 0) != 0) return -1;      // (read at refresh time)
+        const int bit = sp.wname.find("mlp.fc1.weight") != std::string::npos ? 1 : sp.wname.find("attn.qkv.weight") != std::string::npos ? 2 : 4;
+        if (!(options().gemm_rs & bit)) return -1;                                                                              // (bit set: 1 fc1, 2 qkv, 4 proj + fc2)
         if (sp.K == 768 && (sp.wname.find("attn.qkv.weight") != std::string::npos || sp.wname.find("mlp.fc1.weight") != std::string::npos)) return 0;
         if (sp.N == 768 && sp.K % 192 == 0 && (sp.wname.find("attn.proj.weight") != std::string::npos || sp.wname.find("mlp.fc2.weight") != std::string::npos)) return 1;
         return -1;
@@ -974,7 +976,7 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
     }
     if (strcmp(key, "mlp_variant") == 0) return 0;      // (accepted and ignored: the one-wave-per-SIMD build was removed in round 4)
     if (strcmp(key, "gemm_rs") == 0) {
-        dseg::options().gemm_rs = value ? 1 : 0;
+        dseg::options().gemm_rs = value & 7;
         return 0;
     }
     if (strcmp(key, "gemm_rs_min_rows") == 0) {

@@ -149,9 +149,10 @@ struct Options {
     int qkv_fused = 0;       // 1: ... and LayerNorm1 + qkv of the NEXT block at its end (blocks 1.. then have no LN+qkv launch); measured
                              // +1 % on one stream, +-0 on two: the tail is bound by the same HBM write burst as the launch it replaces
     int qkv_fused3 = 1;      // hi + lo planes (mlp_fused3.hip): 1 = LayerNorm1 + qkv of the NEXT block at the end of the fused projection + MLP launch
-    int gemm_rs = 0;         // 1: the row-stationary streaming GEMMs (gemm_rs.hip) where they apply (embed_dim 768, one plane, >= gemm_rs_min_rows rows).
-                             // Off: measured EQUAL to gemm_big.hip on qkv / fc1 (261 / 334 us against 252 / 352 at 57 616 rows) and slower on proj / fc2 --
-                             // with its output stores masked off the same main loop runs at 2.0 PFLOP/s (105 / 118 us): profiles/r06_gemm_rs.md
+    int gemm_rs = 3;         // the row-stationary streaming GEMMs (gemm_rs.hip; embed_dim 768, one plane, >= gemm_rs_min_rows rows), a bit per linear:
+                             // 1 = mlp.fc1 (its GELU epilogue rides in the MFMA gaps: 329 against gemm_big's 357 us at 57 616 rows), 2 = attn.qkv
+                             // (-3 % on the launch), 4 = attn.proj and mlp.fc2 (slower); 0 = never.  configs.vitb on one box: 850 / 865 / 873
+                             // frames/s with 0 / 1 / 3 (profiles/r06_gemm_rs.md).  Read when the weights are packed and at every forward
     int gemm_rs_min_rows = 24000;
     int proj_fused = 1;      // 1: the block's attention output projection runs inside the fused MLP launch
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)

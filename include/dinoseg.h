@@ -283,7 +283,8 @@ int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* Wproj, cons
  * nn.Linear computes in Attention.qkv / Mlp.fc1 (K = 768: epi 4 = the Q / K / V scatter of dinoseg_op_qkv_gemm, epi 2 = GELU into out16 [M][ldo])
  * and in Attention.proj / Mlp.fc2 with the residual add (N = 768, epi 1: x_inout [M][768] += A W^T + bias) -- vision_transformer.py:75, :60-61, :105,
  * :63 + :123 / :135.  Wp: the fp32 weight [N][K] re-packed by dinoseg_op_pack_rs (N * K 16-bit elements; kind 0 for epi 2 / 4, kind 1 for epi 1).
- * dinoseg_forward uses them for ViT-B/8 batches of >= option "gemm_rs_min_rows" rows (option "gemm_rs", default 1). */
+ * dinoseg_forward uses them for ViT-B/8 batches of >= option "gemm_rs_min_rows" rows; option "gemm_rs" is a bit per linear (1 mlp.fc1,
+ * 2 attn.qkv, 4 attn.proj + mlp.fc2; default 3: the two that measure faster than the generic kernel). */
 int dinoseg_op_pack_rs(const float* W, int32_t N, int32_t K, int32_t kind, void* dst, void* stream);
 int dinoseg_op_gemm_rs(const void* A, int32_t lda, const void* Wp, const float* bias, int32_t M, int32_t N, int32_t K, int32_t epi,
                        float* x_inout, void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok, int32_t npad, int32_t heads,
