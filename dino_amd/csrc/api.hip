@@ -1179,6 +1179,31 @@ extern "C" int dinoseg_op_proj_mlp_fused3(float* X, const void* ctx, int64_t ctx
     return launch_mlp_fused3(g, reinterpret_cast<hipStream_t>(stream));
 }
 
+extern "C" int64_t dinoseg_op_mlp4_pack_elems(int32_t D, int32_t F) { return mlp_fused4_pack_elems(D, F); }
+
+extern "C" int dinoseg_op_pack_mlp4(const float* Wproj, const float* W1, const float* W2, int32_t D, int32_t F, int32_t fmt, void* dst,
+                                    void* stream) {
+    if (fmt != FMT_BF16 && fmt != FMT_FP16) {
+        dinoseg_set_error("dinoseg_op_pack_mlp4: bad operand format %d", fmt);
+        return -1;
+    }
+    return launch_pack_mlp4(Wproj, W1, W2, D, F, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), fmt);
+}
+
+extern "C" int dinoseg_op_proj_mlp_fused4(float* X, const void* ctx, const float* bproj, const float* gamma, const float* beta, float eps,
+                                          const void* Wp, const float* b1, const float* b2, int32_t M, int32_t D, int32_t F, int32_t fmt,
+                                          void* stream) {
+    if (!mlp_fused4_supported(D, F, 1) || (fmt != FMT_BF16 && fmt != FMT_FP16)) {
+        dinoseg_set_error("dinoseg_op_proj_mlp_fused4: unsupported shape D=%d F=%d or format %d", D, F, fmt);
+        return -1;
+    }
+    MlpFused3Params g = {};
+    g.X = X; g.gamma = gamma; g.beta = beta; g.eps = eps;
+    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
+    g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.bproj = bproj; g.fmt = fmt;
+    return launch_mlp_fused4(g, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int dinoseg_op_block_tail_fused3(float* X, const void* ctx, int64_t ctx_plane, const float* bproj, const float* gamma2,
                                             const float* beta2, float eps, const void* Wp, const float* b1, const float* b2,
                                             const float* bqkv, const float* gamma1, const float* beta1, void* q, void* k, void* v,

@@ -133,6 +133,12 @@ long mlp_fused3_pack_elems(int D, int F);       // 16-bit elements of the packed
 int launch_pack_mlp3(const float* Wproj, const float* W1, const float* W2, const float* Wqkv_next /* nullable */, int D, int F, bf16_t* dst,
                      hipStream_t s, int fmt);
 int launch_mlp_fused3(const MlpFused3Params& p, hipStream_t s);
+// The same launch on ONE operand plane, one wave per SIMD (mlp_fused4.hip; MlpFused3Params without the plane strides and without a qkv tail):
+// Wp = launch_pack_mlp4's 54 slots of 48 fragments (Wproj may be null for an MLP-only copy: its six slots are zero and never read)
+bool mlp_fused4_supported(int D, int F, int planes);
+long mlp_fused4_pack_elems(int D, int F);       // 16-bit elements of the packed copy (0: unsupported shape)
+int launch_pack_mlp4(const float* Wproj /* nullable */, const float* W1, const float* W2, int D, int F, bf16_t* dst, hipStream_t s, int fmt);
+int launch_mlp_fused4(const MlpFused3Params& p, hipStream_t s);
 
 // tuning knobs (dinoseg_set_option): see api.hip
 struct Options {

@@ -765,6 +765,80 @@ def test_proj_mlp_fused(cuda, M_):
     assert float((got - two).abs().max()) <= 2.0 ** -9 * scale + 1e-3
 
 
+def _q1(x: torch.Tensor, fp16: bool) -> torch.Tensor:
+    """the fp32 value of x rounded to the one-plane operand format"""
+    return x.to(torch.float16 if fp16 else torch.bfloat16).float()
+
+
+def _pack_mlp4(Wpr, W1, W2, fp16: bool) -> torch.Tensor:
+    F_, D_ = W1.shape
+    n = capi.lib().dinoseg_op_mlp4_pack_elems(D_, F_)
+    assert n == 54 * 48 * 512
+    out = torch.empty((n,), dtype=torch.int16, device=W1.device)
+    capi.check(capi.lib().dinoseg_op_pack_mlp4(None if Wpr is None else Wpr.contiguous().data_ptr(), W1.contiguous().data_ptr(),
+                                                W2.contiguous().data_ptr(), D_, F_, int(fp16), out.data_ptr(), S()))
+    return out
+
+
+@pytest.mark.parametrize("fp16", [True, False])
+@pytest.mark.parametrize("M_", [128, 77, 128 * 5 + 33, 128 * 300 + 19])
+def test_proj_mlp_fused_one_wave(cuda, M_, fp16):
+    """mlp_fused4.hip: the attention output projection + the MLP half of a block in ONE launch with one wave per SIMD, one operand plane:
+        x += ctx . Wproj^T + bproj;   x += fc2(gelu(fc1(LayerNorm(x))))      (vision_transformer.py:104-105, :123, :135 -> :59-65)
+    against fp64 on the operands the kernel sees (ctx / weights / LayerNorm and GELU outputs rounded to the operand format), and -- bf16
+    operands -- against mlp_fused2.hip's launch, which it replaces.  M = 38 419: more items than CUs (the weight stream runs on across
+    the item boundary, the next item's rows are loaded in the last step's gaps); 77 / 673: ragged last item (clamped rows)."""
+    D_, F_ = 384, 1536
+    X = seeded((M_, D_), 41) * 1.7 + 0.4 + torch.arange(D_, device="cuda", dtype=torch.float32)[None, :] * 1e-3
+    ctx_i, ctx = _one_plane(seeded((M_, D_), 48) * 0.8, fp16)
+    Wpr = seeded((D_, D_), 49) * 0.07 + torch.arange(D_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    bpr = seeded((D_,), 50) * 0.3
+    gam, bet = 1 + 0.2 * seeded((D_,), 42), 0.1 * seeded((D_,), 43)
+    W1 = seeded((F_, D_), 44) * 0.06 + torch.arange(F_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    b1 = seeded((F_,), 45) * 0.5
+    W2 = seeded((D_, F_), 46) * 0.04 + torch.arange(D_, device="cuda", dtype=torch.float32)[:, None] * 1e-5
+    b2 = seeded((D_,), 47)
+    lib = capi.lib()
+    Wp = _pack_mlp4(Wpr, W1, W2, fp16)
+    got = X.clone()
+    capi.check(lib.dinoseg_op_proj_mlp_fused4(got.data_ptr(), ctx_i.data_ptr(), bpr.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6,
+                                              Wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), M_, D_, F_, int(fp16), S()))
+    torch.cuda.synchronize()
+    xmid = X.double() + ctx.double() @ _q1(Wpr, fp16).double().t() + bpr.double()
+    A = _q1(_ln_ref(xmid.float(), gam, bet).cuda(), fp16).double()
+    z = A @ _q1(W1, fp16).double().t() + b1.double()
+    Hq = _q1(O.gelu_erf(z.float().cpu()).cuda(), fp16).double()
+    delta = Hq @ _q1(W2, fp16).double().t() + b2.double()
+    want = (xmid + delta).float()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    scale = float(delta.abs().max())
+    assert err <= 2.0 ** -9 * scale + 1e-3, (err, scale)
+    assert float((got - X).abs().max()) > 0.5 * scale
+    # deterministic: a second launch on the same input gives the same bits
+    again = X.clone()
+    capi.check(lib.dinoseg_op_proj_mlp_fused4(again.data_ptr(), ctx_i.data_ptr(), bpr.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6,
+                                              Wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), M_, D_, F_, int(fp16), S()))
+    torch.cuda.synchronize()
+    assert torch.equal(got, again)
+    # the MLP half alone (ctx = null) on the projected rows: the same kernel without its projection steps
+    mid = xmid.float().contiguous()
+    capi.check(lib.dinoseg_op_proj_mlp_fused4(mid.data_ptr(), None, None, gam.data_ptr(), bet.data_ptr(), 1e-6, Wp.data_ptr(),
+                                              b1.data_ptr(), b2.data_ptr(), M_, D_, F_, int(fp16), S()))
+    torch.cuda.synchronize()
+    assert float((mid - want).abs().max()) <= 2.0 ** -9 * scale + 1e-3
+    if not fp16:
+        # the two-waves-per-SIMD kernel it replaces (op_fmt = bf16)
+        two = X.clone()
+        n = lib.dinoseg_op_proj_pack_elems(D_)
+        Wprp = torch.empty((n,), dtype=torch.int16, device="cuda")
+        capi.check(lib.dinoseg_op_pack_proj(Wpr.data_ptr(), D_, Wprp.data_ptr(), S()))
+        capi.check(lib.dinoseg_op_proj_mlp_fused(two.data_ptr(), ctx_i.data_ptr(), Wprp.data_ptr(), bpr.data_ptr(), gam.data_ptr(),
+                                                 bet.data_ptr(), 1e-6, pack_mlp(W1, W2).data_ptr(), b1.data_ptr(), b2.data_ptr(), M_, D_, F_, S()))
+        torch.cuda.synchronize()
+        assert float((got - two).abs().max()) <= 2.0 ** -9 * scale + 1e-3
+
+
 def _split_planes(x: torch.Tensor, fp16: bool):
     """fp32 -> (int16 planes [2, ...] as the hi + lo kernels read them, the fp32 value the two planes carry)"""
     dt = torch.float16 if fp16 else torch.bfloat16
