@@ -79,18 +79,22 @@ __global__ __launch_bounds__(256) void pack_mlp4_kernel(const float* __restrict_
         const int lane = (int)(q & 63); q >>= 6;
         const int frag = (int)(q % NFRAG);
         const int slot = (int)(q / NFRAG);
-        const int i = attn::sigma23(lane & 31), h = lane >> 5;
+        const int h = lane >> 5;
         const int half = frag / NKS, r = frag % NKS;
         int kind, u;
         mf4_slot_kind(slot, kind, u);
         float v;
-        if (kind == 1) {             // fc1: A row = hidden unit, k = input feature, fragment = (k-step, tile half): the two tiles' products alternate
-            v = W1[(long)((2 * u + (frag & 1)) * HT + i) * D + (frag >> 1) * 16 + h * 8 + e];
-        } else if (kind == 0) {      // proj: A row = output feature, k = the k-tile's 32 inputs, fragment = (k-tile half, db, s2)
-            const int db = r >> 1, s2 = r & 1;
+        if (kind == 1) {             // fc1: A row = hidden unit (sigma23 order: the accumulator layout is fc2's operand layout), fragment = (k-step, tile
+                                     // half): the two tiles' products alternate.  k runs in the order LayerNorm2 leaves the row in a lane's registers:
+                                     // element e of lane half h = feature 16 ks + 8 (e >> 2) + 4 h + (e & 3)
+            const int i = attn::sigma23(lane & 31);
+            v = W1[(long)((2 * u + (frag & 1)) * HT + i) * D + (frag >> 1) * 16 + 8 * (e >> 2) + 4 * h + (e & 3)];
+        } else if (kind == 0) {      // proj: A row = output feature (natural order: register 4 g + e of lane half h = feature 32 db + 8 g + 4 h + e, the
+                                     // two lanes of a row hold adjacent 16-byte pieces), k = the k-tile's 32 inputs, fragment = (k-tile half, db, s2)
+            const int db = r >> 1, s2 = r & 1, i = lane & 31;
             v = Wpr ? Wpr[(long)(db * 32 + i) * D + (2 * u + half) * 32 + s2 * 16 + h * 8 + e] : 0.f;
-        } else {                     // fc2: A row = output feature, k = the hidden tile's 32 units, fragment = (tile half, s2, db)
-            const int s2 = r / NDB, db = r % NDB;
+        } else {                     // fc2: A row = output feature (natural order), k = the hidden tile's 32 units, fragment = (tile half, s2, db)
+            const int s2 = r / NDB, db = r % NDB, i = lane & 31;
             v = W2[(long)(db * 32 + i) * F + (2 * u + half) * HT + s2 * 16 + h * 8 + e];
         }
         dst[idx] = pack1(v, fmt);
@@ -173,13 +177,16 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
         const uint32_t frag_rd_i = lds_base + lane16_i;
         // this lane's row of item `it` (clamped: an item past the end is row M - 1 for every lane), from a fresh opaque lane id: the row
         // pointers are recomputed where they are used -- kept alive across the item they are spilled
-        auto lane_row = [&](int it) __attribute__((always_inline)) -> long {
+        // (HS: elements between the two lanes of a row -- 8 in a ctx fragment, 4 in the fp32 row, whose 16-byte pieces the two lanes hold side by side)
+        auto lane_row_hs = [&](int it, int hs) __attribute__((always_inline)) -> long {
             uint32_t z = 0;
             asm volatile("" : "+v"(z));
             const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
             const long r = (long)it * BM + wave * 32 + (int)(l & 31);
-            return (r < M ? r : (long)M - 1) * D + (l >> 5) * 8;
+            return (r < M ? r : (long)M - 1) * D + (l >> 5) * hs;
         };
+        auto lane_row = [&](int it) __attribute__((always_inline)) -> long { return lane_row_hs(it, 8); };
+        auto lane_row_x = [&](int it) __attribute__((always_inline)) -> long { return lane_row_hs(it, 4); };
 
         // rows of an item.  PROJ: the projection accumulates from zero while the item's x row arrives in xs (48 loads of 16 bytes issued in the
         // gaps of the six projection steps, into registers that are dead there: the fc1 accumulators, the GELU's, the ctx fragments already
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
         auto load_xs = [&](const float* xr, auto j_tag) __attribute__((always_inline)) {
             constexpr int J = decltype(j_tag)::value;
             xs[J] = f32x4{1.f, 2.f, 3.f, (float)J};
-            if (!(MF4_ABL & 32)) xs[J] = *reinterpret_cast<const f32x4*>(xr + (J >> 1) * 16 + (J & 1) * 4);
+            if (!(MF4_ABL & 32)) xs[J] = *reinterpret_cast<const f32x4*>(xr + (J >> 1) * 16 + (J & 1) * 8);
         };
         auto load_ctx = [&](const bf16_t* cr, auto k_tag) __attribute__((always_inline)) {
             constexpr int k = decltype(k_tag)::value;
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
             if (!(MF4_ABL & 32)) u = *reinterpret_cast<const uint4*>(cr + k * 16);
             xn[k] = __builtin_bit_cast(bf16x8, u);
         };
-        const float* const xr_item = p.X + lane_row(item);
+        const float* const xr_item = p.X + lane_row_x(item);
         if constexpr (PROJ) {
             if (item == (int)blockIdx.x)
                 mf_for(std::make_integer_sequence<int, NKS>{}, [&](auto k_tag) __attribute__((always_inline)) { load_ctx(p.ctx + lane_row(item), k_tag); });
@@ -291,12 +298,13 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
             });
         }
 
-        // ---- LayerNorm2 of the rows in o (register 8 s2 + j of block db = feature 32 db + 16 s2 + 8 lh + j) -> xn as B-operand fragments.
+        // ---- LayerNorm2 of the rows in o (register 4 g + e of block db = feature 32 db + 8 g + 4 lh + e) -> xn as B-operand fragments (fragment
+        // k = registers 8 (k & 1) .. + 7 of block k >> 1: fc1's weights are packed in that k order).
         // x + b_proj is added to o before the statistics, b2 after the normalised copy has been taken (the two residual biases)
         {
             uint32_t zz = 0;
             asm volatile("" : "+v"(zz));
-            const uint32_t lo8 = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zz)) >> 5) * 8;
+            const uint32_t lo8 = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zz)) >> 5) * 4;      // (this lane's pieces: + 0 and + 8)
             const float* const sG = reinterpret_cast<const float*>(smem + G_OFF) + lo8;
             const float* const sBe = reinterpret_cast<const float*>(smem + BE_OFF) + lo8;
             const float* const sBp = reinterpret_cast<const float*>(smem + BP_OFF) + lo8;
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
             if constexpr (PROJ) {
 #pragma unroll
                 for (int k = 0; k < NKS; ++k) {
-                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(sBp + k * 16), c1 = *reinterpret_cast<const f32x4*>(sBp + k * 16 + 4);
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(sBp + k * 16), c1 = *reinterpret_cast<const f32x4*>(sBp + k * 16 + 8);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         o[k >> 1][(k & 1) * 8 + e] += xs[2 * k][e] + c0[e];
@@ -341,9 +349,9 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
 #pragma unroll
             for (int k = 0; k < NKS; ++k) {
                 __builtin_amdgcn_sched_barrier(0);
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(sG + k * 16), g1 = *reinterpret_cast<const f32x4*>(sG + k * 16 + 4);
-                const f32x4 e0 = *reinterpret_cast<const f32x4*>(sBe + k * 16), e1 = *reinterpret_cast<const f32x4*>(sBe + k * 16 + 4);
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(sB2 + k * 16), c1 = *reinterpret_cast<const f32x4*>(sB2 + k * 16 + 4);
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(sG + k * 16), g1 = *reinterpret_cast<const f32x4*>(sG + k * 16 + 8);
+                const f32x4 e0 = *reinterpret_cast<const f32x4*>(sBe + k * 16), e1 = *reinterpret_cast<const f32x4*>(sBe + k * 16 + 8);
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(sB2 + k * 16), c1 = *reinterpret_cast<const f32x4*>(sB2 + k * 16 + 8);
                 float y[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -464,7 +472,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
             if constexpr (TAIL) {
                 // (no row guard: a lane past the last row works on a copy of row M - 1 -- the clamped loads -- and every output column of an
                 // MFMA is computed alike, so it stores the same bits to the same place as that row's own lane)
-                float* const xrow = p.X + lane_row(item);
+                float* const xrow = p.X + lane_row_x(item);
                 mf_for(std::make_integer_sequence<int, NKS>{}, [&](auto k_tag) __attribute__((always_inline)) {
                     constexpr int k = decltype(k_tag)::value;
                     f32x4 a, b;
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
                         asm volatile("" ::"v"(a), "v"(b));
                     } else {
                         *reinterpret_cast<f32x4*>(xrow + k * 16) = a;
-                        *reinterpret_cast<f32x4*>(xrow + k * 16 + 4) = b;
+                        *reinterpret_cast<f32x4*>(xrow + k * 16 + 8) = b;
                     }
                 });
             }
