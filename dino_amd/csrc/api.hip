@@ -198,6 +198,8 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
                 h->packed_proj.clear();
                 h->packed_qkvf.clear();
                 h->packed_mlp3.clear();
+    h->packed_mlp4.clear();
+                h->packed_mlp4.clear();
                 h->packed_rs.clear();
                 h->bound.clear();
                 h->grads.clear();
@@ -273,6 +275,7 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     const int Dm = h->cfg.embed_dim, Fh = h->cfg.embed_dim * h->cfg.mlp_ratio;
     const bool mlp_fusable = mlp_fused_supported(Dm, Fh, h->planes);
     const bool mlp3_fusable = mlp_fused3_supported(Dm, Fh, h->planes);
+    const bool mlp4_fusable = mlp_fused4_supported(Dm, Fh, h->planes);      // (31 MB at 12 blocks: packed whether or not option mlp_fused4 is set)
     // one-plane modes of the wide model: fragment-order copies of the four block linears for the row-stationary GEMMs (gemm_rs.hip)
     auto rs_kind = [&](const LinSpec& sp) -> int {
         if (!options().gemm_rs || h->planes != 1 || Dm != 768 || sp.wname.rfind("dino.blocks.", 0) != 0) return -1;      // (read at refresh time)
@@ -285,6 +288,7 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     for (const LinSpec& sp : specs)
         if (rs_kind(sp) >= 0) total += align_up((size_t)sp.N * sp.K * sizeof(bf16_t), 256);
     if (mlp3_fusable) total += (size_t)h->cfg.n_blocks * align_up((size_t)mlp_fused3_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
+    if (mlp4_fusable) total += (size_t)h->cfg.n_blocks * align_up((size_t)mlp_fused4_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
     if (mlp_fusable)
         total += (size_t)h->cfg.n_blocks * (align_up((size_t)mlp_fused_pack_elems(Dm, Fh) * sizeof(bf16_t), 256) +
                                             align_up((size_t)mlp_fused_proj_pack_elems(Dm) * sizeof(bf16_t), 256) +
@@ -338,6 +342,11 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
         for (int i = 0; i < h->cfg.n_blocks; ++i) {
             h->packed_mlp3["dino.blocks." + std::to_string(i) + "."] = reinterpret_cast<bf16_t*>(h->wbuf + off);
             off += align_up((size_t)mlp_fused3_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
+        }
+    if (mlp4_fusable)
+        for (int i = 0; i < h->cfg.n_blocks; ++i) {
+            h->packed_mlp4["dino.blocks." + std::to_string(i) + "."] = reinterpret_cast<bf16_t*>(h->wbuf + off);
+            off += align_up((size_t)mlp_fused4_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
         }
     if (mlp_fusable)
         for (int i = 0; i < h->cfg.n_blocks; ++i) {
@@ -507,6 +516,9 @@ static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s) {
         DSEG_TRY(launch_pack_mlp(W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc2.weight"), Dm, Fh, kv.second, s, h->fmt));
     for (auto& kv : h->packed_proj) DSEG_TRY(launch_pack_proj(W(h, kv.first + "attn.proj.weight"), Dm, kv.second, s, h->fmt));
     for (auto& kv : h->packed_qkvf) DSEG_TRY(launch_pack_qkv(W(h, kv.first + "attn.qkv.weight"), Dm, kv.second, s, h->fmt));
+    for (auto& kv : h->packed_mlp4)
+        DSEG_TRY(launch_pack_mlp4(W(h, kv.first + "attn.proj.weight"), W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc2.weight"), Dm, Fh,
+                                  kv.second, s, h->fmt));
     for (int i = 0; i < h->cfg.n_blocks; ++i) {      // (block i's stream ends with the qkv weight of block i + 1: the tail of its fused launch)
         const std::string b = "dino.blocks." + std::to_string(i) + ".", nb = "dino.blocks." + std::to_string(i + 1) + ".";
         if (!h->packed_mlp3.count(b)) continue;
@@ -716,6 +728,15 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
                 }
             }
             DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_mlp_fused3(g, s)));
+        } else if (fuse_mlp && fuse_proj && options().mlp_fused4 && !options().qkv_fused && h->packed_mlp4.count(b)) {
+            DSEG_TRY(ensure_mlp_packs(h, s));
+            // the same launch with one wave per SIMD (mlp_fused4.hip)
+            MlpFused3Params g = {};
+            g.X = X; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
+            g.Wp = h->packed_mlp4.at(b); g.b1 = W(h, b + "mlp.fc1.bias"); g.b2 = W(h, b + "mlp.fc2.bias");
+            g.M = L.M; g.fmt = FM;
+            g.ctx = CTX; g.bproj = W(h, b + "attn.proj.bias");
+            DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_mlp_fused4(g, s)));
         } else if (fuse_mlp) {
             DSEG_TRY(ensure_mlp_packs(h, s));      // (a split forward has done this before its fork)
             // LN2 + fc1 + GELU + fc2 + residual in one launch: the hidden activation never reaches HBM (mlp_fused2.hip)
@@ -985,6 +1006,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
     }
     if (strcmp(key, "qkv_fused3") == 0) {
         dseg::options().qkv_fused3 = value ? 1 : 0;
+        return 0;
+    }
+    if (strcmp(key, "mlp_fused4") == 0) {
+        dseg::options().mlp_fused4 = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "mlp_fused3_min_rows") == 0) {

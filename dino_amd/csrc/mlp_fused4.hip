@@ -49,7 +49,8 @@ static_assert(PIECES == 12, "three groups of four pieces");
 #ifndef MF4_RA
 #define MF4_RA 4
 #endif
-constexpr int RA = MF4_RA, NFR = RA + 1;            // fragments read ahead; fragment registers
+constexpr int RA = MF4_RA, NFR = RA + 2;            // fragments read ahead (even: they are read in pairs, one counted wait per pair); fragment registers
+static_assert(RA % 2 == 0 && RA >= 2, "pairs");
 }  // namespace mf4
 
 #ifndef MF4_ABL
@@ -263,9 +264,15 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
             mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
             mf_for(std::make_integer_sequence<int, NFRAG>{}, [&](auto g_tag) __attribute__((always_inline)) {
                 constexpr int G = decltype(g_tag)::value;
-                if constexpr (G + RA < NFRAG) issue_read(std::integral_constant<int, G + RA>{});
+                if constexpr ((G & 1) == 0) {
+                    if constexpr (G + RA < NFRAG) {
+                        issue_read(std::integral_constant<int, G + RA>{});
+                        issue_read(std::integral_constant<int, G + RA + 1>{});
+                    }
+                    // fragments G and G + 1 have landed: at most the RA read behind them are in flight
+                    if (!(MF4_ABL & 16)) mf_wait<(NFRAG - 2 - G < RA ? NFRAG - 2 - G : RA)>();
+                }
                 if (MF4_ABL & 16) fr[G % NFR] = xn[G % NKS];
-                else mf_wait<(NFRAG - 1 - G < RA ? NFRAG - 1 - G : RA)>();
                 mma(g_tag, fr[G % NFR]);
                 gap(g_tag);
             });
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
 
         // ---- the GELU program of one tile's 16 accumulator values per lane: element n runs instruction i at program index 3 n + i
         // (gelu_fast of common.h; the pair (n - 1, n) is packed behind the odd element's last instruction)
-        constexpr int GELU_OPS = 9, GELU_STRIDE = 3, GELU_LEN = 15 * GELU_STRIDE + GELU_OPS + 1;      // program indices 0 .. 54
+        constexpr int GELU_OPS = 10, GELU_STRIDE = 3, GELU_LEN = 15 * GELU_STRIDE + GELU_OPS + 1;      // program indices 0 .. 55
         constexpr int CARRY = 24;      // a tile's program starts at gap CARRY of one step and goes on at gap 0 of the next with index 48 - CARRY
         static_assert(GELU_LEN - (NFRAG - CARRY) <= 36 - 4, "P (s2 = 1) is complete before the fc2 products of the second tile that read it");
         float exA[16], eaA[16], ebA[16], ecA[16], exB[16], eaB[16], ebB[16], ecB[16];
@@ -381,18 +388,19 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
         auto gelu_op = [&](auto n_tag, auto i_tag, const f32x16& s, float(&ex)[16], float(&ea)[16], float(&eb)[16], float(&ec)[16],
                            uint32_t(&pd)[8]) __attribute__((always_inline)) {
             constexpr int N = decltype(n_tag)::value, I = decltype(i_tag)::value;
-            if (MF4_ABL & 1) {
-                if constexpr (I == 0) ex[N] = s[N];
-            } else {
-                if constexpr (I == 0) ea[N] = __builtin_amdgcn_fmed3f(s[N], -8.0f, 8.0f);
-                if constexpr (I == 1) eb[N] = ea[N] * ea[N];
-                if constexpr (I == 2) ec[N] = fmaf(1.01537542e-3f, eb[N], -1.06782573e-1f);
-                if constexpr (I == 3) ec[N] = fmaf(ec[N], eb[N], -2.30111381f);
-                if constexpr (I == 4) ec[N] = ec[N] * ea[N];
-                if constexpr (I == 5) ec[N] = __builtin_amdgcn_exp2f(ec[N]);
-                if constexpr (I == 6) ec[N] = 1.0f + ec[N];
-                if constexpr (I == 7) ec[N] = __builtin_amdgcn_rcpf(ec[N]);
-                if constexpr (I == 8) ex[N] = s[N] * ec[N];
+            // (instruction 0 brings the accumulator value into a vector register: left to the compiler, the 32 reads of a step's two tiles stand in
+            // front of its first product)
+            if constexpr (I == 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(ex[N]) : "a"(s[N]));
+            if (!(MF4_ABL & 1)) {
+                if constexpr (I == 1) ea[N] = __builtin_amdgcn_fmed3f(ex[N], -8.0f, 8.0f);
+                if constexpr (I == 2) eb[N] = ea[N] * ea[N];
+                if constexpr (I == 3) ec[N] = fmaf(1.01537542e-3f, eb[N], -1.06782573e-1f);
+                if constexpr (I == 4) ec[N] = fmaf(ec[N], eb[N], -2.30111381f);
+                if constexpr (I == 5) ec[N] = ec[N] * ea[N];
+                if constexpr (I == 6) ec[N] = __builtin_amdgcn_exp2f(ec[N]);
+                if constexpr (I == 7) ec[N] = 1.0f + ec[N];
+                if constexpr (I == 8) ec[N] = __builtin_amdgcn_rcpf(ec[N]);
+                if constexpr (I == 9) ex[N] = ex[N] * ec[N];
             }
             if constexpr (I == GELU_OPS && (N & 1)) pd[N >> 1] = pack2<FMT>(ex[N - 1], ex[N]);
         };

@@ -286,6 +286,37 @@ def load(golden_dir, name):
 FP16_BOUND = {1: (3.8e-2, 9), 12: (4.0e-2, 12)}
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("L", [1, 12])
+def test_g3_vits8_480_one_wave_fused_mlp_is_bounded(cuda, golden_dir, L, precision):
+    """Library option mlp_fused4: the projection + MLP half of every block through mlp_fused4.hip (one wave per SIMD) instead of
+    mlp_fused2.hip -- against the reference's log-probabilities (G3) within the mode's bounds, and close to the default route's output."""
+    g = load(golden_dir, f"g3_vits8_L{L}_r480")
+    m, _, _ = build(L, precision)
+    frames = torch.from_numpy(synthetic_frames(1, 480, seed=int(g["frame_seed"]))).cuda()
+    lib = capi.lib()
+    out = {}
+    try:
+        for f4 in (0, 1):
+            for k, v in (("mlp_fused", 2), ("proj_fused", 1), ("qkv_fused", 0), ("mlp_fused4", f4)):
+                capi.check(lib.dinoseg_set_option(k.encode(), v))
+            lp, am = m.forward_frames(frames)
+            torch.cuda.synchronize()
+            out[f4] = (lp.cpu(), am.cpu().long())
+    finally:
+        for k, v in (("mlp_fused", 1), ("proj_fused", 1), ("qkv_fused", 0), ("mlp_fused4", 0)):
+            capi.check(lib.dinoseg_set_option(k.encode(), v))
+    lp, am = out[1]
+    assert torch.isfinite(lp).all()
+    err = float((lp - torch.from_numpy(g["logp"])).abs().max())
+    flips = int((am != torch.from_numpy(g["argmax"].astype(np.int64))).sum())
+    tol, max_flips = FP16_BOUND[L] if precision == "fp16" else (0.2, 36)
+    print(f"{precision} L={L} mlp_fused4: max|dlogp| {err:.3e}, {flips} flips; against the two-wave kernel {float((lp - out[0][0]).abs().max()):.3e}")
+    assert err <= tol and flips <= max_flips, (err, flips)
+    assert not torch.equal(lp, out[0][0])          # (the option took effect: another summation order)
+    assert float((lp - out[0][0]).abs().max()) <= tol
+
+
 @pytest.mark.parametrize("mlp_fused,proj_fused,qkv_fused,gemm_ln", [(0, 0, 0, 0), (0, 0, 0, 2), (2, 0, 0, 2), (2, 1, 0, 2), (2, 1, 1, 2)])
 @pytest.mark.parametrize("L", [1, 12])
 def test_g3_vits8_480_fp16_mode_is_bounded(cuda, golden_dir, L, mlp_fused, proj_fused, qkv_fused, gemm_ln):
