@@ -18,8 +18,8 @@ python3 bench.py --config finetune --steps 10 --warmup 3 > $OUT/bench_finetune_b
 python3 bench.py --config finetune --precision bf16x3 --steps 6 --warmup 2 > $OUT/bench_finetune_bf16x3.json 2>/dev/null
 python3 bench.py --blocks 3 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode > $OUT/bench_L3.json 2>/dev/null
 python3 bench.py --batch 1 --streams 1 --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode --no-two-stream > $OUT/bench_B1.json 2>/dev/null
-python3 bench.py --gpus 2 --steps 6 --warmup 2 --no-cpu-baseline --no-parity-mode > $OUT/bench_rehearsal2.json 2>$OUT/bench_rehearsal2.err
-python3 bench.py --gpus 2 --config finetune --steps 4 --warmup 2 > $OUT/bench_rehearsal2_finetune.json 2>$OUT/bench_rehearsal2_finetune.err
+DINOSEG_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 6 --warmup 2 --no-cpu-baseline --no-parity-mode > $OUT/bench_rehearsal2.json 2>$OUT/bench_rehearsal2.err
+DINOSEG_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --config finetune --steps 4 --warmup 2 > $OUT/bench_rehearsal2_finetune.json 2>$OUT/bench_rehearsal2_finetune.err
 for f in $OUT/bench_*.json; do echo "== $f"; tail -1 $f | cut -c1-200; done
 python3 tools/latency_b1.py bf16x3,fp16x3,fp16 > $OUT/latency_b1.txt 2>/dev/null; grep "^L=" $OUT/latency_b1.txt
 export TMPDIR=/tmp

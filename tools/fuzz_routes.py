@@ -1,8 +1,9 @@
 """GPU box: random (resolution, batch) shapes through every dispatch route of the linears, all against one reference route of the same
 model (bounded: the routes differ only in rounding points / summation order), two streams bit-identical to one.
     python tools/fuzz_routes.py [cases] [seed] [precision: bf16 (default) | fp16 | bf16x3 | fp16x3]
-single-plane precisions: separate kernels, fused MLP, + projection, + qkv tail, one / two streams; hi+lo precisions: 128x128 kernel only,
-persistent GEMM wherever allowed, LayerNorm-fused GEMMs wherever supported, the defaults, two streams."""
+single-plane precisions: separate kernels, fused MLP, + projection, + qkv tail, the one-wave fused launch, one / two streams; hi+lo precisions:
+128x128 kernel only, persistent GEMM wherever allowed, LayerNorm-fused GEMMs wherever supported, the fused launch of round 6 at every size without and
+with its qkv tail, the defaults, two streams."""
 import os
 import sys
 
@@ -31,19 +32,22 @@ for c in range(cases):
     outs = {}
     single = prec in ("bf16", "fp16")
     if single:
-        routes = (("separate", dict(mlp_fused=0, proj_fused=0, qkv_fused=0, streams=1)),
-                  ("fused", dict(mlp_fused=2, proj_fused=0, qkv_fused=0, streams=1)),
-                  ("fused+proj", dict(mlp_fused=2, proj_fused=1, qkv_fused=0, streams=1)),
-                  ("fused+proj+qkv", dict(mlp_fused=2, proj_fused=1, qkv_fused=1, streams=1)),
-                  ("two streams", dict(mlp_fused=2, proj_fused=1, qkv_fused=0, streams=2, split_min=2)),
-                  ("two streams+qkv", dict(mlp_fused=2, proj_fused=1, qkv_fused=1, streams=2, split_min=2)))
+        routes = (("separate", dict(mlp_fused=0, proj_fused=0, qkv_fused=0, streams=1, mlp_fused4=0)),
+                  ("fused", dict(mlp_fused=2, proj_fused=0, qkv_fused=0, streams=1, mlp_fused4=0)),
+                  ("fused+proj", dict(mlp_fused=2, proj_fused=1, qkv_fused=0, streams=1, mlp_fused4=0)),
+                  ("fused+proj+qkv", dict(mlp_fused=2, proj_fused=1, qkv_fused=1, streams=1, mlp_fused4=0)),
+                  ("one wave", dict(mlp_fused=2, proj_fused=1, qkv_fused=0, streams=1, mlp_fused4=1)),          # (round 6: mlp_fused4.hip)
+                  ("two streams", dict(mlp_fused=2, proj_fused=1, qkv_fused=0, streams=2, split_min=2, mlp_fused4=0)),
+                  ("two streams+qkv", dict(mlp_fused=2, proj_fused=1, qkv_fused=1, streams=2, split_min=2, mlp_fused4=0)))
         tol, flip_tol = (0.25, 0.02) if prec == "bf16" else (0.06, 0.01)
     else:
-        routes = (("separate", dict(gemm_big=0, gemm_ln=0, streams=1)),
-                  ("persistent", dict(gemm_big=2, gemm_ln=0, streams=1)),
-                  ("ln-fused", dict(gemm_big=1, gemm_ln=2, streams=1)),
-                  ("fused+proj", dict(gemm_big=1, gemm_ln=1, streams=1)),          # (the name the identity check below uses: the defaults)
-                  ("two streams", dict(gemm_big=1, gemm_ln=1, streams=2, split_min=2)))
+        routes = (("separate", dict(gemm_big=0, gemm_ln=0, streams=1, mlp_fused=0, qkv_fused3=1)),
+                  ("persistent", dict(gemm_big=2, gemm_ln=0, streams=1, mlp_fused=0, qkv_fused3=1)),
+                  ("ln-fused", dict(gemm_big=1, gemm_ln=2, streams=1, mlp_fused=0, qkv_fused3=1)),
+                  ("fused3", dict(gemm_big=1, gemm_ln=1, streams=1, mlp_fused=2, qkv_fused3=0)),       # (round 6: mlp_fused3.hip at every size)
+                  ("fused3+qkv", dict(gemm_big=1, gemm_ln=1, streams=1, mlp_fused=2, qkv_fused3=1)),   # ... with LayerNorm1 + qkv of the next block
+                  ("fused+proj", dict(gemm_big=1, gemm_ln=1, streams=1, mlp_fused=1, qkv_fused3=1)),   # (the name the identity check below uses: the defaults)
+                  ("two streams", dict(gemm_big=1, gemm_ln=1, streams=2, split_min=2, mlp_fused=1, qkv_fused3=1)))
         tol, flip_tol = (1.5e-3, 0.003) if prec == "bf16x3" else (3e-4, 0.001)
     for name, opts in routes:
         for k, v in opts.items():
@@ -66,6 +70,6 @@ for c in range(cases):
     if single:
         assert torch.equal(outs["two streams+qkv"][0], outs["fused+proj+qkv"][0]), ("two streams + qkv differ", r, B)
     print(line, flush=True)
-for k, v in dict(mlp_fused=1, proj_fused=1, qkv_fused=0, streams=2, split_min=8, gemm_big=1, gemm_ln=1).items():
+for k, v in dict(mlp_fused=1, proj_fused=1, qkv_fused=0, streams=2, split_min=8, gemm_big=1, gemm_ln=1, mlp_fused4=0, qkv_fused3=1).items():
     dino_amd.set_option(k, v)
 print(f"{cases} cases, worst |dlogp| between routes {worst:.3f}")

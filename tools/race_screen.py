@@ -124,5 +124,62 @@ for variant in (3, 11, 11 | 1024 | 2048, 11 | 1024 | 2048 | 65536, 11 | 16 | 102
                                               B * ntok * H * 64, lse.data_ptr(), B, H, ntok, npad, planes, S()))
       screen(f"attention variant {variant} B={B} H={H} N={ntok} planes={planes}", run, lambda: [ctx, lse])
 capi.check(lib.dinoseg_set_option(b"attn_variant", 11 | 1024 | 65536))
+
+# round 6: the one-wave-per-SIMD fused launches (three-slot LDS-DMA ring shared by four waves, counted vmcnt over pieces, row loads and stores in ONE
+# in-order queue, counted lgkmcnt over the fragment reads, M0 set once per four pieces) and the row-stationary GEMMs (same ring)
+D_, F_, H_ = 384, 1536, 6
+for (Bq, ntok, fp16) in [(32, 3601, True), (11, 3601, False), (3, 130, True), (1, 65, False)]:
+    M_ = Bq * ntok
+    npad = (ntok + 63) // 64 * 64
+    c = T._mlp3_case(M_, fp16, 300, tail=True)
+    ctx_pl, _ = T._split_planes(c["ctx"], fp16)
+    x3 = torch.zeros_like(c["X"])
+    q3 = torch.zeros((2, Bq, H_, npad, 64), dtype=torch.int16, device="cuda")
+    k3, v3 = torch.zeros_like(q3), torch.zeros_like(q3)
+
+    def run3():
+        x3.copy_(c["X"])
+        capi.check(lib.dinoseg_op_proj_mlp_fused3(x3.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), c["gam"].data_ptr(),
+                                                  c["bet"].data_ptr(), 1e-6, c["Wp"].data_ptr(), c["b1"].data_ptr(), c["b2"].data_ptr(), M_, D_, F_,
+                                                  int(fp16), S()))
+    screen(f"mlp_fused3 B={Bq} N={ntok} fp16={fp16}", run3, lambda: [x3])
+
+    def run3t():
+        x3.copy_(c["X"])
+        capi.check(lib.dinoseg_op_block_tail_fused3(x3.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), c["gam"].data_ptr(),
+                                                    c["bet"].data_ptr(), 1e-6, c["Wp"].data_ptr(), c["b1"].data_ptr(), c["b2"].data_ptr(),
+                                                    c["bq"].data_ptr(), c["gam1"].data_ptr(), c["bet1"].data_ptr(), q3.data_ptr(), k3.data_ptr(),
+                                                    v3.data_ptr(), Bq * H_ * npad * 64, Bq, ntok, npad, H_, 0.125 * LOG2E, int(fp16), D_, F_,
+                                                    int(fp16), S()))
+    screen(f"mlp_fused3 + qkv tail B={Bq} N={ntok} fp16={fp16}", run3t, lambda: [x3, q3, k3, v3])
+    ctx1, _ = T._one_plane(c["ctx"], fp16)
+    Wp4 = T._pack_mlp4(c["Wpr"], c["W1"], c["W2"], fp16)
+    x4 = torch.zeros_like(c["X"])
+
+    def run4():
+        x4.copy_(c["X"])
+        capi.check(lib.dinoseg_op_proj_mlp_fused4(x4.data_ptr(), ctx1.data_ptr(), c["bpr"].data_ptr(), c["gam"].data_ptr(), c["bet"].data_ptr(), 1e-6,
+                                                  Wp4.data_ptr(), c["b1"].data_ptr(), c["b2"].data_ptr(), M_, D_, F_, int(fp16), S()))
+    screen(f"mlp_fused4 B={Bq} N={ntok} fp16={fp16}", run4, lambda: [x4])
+    del c, ctx_pl, x3, q3, k3, v3, x4, Wp4
+
+for (M_, fp16) in [(57616, True), (24001, False), (300, True)]:
+    capi.check(lib.dinoseg_set_option(b"op_fmt", int(fp16)))
+    K = 768
+    Ap, _ = T._one_plane(seeded((M_, K), 61) * 0.7, fp16)
+    for name, N, kind, epi in (("fc1 gelu", 3072, 0, capi.EPI_GELU), ("proj resid", 768, 1, capi.EPI_RESID)):
+        W, bias = seeded((N, K), 62) * 0.05, seeded((N,), 63) * 0.3
+        Wp = T._pack_rs(W, kind)
+        X0 = seeded((M_, N), 64) if epi == capi.EPI_RESID else None
+        xo = torch.zeros((M_, N), device="cuda") if epi == capi.EPI_RESID else None
+        o16 = torch.zeros((M_, N), dtype=torch.int16, device="cuda") if epi == capi.EPI_GELU else None
+
+        def runrs():
+            if xo is not None:
+                xo.copy_(X0)
+            capi.check(lib.dinoseg_op_gemm_rs(Ap.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), M_, N, K, epi, None if xo is None else xo.data_ptr(),
+                                              None if o16 is None else o16.data_ptr(), N if o16 is not None else 0, None, None, None, 0, 0, 0, 0.0, S()))
+        screen(f"gemm_rs {name} M={M_} fp16={fp16}", runrs, lambda: [xo if xo is not None else o16])
+capi.check(lib.dinoseg_set_option(b"op_fmt", 0))
 print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad})")
 sys.exit(1 if bad else 0)
