@@ -562,11 +562,20 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     const int dB = disp_B > 0 ? disp_B : B;
     const int disp_M = dB * L.ntok, disp_Mp = dB * L.n;
     // a block linear through the row-stationary streaming kernels (gemm_rs.hip) where a fragment-order copy exists and the batch fills the chip
+    // ... and with the LayerNorm in front of it in its prologue (qkv / fc1 of the wide model: no LayerNorm launch, no 16-bit A round trip)
+    auto rs_takes_ln = [&](const std::string& wname) -> bool {
+        return options().gemm_rs && options().gemm_rs_ln && disp_M >= options().gemm_rs_min_rows && h->packed_rs.count(wname) && P == 1 &&
+               !(mreq && mreq->cls_mask);
+    };
     auto gemm_any = [&](GemmParams& g, const std::string& wname) -> int {
         if (options().gemm_rs && disp_M >= options().gemm_rs_min_rows && h->packed_rs.count(wname)) {
             GemmParams r = g;
             r.W = h->packed_rs.at(wname);
             if (gemm_rs_supported(r)) return launch_gemm_rs(r, s);
+        }
+        if (g.ln_x) {      // (rs_takes_ln said the LayerNorm runs inside: no normalised A exists for another kernel)
+            dinoseg_set_error("internal: %s was routed to gemm_rs with its LayerNorm inside, which does not take it", wname.c_str());
+            return -1;
         }
         return launch_gemm(g, s);
     };
@@ -637,11 +646,14 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.dmodel = D; g.qscale = qscale; g.fmt = FM;
             DSEG_PROF(DINOSEG_PROF_QKV, DSEG_TRY(launch_gemm_ln(g, D, P, s)));
         } else {
+        const bool ln_inside = rs_takes_ln(b + "attn.qkv.weight");
+        if (!ln_inside)
         DSEG_PROF(DINOSEG_PROF_LN, DSEG_TRY(launch_layernorm(X, W(h, b + "norm1.weight"), W(h, b + "norm1.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
                                   nullptr, 0, L.ntok, s, FM)));
         {
             const PackedLinear& pk = h->packed.at(b + "attn.qkv.weight");
             GemmParams g = {};
+            if (ln_inside) { g.ln_x = X; g.ln_gamma = W(h, b + "norm1.weight"); g.ln_beta = W(h, b + "norm1.bias"); g.ln_eps = c.ln_eps; }
             g.A = A; g.a_plane = L.a_plane; g.lda = D;
             g.W = pk.w; g.w_plane = pk.plane;
             g.M = L.M; g.N = 3 * D; g.K = D; g.planes = P; g.fmt = FM; g.epi = EPI_QKV; g.dispatch_rows = disp_M;
@@ -765,11 +777,14 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.out_bf16 = HB; g.out_plane = L.hb_plane; g.ldo = F;
             DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_gemm_ln(g, D, P, s)));
         } else {
+        const bool ln_inside = rs_takes_ln(b + "mlp.fc1.weight");
+        if (!ln_inside)
         DSEG_PROF(DINOSEG_PROF_LN, DSEG_TRY(launch_layernorm(X, W(h, b + "norm2.weight"), W(h, b + "norm2.bias"), c.ln_eps, L.M, D, A, L.a_plane, P,
                                   nullptr, 0, L.ntok, s, FM)));
         {
             const PackedLinear& pk = h->packed.at(b + "mlp.fc1.weight");
             GemmParams g = {};
+            if (ln_inside) { g.ln_x = X; g.ln_gamma = W(h, b + "norm2.weight"); g.ln_beta = W(h, b + "norm2.bias"); g.ln_eps = c.ln_eps; }
             g.A = A; g.a_plane = L.a_plane; g.lda = D;
             g.W = pk.w; g.w_plane = pk.plane;
             g.M = L.M; g.N = F; g.K = D; g.planes = P; g.fmt = FM; g.epi = EPI_GELU; g.dispatch_rows = disp_M;
@@ -1000,6 +1015,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().gemm_rs = value & 7;
         return 0;
     }
+    if (strcmp(key, "gemm_rs_ln") == 0) {
+        dseg::options().gemm_rs_ln = value ? 1 : 0;
+        return 0;
+    }
     if (strcmp(key, "gemm_rs_min_rows") == 0) {
         dseg::options().gemm_rs_min_rows = value;
         return 0;
@@ -1174,6 +1193,23 @@ extern "C" int dinoseg_op_gemm_rs(const void* A, int32_t lda, const void* Wp, co
     g.A = reinterpret_cast<const bf16_t*>(A); g.lda = lda; g.W = reinterpret_cast<const bf16_t*>(Wp); g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.planes = 1; g.fmt = options().op_fmt; g.epi = epi;
     g.out_f32 = x_inout; g.ldo_f32 = N; g.out_bf16 = reinterpret_cast<bf16_t*>(out16); g.ldo = ldo;
+    g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
+    g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = heads * 64; g.qscale = qscale;
+    return launch_gemm_rs(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_ln_gemm_rs(const float* X, const float* gamma, const float* beta, float eps, const void* Wp, const float* bias, int32_t M,
+                                     int32_t N, int32_t K, int32_t epi, void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok,
+                                     int32_t npad, int32_t heads, float qscale, void* stream) {
+    if (!X || !gamma || !beta) {
+        dinoseg_set_error("dinoseg_op_ln_gemm_rs: null rows / LayerNorm constants");
+        return -1;
+    }
+    GemmParams g = {};
+    g.ln_x = X; g.ln_gamma = gamma; g.ln_beta = beta; g.ln_eps = eps;
+    g.W = reinterpret_cast<const bf16_t*>(Wp); g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.planes = 1; g.fmt = options().op_fmt; g.epi = epi;
+    g.out_bf16 = reinterpret_cast<bf16_t*>(out16); g.ldo = ldo;
     g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
     g.ntok = ntok; g.npad = npad; g.heads = heads; g.dmodel = heads * 64; g.qscale = qscale;
     return launch_gemm_rs(g, reinterpret_cast<hipStream_t>(stream));

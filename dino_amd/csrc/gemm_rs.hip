@@ -62,7 +62,9 @@ int launch_pack_rs(const float* W, int N, int K, int kind, bf16_t* dst, hipStrea
 //  an uncounted asm instruction: the same time, launch for launch (profiles/r06_gemm_rs.md), and two hazards hipcc does not pad around inline asm
 //  on the way: a VALU-written SGPR pair read by an asm VMEM instruction needs `s_nop 4` in front, an asm store's data registers two wait states
 //  behind.  The plain form below has neither.)
-template <int FMT, int EPI, int KS>
+// LN: the stationary rows are LayerNorm(ln_x) computed here -- the fp32 row of a lane (384 values) is loaded once, normalised in registers (two-pass
+// statistics, one cross-half shuffle) and packed into the fragments: no LayerNorm launch, no 16-bit A round trip (vision_transformer.py:122 / :134)
+template <int FMT, int EPI, int KS, bool LN>
 __global__ __launch_bounds__(rs::THREADS, 1) void gemm_bstat_kernel(GemmParams p) {
     using namespace rs;
     static_assert(KS == 48, "the gap programs below are written for 48-gap steps (K = 768)");
@@ -93,7 +95,53 @@ __global__ __launch_bounds__(rs::THREADS, 1) void gemm_bstat_kernel(GemmParams p
         const uint32_t frag_rd_i = st.lds_base + lane16_i;
         const int r_ = item * BM + wave * 32 + (int)lr_i;
         const int rc = r_ < M ? r_ : M - 1;      // (clamped: a row past the end is a copy of row M - 1 and rewrites its bytes)
-        {
+        if constexpr (LN) {
+            const float* xr = p.ln_x + (long)rc * (KS * 16) + lh_i * 8;
+            f32x4 r[2 * KS];
+#pragma unroll
+            for (int j = 0; j < 2 * KS; ++j) r[j] = *reinterpret_cast<const f32x4*>(xr + (j >> 1) * 16 + (j & 1) * 4);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2 * KS; j += 2) sum += ((r[j][0] + r[j][1]) + (r[j][2] + r[j][3])) + ((r[j + 1][0] + r[j + 1][1]) + (r[j + 1][2] + r[j + 1][3]));
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / (KS * 16));
+            float qv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2 * KS; ++j) {
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dlt = r[j][e] - mean;
+                    part = fmaf(dlt, dlt, part);
+                }
+                qv += part;
+            }
+            qv += __shfl_xor(qv, 32);
+            const float rstd = 1.0f / sqrtf(qv * (1.0f / (KS * 16)) + p.ln_eps);
+            float mean_n = mean;
+            asm volatile("" : "+v"(mean_n));
+            const float* gp = p.ln_gamma + lh_i * 8;
+            const float* bp = p.ln_beta + lh_i * 8;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                asm volatile("" ::: "memory");      // (one k-step of constants in flight: hoisted, the loads of a row's constants would need 384 registers)
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp + k * 16), g1 = *reinterpret_cast<const f32x4*>(gp + k * 16 + 4);
+                const f32x4 e0 = *reinterpret_cast<const f32x4*>(bp + k * 16), e1 = *reinterpret_cast<const f32x4*>(bp + k * 16 + 4);
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = (r[2 * k][e] - mean_n) * rstd * g0[e] + e0[e];
+                    y[4 + e] = (r[2 * k + 1][e] - mean_n) * rstd * g1[e] + e1[e];
+                }
+                uint4 u;
+                u.x = pack2_sat<FMT>(y[0], y[1]);
+                u.y = pack2_sat<FMT>(y[2], y[3]);
+                u.z = pack2_sat<FMT>(y[4], y[5]);
+                u.w = pack2_sat<FMT>(y[6], y[7]);
+                xn[k] = __builtin_bit_cast(bf16x8, u);
+            }
+        } else {
             const bf16_t* ar = p.A + (long)rc * p.lda + lh_i * 8;
             mf_for(std::make_integer_sequence<int, KS>{}, [&](auto k_tag) __attribute__((always_inline)) {
                 constexpr int k = decltype(k_tag)::value;
@@ -365,7 +413,7 @@ __global__ __launch_bounds__(rs::THREADS, 1) void gemm_cstat_kernel(GemmParams p
 
 // ------------------------------------------------------------------------------------------------ host
 bool gemm_rs_supported(const GemmParams& p) {
-    if (p.planes != 1 || p.bias == nullptr || p.M < 1 || p.lda % 8 != 0 || p.resid != nullptr || p.aux_out != nullptr || p.ksplit > 1) return false;
+    if (p.planes != 1 || p.bias == nullptr || p.M < 1 || (p.ln_x == nullptr && p.lda % 8 != 0) || (p.ln_x != nullptr && (p.epi == EPI_RESID || !p.ln_gamma || !p.ln_beta)) || p.resid != nullptr || p.aux_out != nullptr || p.ksplit > 1) return false;
     if (p.epi == EPI_RESID) return p.N == 768 && p.K % 192 == 0 && p.K >= 576 && p.ldo_f32 == p.N && p.out_f32 != nullptr;
     if (p.epi == EPI_GELU) return p.K == 768 && p.N % 64 == 0 && p.N >= 128 && p.ldo % 8 == 0 && p.N * 4 <= 16 * 1024 && p.out_bf16 != nullptr;
     if (p.epi == EPI_QKV) return p.K == 768 && p.dmodel == 768 && p.N == 3 * p.dmodel && p.heads * 64 == p.dmodel && p.q && p.k && p.v;
@@ -379,8 +427,10 @@ static int launch_gemm_rs_fmt(const GemmParams& p, hipStream_t s) {
     static PerDeviceOnce once;
     if (once.first()) {
         auto opt_in = [](const void* fn, int bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
-        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&gemm_bstat_kernel<FMT, EPI_GELU, 48>), LDS_B));
-        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&gemm_bstat_kernel<FMT, EPI_QKV, 48>), LDS_B));
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&gemm_bstat_kernel<FMT, EPI_GELU, 48, false>), LDS_B));
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&gemm_bstat_kernel<FMT, EPI_QKV, 48, false>), LDS_B));
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&gemm_bstat_kernel<FMT, EPI_GELU, 48, true>), LDS_B));
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&gemm_bstat_kernel<FMT, EPI_QKV, 48, true>), LDS_B));
         DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&gemm_cstat_kernel<FMT>), LDS_C));
         once.mark();
     }
@@ -400,8 +450,11 @@ static int launch_gemm_rs_fmt(const GemmParams& p, hipStream_t s) {
         return 0;
     }
     const dim3 g(grid);
-    if (p.epi == EPI_GELU) hipLaunchKernelGGL((gemm_bstat_kernel<FMT, EPI_GELU, 48>), g, b, LDS_B, s, p);
-    else hipLaunchKernelGGL((gemm_bstat_kernel<FMT, EPI_QKV, 48>), g, b, LDS_B, s, p);
+    if (p.ln_x) {
+        if (p.epi == EPI_GELU) hipLaunchKernelGGL((gemm_bstat_kernel<FMT, EPI_GELU, 48, true>), g, b, LDS_B, s, p);
+        else hipLaunchKernelGGL((gemm_bstat_kernel<FMT, EPI_QKV, 48, true>), g, b, LDS_B, s, p);
+    } else if (p.epi == EPI_GELU) hipLaunchKernelGGL((gemm_bstat_kernel<FMT, EPI_GELU, 48, false>), g, b, LDS_B, s, p);
+    else hipLaunchKernelGGL((gemm_bstat_kernel<FMT, EPI_QKV, 48, false>), g, b, LDS_B, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -48,6 +48,8 @@ struct GemmParams {
                                                 // half-batches of a split forward take the route of the whole batch (same summation order)
     int ksplit;                                 // >1: split the K loop over grid.y (EPI_ATOMIC, or EPI_PLAIN partial tiles)
     long split_stride;                          // EPI_PLAIN with ksplit > 1: slice y writes out_f32 + y * split_stride (floats)
+    // launch_gemm_rs, EPI_GELU / EPI_QKV only: A = LayerNorm(ln_x) computed in the kernel's prologue (ln_x fp32 [M][K] rows, row stride K; A unused)
+    const float* ln_x; const float* ln_gamma; const float* ln_beta; float ln_eps;
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);       // dispatches between the two kernels below
 int launch_gemm_small(const GemmParams& p, hipStream_t s); // 128x128 tile, bf16 or bf16x3 (gemm.hip)
@@ -163,6 +165,7 @@ struct Options {
                              // (-3 % on the launch), 4 = attn.proj and mlp.fc2 (slower); 0 = never.  configs.vitb on one box: 850 / 865 / 873
                              // frames/s with 0 / 1 / 3 (profiles/r06_gemm_rs.md).  Read when the weights are packed and at every forward
     int gemm_rs_min_rows = 24000;
+    int gemm_rs_ln = 1;      // ... with the LayerNorm in front of qkv / fc1 computed in the kernel's prologue (no LayerNorm launch, no 16-bit A round trip)
     int proj_fused = 1;      // 1: the block's attention output projection runs inside the fused MLP launch
     int streams = 2;         // 2: dinoseg_forward runs a batch of >= split_min frames as two half-batches on two streams (api.hip)
     int split_min = 8;       // (8 frames @480: +6 %, 12: +16 %, 16: +12 %; 6 frames and fewer: slower split)

@@ -1131,3 +1131,62 @@ def test_gemm_rs_qkv_layout(cuda, B, ntok, fp16):
     assert float((gk[:, :, :ntok] - ref[1]).abs().max()) <= tol(ref[1], dt)
     assert float((gv[:, :, :ntok] - ref[2]).abs().max()) <= tol(ref[2], torch.bfloat16)
     assert torch.all(q[:, :, ntok:] == 0) and torch.all(k[:, :, ntok:] == 0) and torch.all(v[:, :, ntok:] == 0)
+
+
+@pytest.mark.parametrize("fp16", [True, False])
+@pytest.mark.parametrize("B,ntok", [(1, 65), (3, 130), (10, 3601)])
+def test_ln_gemm_rs(cuda, B, ntok, fp16):
+    """gemm_rs.hip with the LayerNorm in its prologue (`self.qkv(self.norm1(x))` / `self.fc1(self.norm2(x))`, vision_transformer.py:122 -> :75,
+    :134 -> :60-61, embed_dim 768): against the two launches it replaces (dinoseg_op_layernorm, then dinoseg_op_gemm_rs on its output) -- the
+    same MFMAs on operands that differ only where the two LayerNorms round a value differently -- and against fp64 on the rounded LayerNorm output;
+    Q / K / V layout and pad rows as without the LayerNorm.  (10, 3601): 36 010 rows = more items than CUs, ragged last item."""
+    H, D, F_ = 12, 768, 3072
+    M_, npad = B * ntok, (ntok + 63) // 64 * 64
+    lib = capi.lib()
+    X = seeded((M_, D), 231) * 1.6 + 0.3 + torch.arange(D, device="cuda", dtype=torch.float32)[None, :] * 1e-3
+    X[:, 7] += 25.0          # (an outlier channel, as the residual stream has them: the statistics are two-pass)
+    gam, bet = 1 + 0.2 * seeded((D,), 232), 0.1 * seeded((D,), 233)
+    Wq_, bq = seeded((3 * D, D), 234) * 0.05, seeded((3 * D,), 235)
+    W1, b1 = seeded((F_, D), 236) * 0.04, seeded((F_,), 237) * 0.5
+    qscale = 0.125 * LOG2E
+    dt = torch.float16 if fp16 else torch.bfloat16
+    capi.check(lib.dinoseg_set_option(b"op_fmt", int(fp16)))
+    try:
+        A16 = torch.zeros((1, M_, D), dtype=torch.int16, device="cuda")
+        capi.check(lib.dinoseg_op_layernorm(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, M_, D, A16.data_ptr(), M_ * D, 1, None, 0, ntok, S()))
+        Wpq, Wp1 = _pack_rs(Wq_, 0), _pack_rs(W1, 0)
+        outs = {}
+        for ln in (False, True):
+            q = torch.zeros((B, H, npad, 64), dtype=torch.int16, device="cuda")
+            k, v = torch.zeros_like(q), torch.zeros_like(q)
+            hb = torch.zeros((M_, F_), dtype=torch.int16, device="cuda")
+            if ln:
+                capi.check(lib.dinoseg_op_ln_gemm_rs(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wpq.data_ptr(), bq.data_ptr(), M_, 3 * D, D, 4,
+                                                     None, 0, q.data_ptr(), k.data_ptr(), v.data_ptr(), ntok, npad, H, qscale, S()))
+                capi.check(lib.dinoseg_op_ln_gemm_rs(X.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-6, Wp1.data_ptr(), b1.data_ptr(), M_, F_, D,
+                                                     capi.EPI_GELU, hb.data_ptr(), F_, None, None, None, 0, 0, 0, 0.0, S()))
+            else:
+                capi.check(lib.dinoseg_op_gemm_rs(A16.data_ptr(), D, Wpq.data_ptr(), bq.data_ptr(), M_, 3 * D, D, 4, None, None, 0, q.data_ptr(),
+                                                  k.data_ptr(), v.data_ptr(), ntok, npad, H, qscale, S()))
+                capi.check(lib.dinoseg_op_gemm_rs(A16.data_ptr(), D, Wp1.data_ptr(), b1.data_ptr(), M_, F_, D, capi.EPI_GELU, None, hb.data_ptr(), F_,
+                                                  None, None, None, 0, 0, 0, 0.0, S()))
+            torch.cuda.synchronize()
+            outs[ln] = (q.view(dt).float(), k.view(dt).float(), v.view(torch.bfloat16).float(), hb.view(dt).float(), q, k, v)
+    finally:
+        capi.check(lib.dinoseg_set_option(b"op_fmt", 0))
+    ulp = 2.0 ** -10 if fp16 else 2.0 ** -7
+    for name, a, b_ in zip(("q", "k", "v", "gelu(fc1)"), outs[True][:4], outs[False][:4]):
+        assert torch.isfinite(a).all()
+        # an operand element rounded the other way moves an output by <= |w| ulp(operand): far below one output ulp of the typical magnitude
+        d = (a - b_).abs()
+        assert float(d.max()) <= 4 * (ulp if name != "v" else 2.0 ** -7) * float(b_.abs().max()) + 1e-4, (name, float(d.max()))
+        assert float((d > 0).float().mean()) <= 0.2, (name, float((d > 0).float().mean()))
+    # fp64 on the LayerNorm output as the two-launch path rounds it
+    Aq = A16[0].view(dt).double()
+    ref = (Aq @ _q1(Wq_, fp16).double().t() + bq.double()).float().reshape(B, ntok, 3, H, 64).permute(2, 0, 3, 1, 4)
+    tol = lambda r, e: 3 * e * float(r.abs().max()) + 1e-4
+    assert float((outs[True][0][:, :, :ntok] - ref[0] * qscale).abs().max()) <= tol(ref[0] * qscale, ulp)
+    assert float((outs[True][1][:, :, :ntok] - ref[1]).abs().max()) <= tol(ref[1], ulp)
+    assert float((outs[True][2][:, :, :ntok] - ref[2]).abs().max()) <= tol(ref[2], 2.0 ** -7)
+    for t in outs[True][4:]:
+        assert torch.all(t[:, :, ntok:] == 0)
