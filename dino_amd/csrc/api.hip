@@ -275,7 +275,7 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
     const int Dm = h->cfg.embed_dim, Fh = h->cfg.embed_dim * h->cfg.mlp_ratio;
     const bool mlp_fusable = mlp_fused_supported(Dm, Fh, h->planes);
     const bool mlp3_fusable = mlp_fused3_supported(Dm, Fh, h->planes);
-    const bool mlp4_fusable = mlp_fused4_supported(Dm, Fh, h->planes);      // (31 MB at 12 blocks: packed whether or not option mlp_fused4 is set)
+    const bool mlp4_fusable = options().mlp_fused4 && mlp_fused4_supported(Dm, Fh, h->planes);      // (read at refresh time: a fine-tune step re-packs what exists)
     // one-plane modes of the wide model: fragment-order copies of the four block linears for the row-stationary GEMMs (gemm_rs.hip)
     auto rs_kind = [&](const LinSpec& sp) -> int {
         if (!options().gemm_rs || h->planes != 1 || Dm != 768 || sp.wname.rfind("dino.blocks.", 0) != 0) return -1;      // (read at refresh time)

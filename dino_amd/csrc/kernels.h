@@ -158,7 +158,8 @@ struct Options {
                              // +1 % on one stream, +-0 on two: the tail is bound by the same HBM write burst as the launch it replaces
     int mlp_fused4 = 0;      // one-plane modes: 1 = the fused projection + MLP launch with ONE wave per SIMD (mlp_fused4.hip) instead of mlp_fused2.hip's two
                              // (no qkv tail: only while qkv_fused is 0).  Measured equal (headline 2582 against 2578 frames/s, the launch 361-368 against
-                             // 360-372 us: profiles/r06_mlp_fused4.md), so the older kernel stays the default
+                             // 360-372 us: profiles/r06_mlp_fused4.md), so the older kernel stays the default.
+                             // Read when the weights are packed (dinoseg_refresh_weights) and at every forward
     int qkv_fused3 = 1;      // hi + lo planes (mlp_fused3.hip): 1 = LayerNorm1 + qkv of the NEXT block at the end of the fused projection + MLP launch
     int gemm_rs = 3;         // the row-stationary streaming GEMMs (gemm_rs.hip; embed_dim 768, one plane, >= gemm_rs_min_rows rows), a bit per linear:
                              // 1 = mlp.fc1 (its GELU epilogue rides in the MFMA gaps: 329 against gemm_big's 357 us at 57 616 rows), 2 = attn.qkv

@@ -320,7 +320,7 @@ int dinoseg_op_block_tail_fused3(float* X, const void* ctx, int64_t ctx_plane, c
  * logistic GELU of the benchmark modes), the structure of the hi + lo kernel above -- 128-row items, 32 rows per wave held in registers for
  * the whole item, the weights as one linear stream of 48-KiB slots.  ctx: [M][384] in the operand format, or null = the MLP half only.
  * Wp: dinoseg_op_pack_mlp4 (dinoseg_op_mlp4_pack_elems(D, F) 16-bit elements; Wproj may be null with ctx == null).  Library option
- * "mlp_fused4" (default 0: it measures equal) makes dinoseg_forward use it instead of dinoseg_op_proj_mlp_fused.  vision_transformer.py:104-105, :123, :135 -> :59-65. */
+ * "mlp_fused4" (default 0: it measures equal; set before dinoseg_refresh_weights) makes dinoseg_forward use it instead of dinoseg_op_proj_mlp_fused.  vision_transformer.py:104-105, :123, :135 -> :59-65. */
 int64_t dinoseg_op_mlp4_pack_elems(int32_t D, int32_t F);
 int dinoseg_op_pack_mlp4(const float* Wproj, const float* W1, const float* W2, int32_t D, int32_t F, int32_t fmt, void* dst, void* stream);
 int dinoseg_op_proj_mlp_fused4(float* X, const void* ctx, const float* bproj, const float* gamma, const float* beta, float eps,

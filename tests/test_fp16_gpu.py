@@ -297,7 +297,7 @@ def test_g3_vits8_480_one_wave_fused_mlp_is_bounded(cuda, golden_dir, L, precisi
     lib = capi.lib()
     out = {}
     try:
-        for f4 in (0, 1):
+        for f4 in (1, 0):      # (the option is read when the weights are packed -- at the first forward of this model -- and at every forward)
             for k, v in (("mlp_fused", 2), ("proj_fused", 1), ("qkv_fused", 0), ("mlp_fused4", f4)):
                 capi.check(lib.dinoseg_set_option(k.encode(), v))
             lp, am = m.forward_frames(frames)

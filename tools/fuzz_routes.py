@@ -23,6 +23,11 @@ sd = procedural_state_dict(cfg)
 m = DINOSeg(head="mlp", n_blocks=3, precision=prec, arch=cfg)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
 m.to("cuda:0")
+if prec in ("bf16", "fp16"):      # (option mlp_fused4 is read when the weights are packed: at the first forward)
+    dino_amd.set_option("mlp_fused4", 1)
+    m.set_resolution(64)
+    m.forward_frames(torch.from_numpy(synthetic_frames(1, 64, seed=1)).cuda())
+    torch.cuda.synchronize()
 worst = 0.0
 for c in range(cases):
     r = int(rng.choice([64, 96, 120, 168, 200, 248, 320, 400, 480]))
@@ -67,6 +72,8 @@ for c in range(cases):
         line += f" {name} {err:.1e}/{100 * flips:.2f}%"
         assert err <= tol and flips <= flip_tol, (name, r, B, err, flips)
     assert torch.equal(outs["two streams"][0], outs["fused+proj"][0]), ("two streams differ", r, B)
+    if single:
+        assert not torch.equal(outs["one wave"][0], outs["fused+proj"][0]), ("option mlp_fused4 took no effect", r, B)
     if single:
         assert torch.equal(outs["two streams+qkv"][0], outs["fused+proj+qkv"][0]), ("two streams + qkv differ", r, B)
     print(line, flush=True)
