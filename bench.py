@@ -467,6 +467,11 @@ def main():
     # rehearsal of the N > 1 code path on a one-GPU box: DINOSEG_BENCH_REHEARSAL=1 puts every rank on device 0 and uses gloo
     # (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank over RCCL
     rehearsal = os.environ.get("DINOSEG_BENCH_REHEARSAL") == "1"
+    if not rehearsal and world > 1 and torch.cuda.device_count() < world:
+        # (sysfs may list GPUs this process cannot open; every rank sees the same count, so every rank takes the same decision)
+        if rank == 0:
+            print(f"bench.py: {torch.cuda.device_count()} usable GPU(s) for {world} ranks: rehearsal mode (all ranks on device 0, gloo)", file=sys.stderr)
+        rehearsal = True
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
