@@ -25,6 +25,7 @@ constraints; hipcc only moves the inputs in and the accumulators out.
 """
 import argparse
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -345,12 +346,64 @@ BODIES = (("AZA_BODY_BF16", "v_mfma_f32_32x32x16_bf16", 1, 0), ("AZA_BODY_FP16",
           ("AZA_BODY_ABL3", "v_mfma_f32_32x32x16_bf16", 1, 4), ("AZA_BODY_ABL4", "v_mfma_f32_32x32x16_bf16", 1, 8))
 
 
+# -- MFMA write -> vector read hazard (hipcc pads nothing inside an asm statement) --
+_RE_RANGE = re.compile(r"v\[(\d+):(\d+)\]")
+_RE_ONE = re.compile(r"\bv(\d+)\b")
+MFMA_TO_VALU_WAIT_STATES = 11      # an 8-pass XDL result read by a VALU / LDS / memory instruction (CDNA3 ISA guide, data hazards)
+MFMA_TO_END_WAIT_STATES = 18       # ... and by whatever the compiler places behind the statement
+
+
+def _regs(tok):
+    out = set()
+    for a, b in _RE_RANGE.findall(tok):
+        out |= set(range(int(a), int(b) + 1))
+    for a in _RE_ONE.findall(_RE_RANGE.sub("", tok)):
+        out.add(int(a))
+    return out
+
+
+def check_mfma_hazards(name, lines):
+    """Every register an MFMA writes must not be read by a non-MFMA instruction fewer than MFMA_TO_VALU_WAIT_STATES wait states later, in
+    text order (an instruction = one wait state, `s_nop k` = k + 1: a lower bound of the real distance, an MFMA issue takes longer), nor sit
+    closer than MFMA_TO_END_WAIT_STATES to the end of the body.  Returns the smallest distance found."""
+    last, clock, worst = {}, 0, (10 ** 9, None)
+    for ln in lines:
+        t = ln.strip()
+        if not t or t.startswith(";") or t.endswith(":"):
+            continue
+        op, _, rest = t.partition(" ")
+        ops = [x.strip() for x in rest.split(",")] if rest else []
+        if op == "s_nop":
+            clock += int(ops[0]) + 1
+            continue
+        if op.startswith("v_mfma"):
+            clock += 1
+            for r in _regs(ops[0]):
+                last[r] = clock
+            continue
+        if op.startswith(("v_", "ds_", "global_")):
+            first_src = 0 if op.startswith(("global_store", "ds_write")) else 1
+            for tok in ops[first_src:]:
+                for r in _regs(tok):
+                    if r in last and clock - last[r] < worst[0]:
+                        worst = (clock - last[r], t)
+            if op.startswith("v_") and ops:
+                for r in _regs(ops[0]):
+                    last.pop(r, None)
+        clock += 1
+    assert worst[0] >= MFMA_TO_VALU_WAIT_STATES, f"{name}: `{worst[1]}` reads an MFMA result {worst[0]} wait states after its write"
+    tail = min((clock - c for c in last.values()), default=10 ** 9)
+    assert tail >= MFMA_TO_END_WAIT_STATES, f"{name}: an MFMA result is {tail} wait states old at the end of the body"
+    return worst[0]
+
+
 def render():
     out = ["// GENERATED by tools/gen_attn_asm.py -- do not edit (python tools/gen_attn_asm.py rewrites it; --check compares).",
            "// The tile loop of attn_fwd_za_kernel (attention_za.hip) as one inline-asm body per (queries per wave, operand format); register",
            "// map, pipeline and the lgkmcnt bookkeeping are described in the generator.  AZA_BODY_ABL*: timing-only ablations (-DAZA_ABLATIONS).", ""]
     for name, op, mq, abl in BODIES:
         e = generate(op, mq, abl) if mq > 0 else generate(op, 2, abl, qbs=(0,))      # (-1: the one-block body on the two-block map)
+        check_mfma_hazards(name, e.lines)
         if abl:
             out.append("#ifdef AZA_ABLATIONS")
         out.append(f"// {e.n_inst} instructions")
@@ -372,6 +425,7 @@ def render():
                           ("AZA3_BODY_ABL1", "v_mfma_f32_32x32x16_bf16", 16), ("AZA3_BODY_ABL2", "v_mfma_f32_32x32x16_bf16", 32),
                           ("AZA3_BODY_ABL3", "v_mfma_f32_32x32x16_bf16", 64), ("AZA3_BODY_ABL4", "v_mfma_f32_32x32x16_bf16", 128)):
         e = generate3(op, abl)
+        check_mfma_hazards(name, e.lines)
         if abl:
             out.append("#ifdef AZA_ABLATIONS")
         out.append(f"// {e.n_inst} instructions")
