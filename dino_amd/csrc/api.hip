@@ -199,7 +199,9 @@ extern "C" int dinoseg_bind_weight(dinoseg_handle* h, const char* name, const vo
                 h->packed_qkvf.clear();
                 h->packed_mlp3.clear();
     h->packed_mlp4.clear();
+    h->packed_rs_bias.clear();
                 h->packed_mlp4.clear();
+                h->packed_rs_bias.clear();
                 h->packed_rs.clear();
                 h->bound.clear();
                 h->grads.clear();
@@ -285,8 +287,10 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
         if (sp.N == 768 && sp.K % 192 == 0 && (sp.wname.find("attn.proj.weight") != std::string::npos || sp.wname.find("mlp.fc2.weight") != std::string::npos)) return 1;
         return -1;
     };
+    // (kind 0 with option gemm_rs_ln, read here: the copy carries the LayerNorm in front of the linear -- norm1 for qkv, norm2 for fc1 -- and a folded bias)
+    auto rs_ln = [&](const LinSpec& sp) -> bool { return rs_kind(sp) == 0 && options().gemm_rs_ln; };
     for (const LinSpec& sp : specs)
-        if (rs_kind(sp) >= 0) total += align_up((size_t)sp.N * sp.K * sizeof(bf16_t), 256);
+        if (rs_kind(sp) >= 0) total += align_up((size_t)sp.N * sp.K * sizeof(bf16_t), 256) + (rs_ln(sp) ? align_up((size_t)sp.N * sizeof(float), 256) : 0);
     if (mlp3_fusable) total += (size_t)h->cfg.n_blocks * align_up((size_t)mlp_fused3_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
     if (mlp4_fusable) total += (size_t)h->cfg.n_blocks * align_up((size_t)mlp_fused4_pack_elems(Dm, Fh) * sizeof(bf16_t), 256);
     if (mlp_fusable)
@@ -335,7 +339,16 @@ extern "C" int dinoseg_refresh_weights(dinoseg_handle* h, void* stream) {
         if (rs_kind(sp) >= 0) {
             bf16_t* dst = reinterpret_cast<bf16_t*>(h->wbuf + off);
             off += align_up((size_t)sp.N * sp.K * sizeof(bf16_t), 256);
-            DSEG_TRY(launch_pack_rs(W(h, sp.wname), sp.N, sp.K, rs_kind(sp), dst, s, sp.fmt));
+            if (rs_ln(sp)) {
+                float* fb = reinterpret_cast<float*>(h->wbuf + off);
+                off += align_up((size_t)sp.N * sizeof(float), 256);
+                const std::string blk = sp.wname.substr(0, sp.wname.find(sp.wname.find("attn.qkv") != std::string::npos ? "attn.qkv" : "mlp.fc1"));
+                const std::string nrm = blk + (sp.wname.find("attn.qkv") != std::string::npos ? "norm1" : "norm2");
+                DSEG_TRY(launch_pack_rs_ln(W(h, sp.wname), W(h, nrm + ".weight"), W(h, nrm + ".bias"), W(h, sp.bname), sp.N, sp.K, dst, fb, s, sp.fmt));
+                h->packed_rs_bias[sp.wname] = fb;
+            } else {
+                DSEG_TRY(launch_pack_rs(W(h, sp.wname), sp.N, sp.K, rs_kind(sp), dst, s, sp.fmt));
+            }
             h->packed_rs[sp.wname] = dst;
         }
     if (mlp3_fusable)
@@ -564,13 +577,15 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
     // a block linear through the row-stationary streaming kernels (gemm_rs.hip) where a fragment-order copy exists and the batch fills the chip
     // ... and with the LayerNorm in front of it in its prologue (qkv / fc1 of the wide model: no LayerNorm launch, no 16-bit A round trip)
     auto rs_takes_ln = [&](const std::string& wname) -> bool {
-        return options().gemm_rs && options().gemm_rs_ln && disp_M >= options().gemm_rs_min_rows && h->packed_rs.count(wname) && P == 1 &&
+        return options().gemm_rs && options().gemm_rs_ln && disp_M >= options().gemm_rs_min_rows && h->packed_rs_bias.count(wname) && P == 1 &&
                !(mreq && mreq->cls_mask);
     };
     auto gemm_any = [&](GemmParams& g, const std::string& wname) -> int {
-        if (options().gemm_rs && disp_M >= options().gemm_rs_min_rows && h->packed_rs.count(wname)) {
+        // (a copy that carries the LayerNorm serves only the launch with the LayerNorm inside)
+        if (options().gemm_rs && disp_M >= options().gemm_rs_min_rows && h->packed_rs.count(wname) && (g.ln_x != nullptr) == (h->packed_rs_bias.count(wname) != 0)) {
             GemmParams r = g;
             r.W = h->packed_rs.at(wname);
+            if (g.ln_x) r.bias = h->packed_rs_bias.at(wname);
             if (gemm_rs_supported(r)) return launch_gemm_rs(r, s);
         }
         if (g.ln_x) {      // (rs_takes_ln said the LayerNorm runs inside: no normalised A exists for another kernel)
@@ -653,7 +668,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
         {
             const PackedLinear& pk = h->packed.at(b + "attn.qkv.weight");
             GemmParams g = {};
-            if (ln_inside) { g.ln_x = X; g.ln_gamma = W(h, b + "norm1.weight"); g.ln_beta = W(h, b + "norm1.bias"); g.ln_eps = c.ln_eps; }
+            if (ln_inside) { g.ln_x = X; g.ln_eps = c.ln_eps; }
             g.A = A; g.a_plane = L.a_plane; g.lda = D;
             g.W = pk.w; g.w_plane = pk.plane;
             g.M = L.M; g.N = 3 * D; g.K = D; g.planes = P; g.fmt = FM; g.epi = EPI_QKV; g.dispatch_rows = disp_M;
@@ -784,7 +799,7 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
         {
             const PackedLinear& pk = h->packed.at(b + "mlp.fc1.weight");
             GemmParams g = {};
-            if (ln_inside) { g.ln_x = X; g.ln_gamma = W(h, b + "norm2.weight"); g.ln_beta = W(h, b + "norm2.bias"); g.ln_eps = c.ln_eps; }
+            if (ln_inside) { g.ln_x = X; g.ln_eps = c.ln_eps; }
             g.A = A; g.a_plane = L.a_plane; g.lda = D;
             g.W = pk.w; g.w_plane = pk.plane;
             g.M = L.M; g.N = F; g.K = D; g.planes = P; g.fmt = FM; g.epi = EPI_GELU; g.dispatch_rows = disp_M;
@@ -1198,16 +1213,22 @@ extern "C" int dinoseg_op_gemm_rs(const void* A, int32_t lda, const void* Wp, co
     return launch_gemm_rs(g, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int dinoseg_op_ln_gemm_rs(const float* X, const float* gamma, const float* beta, float eps, const void* Wp, const float* bias, int32_t M,
-                                     int32_t N, int32_t K, int32_t epi, void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok,
-                                     int32_t npad, int32_t heads, float qscale, void* stream) {
-    if (!X || !gamma || !beta) {
-        dinoseg_set_error("dinoseg_op_ln_gemm_rs: null rows / LayerNorm constants");
+extern "C" int dinoseg_op_pack_rs_ln(const float* W, const float* gamma, const float* beta, const float* bias, int32_t N, int32_t K, void* dst_w,
+                                     float* dst_bias, void* stream) {
+    return launch_pack_rs_ln(W, gamma, beta, bias, N, K, reinterpret_cast<bf16_t*>(dst_w), dst_bias, reinterpret_cast<hipStream_t>(stream),
+                             options().op_fmt);
+}
+
+extern "C" int dinoseg_op_ln_gemm_rs(const float* X, float eps, const void* Wp, const float* bias_folded, int32_t M, int32_t N, int32_t K,
+                                     int32_t epi, void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok, int32_t npad, int32_t heads,
+                                     float qscale, void* stream) {
+    if (!X) {
+        dinoseg_set_error("dinoseg_op_ln_gemm_rs: null rows");
         return -1;
     }
     GemmParams g = {};
-    g.ln_x = X; g.ln_gamma = gamma; g.ln_beta = beta; g.ln_eps = eps;
-    g.W = reinterpret_cast<const bf16_t*>(Wp); g.bias = bias;
+    g.ln_x = X; g.ln_eps = eps;
+    g.W = reinterpret_cast<const bf16_t*>(Wp); g.bias = bias_folded;
     g.M = M; g.N = N; g.K = K; g.planes = 1; g.fmt = options().op_fmt; g.epi = epi;
     g.out_bf16 = reinterpret_cast<bf16_t*>(out16); g.ldo = ldo;
     g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);

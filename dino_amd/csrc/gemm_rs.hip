@@ -24,7 +24,10 @@ namespace dseg {
 //                                  k = 16 ks + 8 (lane >> 5) + e
 //               -> kind 1 (cstat, N = 768): [half nh of N][pair k2 of k-tiles = K / 64][fragment 24 kk + 2 db + s2][64 lanes][8]: A row = output
 //                                  feature 384 nh + 32 db + sigma23(lane & 31), k = 64 k2 + 32 kk + 16 s2 + 8 (lane >> 5) + e
-__global__ __launch_bounds__(256) void pack_rs_kernel(const float* __restrict__ W, int N, int K, int kind, bf16_t* __restrict__ dst, int fmt) {
+// gamma (kind 0, optional): the weight of the LayerNorm in front of the linear, folded into its columns -- LayerNorm(x) W^T + b =
+// ((x - mean) rstd) (W . diag(gamma))^T + (b + W beta): the kernel's LayerNorm prologue then needs no per-feature constants (fold_ln_bias_kernel)
+__global__ __launch_bounds__(256) void pack_rs_kernel(const float* __restrict__ W, int N, int K, int kind, bf16_t* __restrict__ dst, int fmt,
+                                                      const float* __restrict__ gamma) {
     const long total = (long)N * K;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         long q = idx;
@@ -35,6 +38,7 @@ __global__ __launch_bounds__(256) void pack_rs_kernel(const float* __restrict__ 
         if (kind == 0) {
             const int ks = (int)(q % (K / 16)), n = (int)(q / (K / 16));
             v = W[(long)(n * 32 + i) * K + ks * 16 + h * 8 + e];
+            if (gamma) v *= gamma[ks * 16 + h * 8 + e];
         } else {      // [half of N][pair of k-tiles][fragment 24 kk + 2 db + s2]
             const int fr = (int)(q % 48); q /= 48;
             const int k2 = (int)(q % (K / 64)), nh = (int)(q / (K / 64));
@@ -50,7 +54,33 @@ int launch_pack_rs(const float* W, int N, int K, int kind, bf16_t* dst, hipStrea
         dinoseg_set_error("pack_rs: null pointer or unsupported shape N=%d K=%d kind=%d", N, K, kind);
         return -1;
     }
-    hipLaunchKernelGGL(pack_rs_kernel, dim3(1024), dim3(256), 0, s, W, N, K, kind, dst, fmt);
+    hipLaunchKernelGGL(pack_rs_kernel, dim3(1024), dim3(256), 0, s, W, N, K, kind, dst, fmt, (const float*)nullptr);
+    DSEG_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// out[n] = bias[n] + sum_k W[n][k] beta[k]  (fp32; one wave per output feature)
+__global__ __launch_bounds__(256) void fold_ln_bias_kernel(const float* __restrict__ W, const float* __restrict__ beta, const float* __restrict__ bias,
+                                                           int N, int K, float* __restrict__ out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc = fmaf(W[(long)n * K + k], beta[k], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[n] = bias[n] + acc;
+}
+
+// the kind-0 copy of W with the LayerNorm in front of the linear folded in (gamma into the columns, beta into the bias): what launch_gemm_rs
+// reads when GemmParams::ln_x is set
+int launch_pack_rs_ln(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, bf16_t* dst_w, float* dst_bias,
+                      hipStream_t s, int fmt) {
+    if (!W || !gamma || !beta || !bias || !dst_w || !dst_bias || N % 32 != 0 || K % 64 != 0) {
+        dinoseg_set_error("pack_rs_ln: null pointer or unsupported shape N=%d K=%d", N, K);
+        return -1;
+    }
+    hipLaunchKernelGGL(pack_rs_kernel, dim3(1024), dim3(256), 0, s, W, N, K, 0, dst_w, fmt, gamma);
+    hipLaunchKernelGGL(fold_ln_bias_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, beta, bias, N, K, dst_bias);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -62,8 +92,9 @@ int launch_pack_rs(const float* W, int N, int K, int kind, bf16_t* dst, hipStrea
 //  an uncounted asm instruction: the same time, launch for launch (profiles/r06_gemm_rs.md), and two hazards hipcc does not pad around inline asm
 //  on the way: a VALU-written SGPR pair read by an asm VMEM instruction needs `s_nop 4` in front, an asm store's data registers two wait states
 //  behind.  The plain form below has neither.)
-// LN: the stationary rows are LayerNorm(ln_x) computed here -- the fp32 row of a lane (384 values) is loaded once, normalised in registers (two-pass
-// statistics, one cross-half shuffle) and packed into the fragments: no LayerNorm launch, no 16-bit A round trip (vision_transformer.py:122 / :134)
+// LN: the stationary rows are (ln_x - mean) rstd computed here -- the fp32 row of a lane (384 values) is loaded once, normalised in registers (two-pass
+// statistics, one cross-half shuffle) and packed into the fragments; the LayerNorm's weight and bias are folded into p.W / p.bias (launch_pack_rs_ln):
+// no LayerNorm launch, no 16-bit A round trip (vision_transformer.py:122 / :134)
 template <int FMT, int EPI, int KS, bool LN>
 __global__ __launch_bounds__(rs::THREADS, 1) void gemm_bstat_kernel(GemmParams p) {
     using namespace rs;
@@ -118,21 +149,15 @@ __global__ __launch_bounds__(rs::THREADS, 1) void gemm_bstat_kernel(GemmParams p
             }
             qv += __shfl_xor(qv, 32);
             const float rstd = 1.0f / sqrtf(qv * (1.0f / (KS * 16)) + p.ln_eps);
-            float mean_n = mean;
-            asm volatile("" : "+v"(mean_n));
-            const float* gp = p.ln_gamma + lh_i * 8;
-            const float* bp = p.ln_beta + lh_i * 8;
+            // (no per-feature constants: the LayerNorm's weight and bias are folded into W and the bias -- launch_pack_rs_ln)
+            const float nmr = -mean * rstd;
 #pragma unroll
             for (int k = 0; k < KS; ++k) {
-                asm volatile("" ::: "memory");      // (one k-step of constants in flight: hoisted, the loads of a row's constants would need 384 registers)
-                __builtin_amdgcn_sched_barrier(0);
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp + k * 16), g1 = *reinterpret_cast<const f32x4*>(gp + k * 16 + 4);
-                const f32x4 e0 = *reinterpret_cast<const f32x4*>(bp + k * 16), e1 = *reinterpret_cast<const f32x4*>(bp + k * 16 + 4);
                 float y[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    y[e] = (r[2 * k][e] - mean_n) * rstd * g0[e] + e0[e];
-                    y[4 + e] = (r[2 * k + 1][e] - mean_n) * rstd * g1[e] + e1[e];
+                    y[e] = fmaf(r[2 * k][e], rstd, nmr);
+                    y[4 + e] = fmaf(r[2 * k + 1][e], rstd, nmr);
                 }
                 uint4 u;
                 u.x = pack2_sat<FMT>(y[0], y[1]);
@@ -413,7 +438,7 @@ __global__ __launch_bounds__(rs::THREADS, 1) void gemm_cstat_kernel(GemmParams p
 
 // ------------------------------------------------------------------------------------------------ host
 bool gemm_rs_supported(const GemmParams& p) {
-    if (p.planes != 1 || p.bias == nullptr || p.M < 1 || (p.ln_x == nullptr && p.lda % 8 != 0) || (p.ln_x != nullptr && (p.epi == EPI_RESID || !p.ln_gamma || !p.ln_beta)) || p.resid != nullptr || p.aux_out != nullptr || p.ksplit > 1) return false;
+    if (p.planes != 1 || p.bias == nullptr || p.M < 1 || (p.ln_x == nullptr && p.lda % 8 != 0) || (p.ln_x != nullptr && p.epi == EPI_RESID) || p.resid != nullptr || p.aux_out != nullptr || p.ksplit > 1) return false;
     if (p.epi == EPI_RESID) return p.N == 768 && p.K % 192 == 0 && p.K >= 576 && p.ldo_f32 == p.N && p.out_f32 != nullptr;
     if (p.epi == EPI_GELU) return p.K == 768 && p.N % 64 == 0 && p.N >= 128 && p.ldo % 8 == 0 && p.N * 4 <= 16 * 1024 && p.out_bf16 != nullptr;
     if (p.epi == EPI_QKV) return p.K == 768 && p.dmodel == 768 && p.N == 3 * p.dmodel && p.heads * 64 == p.dmodel && p.q && p.k && p.v;

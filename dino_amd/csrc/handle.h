@@ -44,6 +44,7 @@ struct dinoseg_handle {
     std::map<std::string, bf16_t*> packed_mlp;      // per block ("dino.blocks.i."): fc1 + fc2 in MFMA fragment order (mlp_fused2.hip)
     std::map<std::string, bf16_t*> packed_proj;     // per block: attn.proj.weight in the same fragment order (mlp_fused2.hip, PROJ)
     std::map<std::string, bf16_t*> packed_rs;       // per Linear weight name, one-plane modes at embed_dim 768: the fragment-order copy gemm_rs.hip streams
+    std::map<std::string, float*> packed_rs_bias;   // ... those of them that carry the LayerNorm in front of the linear (qkv / fc1, option gemm_rs_ln at refresh): the folded bias
     std::map<std::string, bf16_t*> packed_mlp4;     // per block, one-plane modes: attn.proj + fc1 + fc2 as the slot stream of mlp_fused4.hip
     std::map<std::string, bf16_t*> packed_mlp3;     // per block, hi + lo modes: attn.proj + fc1 + fc2 as the slot stream of mlp_fused3.hip
     std::map<std::string, bf16_t*> packed_qkvf;     // per block: attn.qkv.weight in fragment order (mlp_fused2.hip, QKV tail of the block before)

@@ -48,8 +48,9 @@ struct GemmParams {
                                                 // half-batches of a split forward take the route of the whole batch (same summation order)
     int ksplit;                                 // >1: split the K loop over grid.y (EPI_ATOMIC, or EPI_PLAIN partial tiles)
     long split_stride;                          // EPI_PLAIN with ksplit > 1: slice y writes out_f32 + y * split_stride (floats)
-    // launch_gemm_rs, EPI_GELU / EPI_QKV only: A = LayerNorm(ln_x) computed in the kernel's prologue (ln_x fp32 [M][K] rows, row stride K; A unused)
-    const float* ln_x; const float* ln_gamma; const float* ln_beta; float ln_eps;
+    // launch_gemm_rs, EPI_GELU / EPI_QKV only: A = (ln_x - mean) rstd per row, computed in the kernel's prologue (ln_x fp32 [M][K] rows, row stride K;
+    // A unused); W / bias = launch_pack_rs_ln's copies, which carry the LayerNorm's weight and bias
+    const float* ln_x; float ln_eps;
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);       // dispatches between the two kernels below
 int launch_gemm_small(const GemmParams& p, hipStream_t s); // 128x128 tile, bf16 or bf16x3 (gemm.hip)
@@ -60,6 +61,8 @@ int launch_gemm_big(const GemmParams& p, hipStream_t s);   // 256x384 persistent
 // (kind 0 for EPI_GELU / EPI_QKV: K = 768; kind 1 for EPI_RESID: N = 768, in place on out_f32)
 bool gemm_rs_supported(const GemmParams& p);
 int launch_pack_rs(const float* W, int N, int K, int kind, bf16_t* dst, hipStream_t s, int fmt);
+int launch_pack_rs_ln(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, bf16_t* dst_w, float* dst_bias,
+                      hipStream_t s, int fmt);
 int launch_gemm_rs(const GemmParams& p, hipStream_t s);
 
 // LayerNorm-fused A-stationary GEMM for qkv / fc1 (gemm_ln.hip): X fp32 rows are normalised in the prologue, W streams

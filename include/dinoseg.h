@@ -286,11 +286,16 @@ int dinoseg_op_proj_mlp_fused(float* X, const void* ctx, const void* Wproj, cons
  * dinoseg_forward uses them for ViT-B/8 batches of >= option "gemm_rs_min_rows" rows; option "gemm_rs" is a bit per linear (1 mlp.fc1,
  * 2 attn.qkv, 4 attn.proj + mlp.fc2; default 3: the two that measure faster than the generic kernel). */
 int dinoseg_op_pack_rs(const float* W, int32_t N, int32_t K, int32_t kind, void* dst, void* stream);
-/* ... with the LayerNorm in front of the linear in the kernel's prologue (epi 2 / 4 only): A = LayerNorm(X) with X fp32 [M][K] rows, K = 768 --
- * `self.qkv(self.norm1(x))` / `self.fc1(self.norm2(x))` (vision_transformer.py:122 -> :75, :134 -> :60).  Library option "gemm_rs_ln" (default 1). */
-int dinoseg_op_ln_gemm_rs(const float* X, const float* gamma, const float* beta, float eps, const void* Wp, const float* bias, int32_t M,
-                          int32_t N, int32_t K, int32_t epi, void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok, int32_t npad,
-                          int32_t heads, float qscale, void* stream);
+/* ... with the LayerNorm in front of the linear inside the launch (epi 2 / 4 only): `self.qkv(self.norm1(x))` / `self.fc1(self.norm2(x))`
+ * (vision_transformer.py:122 -> :75, :134 -> :60), X fp32 [M][K] rows, K = 768.  The kernel's prologue computes (x - mean) rstd per row; the LayerNorm's
+ * weight and bias ride in the packed copy: dinoseg_op_pack_rs_ln writes W . diag(gamma) in fragment order (N * K 16-bit elements) and the folded bias
+ * bias + W beta ([N] fp32) -- LayerNorm(x) W^T + b = ((x - mean) rstd) (W diag(gamma))^T + (b + W beta).  Library option "gemm_rs_ln" (default 1, read by
+ * dinoseg_refresh_weights). */
+int dinoseg_op_pack_rs_ln(const float* W, const float* gamma, const float* beta, const float* bias, int32_t N, int32_t K, void* dst_w,
+                          float* dst_bias, void* stream);
+int dinoseg_op_ln_gemm_rs(const float* X, float eps, const void* Wp, const float* bias_folded, int32_t M, int32_t N, int32_t K, int32_t epi,
+                          void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok, int32_t npad, int32_t heads, float qscale,
+                          void* stream);
 int dinoseg_op_gemm_rs(const void* A, int32_t lda, const void* Wp, const float* bias, int32_t M, int32_t N, int32_t K, int32_t epi,
                        float* x_inout, void* out16, int32_t ldo, void* q, void* k, void* v, int32_t ntok, int32_t npad, int32_t heads,
                        float qscale, void* stream);
