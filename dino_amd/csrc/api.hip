@@ -535,8 +535,14 @@ static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s) {
     for (int i = 0; i < h->cfg.n_blocks; ++i) {      // (block i's stream ends with the qkv weight of block i + 1: the tail of its fused launch)
         const std::string b = "dino.blocks." + std::to_string(i) + ".", nb = "dino.blocks." + std::to_string(i + 1) + ".";
         if (!h->packed_mlp3.count(b)) continue;
-        DSEG_TRY(launch_pack_mlp3(W(h, b + "attn.proj.weight"), W(h, b + "mlp.fc1.weight"), W(h, b + "mlp.fc2.weight"),
-                                  i + 1 < h->cfg.n_blocks ? W(h, nb + "attn.qkv.weight") : nullptr, Dm, Fh, h->packed_mlp3.at(b), s, h->fmt));
+        MlpFused3Weights w = {};
+        w.Wproj = W(h, b + "attn.proj.weight"); w.W1 = W(h, b + "mlp.fc1.weight"); w.b1 = W(h, b + "mlp.fc1.bias"); w.W2 = W(h, b + "mlp.fc2.weight");
+        w.gamma2 = W(h, b + "norm2.weight"); w.beta2 = W(h, b + "norm2.bias");
+        if (i + 1 < h->cfg.n_blocks) {
+            w.Wqkv_next = W(h, nb + "attn.qkv.weight"); w.bqkv_next = W(h, nb + "attn.qkv.bias");
+            w.gamma1_next = W(h, nb + "norm1.weight"); w.beta1_next = W(h, nb + "norm1.bias");
+        }
+        DSEG_TRY(launch_pack_mlp3(w, Dm, Fh, h->packed_mlp3.at(b), s, h->fmt));
     }
     h->packed_mlp_stale = false;
     return 0;
@@ -740,15 +746,13 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             DSEG_TRY(ensure_mlp_packs(h, s));
             // projection + LN2 + fc1 + GELU + fc2 + residual on hi + lo planes in one launch (mlp_fused3.hip)
             MlpFused3Params g = {};
-            g.X = X; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
-            g.Wp = h->packed_mlp3.at(b); g.b1 = W(h, b + "mlp.fc1.bias"); g.b2 = W(h, b + "mlp.fc2.bias");
+            g.X = X; g.eps = c.ln_eps;
+            g.Wp = h->packed_mlp3.at(b); g.b2 = W(h, b + "mlp.fc2.bias");
             g.M = L.M; g.fmt = FM;
             if (fuse_proj) {
                 g.ctx = CTX; g.ctx_plane = L.ctx_plane; g.bproj = W(h, b + "attn.proj.bias");
                 // ... and LayerNorm1 + qkv of the next block (a tap of this block's output still reads X, which is complete)
                 if (options().qkv_fused3 && i + 1 < c.n_blocks && L.qkv_plane < (1L << 31)) {
-                    const std::string nb = "dino.blocks." + std::to_string(i + 1) + ".";
-                    g.bqkv = W(h, nb + "attn.qkv.bias"); g.gamma1 = W(h, nb + "norm1.weight"); g.beta1 = W(h, nb + "norm1.bias");
                     g.q = Q; g.k = Kb; g.v = V; g.qkv_plane = L.qkv_plane;
                     g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.qscale = qscale; g.v_bf16 = v_bf16;
                     qkv_ready = true;
@@ -1238,26 +1242,43 @@ extern "C" int dinoseg_op_ln_gemm_rs(const float* X, float eps, const void* Wp, 
 
 extern "C" int64_t dinoseg_op_mlp3_pack_elems(int32_t D, int32_t F) { return mlp_fused3_pack_elems(D, F); }
 
-extern "C" int dinoseg_op_pack_mlp3(const float* Wproj, const float* W1, const float* W2, const float* Wqkv_next, int32_t D, int32_t F,
-                                    int32_t fmt, void* dst, void* stream) {
+extern "C" int dinoseg_op_pack_mlp3(const float* Wproj, const float* W1, const float* b1, const float* W2, const float* gamma2, const float* beta2,
+                                    const float* Wqkv_next, const float* bqkv_next, const float* gamma1_next, const float* beta1_next, int32_t D,
+                                    int32_t F, int32_t fmt, void* dst, void* stream) {
     if (fmt != FMT_BF16 && fmt != FMT_FP16) {
         dinoseg_set_error("dinoseg_op_pack_mlp3: bad operand format %d", fmt);
         return -1;
     }
-    return launch_pack_mlp3(Wproj, W1, W2, Wqkv_next, D, F, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), fmt);
+    MlpFused3Weights w = {Wproj, W1, b1, W2, gamma2, beta2, Wqkv_next, bqkv_next, gamma1_next, beta1_next};
+    return launch_pack_mlp3(w, D, F, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), fmt);
 }
 
-extern "C" int dinoseg_op_proj_mlp_fused3(float* X, const void* ctx, int64_t ctx_plane, const float* bproj, const float* gamma,
-                                          const float* beta, float eps, const void* Wp, const float* b1, const float* b2, int32_t M,
-                                          int32_t D, int32_t F, int32_t fmt, void* stream) {
+extern "C" int dinoseg_op_proj_mlp_fused3(float* X, const void* ctx, int64_t ctx_plane, const float* bproj, float eps, const void* Wp, const float* b2,
+                                          int32_t M, int32_t D, int32_t F, int32_t fmt, void* stream) {
     if (!mlp_fused3_supported(D, F, 2) || (fmt != FMT_BF16 && fmt != FMT_FP16)) {
         dinoseg_set_error("dinoseg_op_proj_mlp_fused3: unsupported shape D=%d F=%d or format %d", D, F, fmt);
         return -1;
     }
     MlpFused3Params g = {};
-    g.X = X; g.gamma = gamma; g.beta = beta; g.eps = eps;
-    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
+    g.X = X; g.eps = eps;
+    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b2 = b2; g.M = M;
     g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.ctx_plane = ctx_plane; g.bproj = bproj; g.fmt = fmt;
+    return launch_mlp_fused3(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_block_tail_fused3(float* X, const void* ctx, int64_t ctx_plane, const float* bproj, float eps, const void* Wp,
+                                            const float* b2, void* q, void* k, void* v, int64_t qkv_plane, int32_t B, int32_t ntok, int32_t npad,
+                                            int32_t heads, float qscale, int32_t v_bf16, int32_t D, int32_t F, int32_t fmt, void* stream) {
+    if (!mlp_fused3_supported(D, F, 2) || (fmt != FMT_BF16 && fmt != FMT_FP16) || !q || B <= 0 || npad % 64 != 0) {
+        dinoseg_set_error("dinoseg_op_block_tail_fused3: unsupported shape D=%d F=%d, format %d, or null q", D, F, fmt);
+        return -1;
+    }
+    MlpFused3Params g = {};
+    g.X = X; g.eps = eps;
+    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b2 = b2; g.M = B * ntok;
+    g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.ctx_plane = ctx_plane; g.bproj = bproj; g.fmt = fmt;
+    g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v); g.qkv_plane = qkv_plane;
+    g.ntok = ntok; g.npad = npad; g.heads = heads; g.qscale = qscale; g.v_bf16 = v_bf16;
     return launch_mlp_fused3(g, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1284,25 +1305,6 @@ extern "C" int dinoseg_op_proj_mlp_fused4(float* X, const void* ctx, const float
     g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
     g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.bproj = bproj; g.fmt = fmt;
     return launch_mlp_fused4(g, reinterpret_cast<hipStream_t>(stream));
-}
-
-extern "C" int dinoseg_op_block_tail_fused3(float* X, const void* ctx, int64_t ctx_plane, const float* bproj, const float* gamma2,
-                                            const float* beta2, float eps, const void* Wp, const float* b1, const float* b2,
-                                            const float* bqkv, const float* gamma1, const float* beta1, void* q, void* k, void* v,
-                                            int64_t qkv_plane, int32_t B, int32_t ntok, int32_t npad, int32_t heads, float qscale,
-                                            int32_t v_bf16, int32_t D, int32_t F, int32_t fmt, void* stream) {
-    if (!mlp_fused3_supported(D, F, 2) || (fmt != FMT_BF16 && fmt != FMT_FP16) || !q || B <= 0 || npad % 64 != 0) {
-        dinoseg_set_error("dinoseg_op_block_tail_fused3: unsupported shape D=%d F=%d, format %d, or null q", D, F, fmt);
-        return -1;
-    }
-    MlpFused3Params g = {};
-    g.X = X; g.gamma = gamma2; g.beta = beta2; g.eps = eps;
-    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = B * ntok;
-    g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.ctx_plane = ctx_plane; g.bproj = bproj; g.fmt = fmt;
-    g.bqkv = bqkv; g.gamma1 = gamma1; g.beta1 = beta1;
-    g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v); g.qkv_plane = qkv_plane;
-    g.ntok = ntok; g.npad = npad; g.heads = heads; g.qscale = qscale; g.v_bf16 = v_bf16;
-    return launch_mlp_fused3(g, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t dinoseg_op_qkv_pack_elems(int32_t D) { return mlp_fused_qkv_pack_elems(D); }

@@ -119,24 +119,31 @@ int launch_mlp_fused2(const MlpFusedParams& p, hipStream_t s);     // role-split
 // given), then X += fc2(gelu(fc1(LayerNorm(X)))), in place, one launch, D = 384
 struct MlpFused3Params {
     float* X;                                   // residual stream [M, 384] fp32
-    const float* gamma; const float* beta; float eps;      // norm2
-    const bf16_t* Wp;                           // launch_pack_mlp3: proj + fc1 + fc2 as 108 slots of (lo, hi) fragment pairs, in stream order
-    const float* b1; const float* b2;           // [1536], [384]
+    float eps;                                  // LayerNorm epsilon (norm2; norm1 of the next block in the qkv tail)
+    const bf16_t* Wp;                           // launch_pack_mlp3: proj + fc1 + fc2 as 108 slots of (lo, hi) fragment pairs in stream order (+ the 36
+                                                // slots of the next block's Wqkv), then the folded biases -- the LayerNorms' weights and biases ride in it
+    const float* b2;                            // [384]
     int M;
     const bf16_t* ctx; long ctx_plane;          // attention output planes [2][M][384] (hi, then lo at + ctx_plane elements); null = MLP only
     const float* bproj;
     int fmt;                                    // operand format of ctx, the packed weights and everything in between (FMT_BF16 / FMT_FP16)
-    // optional (with ctx; q != null): LayerNorm1 + the qkv projection of the NEXT block at the end of the same launch -- Wp then carries the 36
-    // slots of that block's Wqkv behind the 108 of this one (launch_pack_mlp3 with Wqkv_next); Q pre-scaled by qscale
-    const float* bqkv; const float* gamma1; const float* beta1;
+    // optional (with ctx; q != null): LayerNorm1 + the qkv projection of the NEXT block at the end of the same launch (Wp packed with Wqkv_next);
+    // Q pre-scaled by qscale
     bf16_t* q; bf16_t* k; bf16_t* v; long qkv_plane;      // each [2][B, heads, npad, 64] (lo plane at + qkv_plane elements; rows >= ntok never written)
     int ntok, npad, heads; float qscale;
     int v_bf16;                                 // fmt == FMT_FP16: V as bf16 hi + lo planes (GemmParams::v_bf16)
+    // mlp_fused4.hip only (one plane; its LayerNorm2 is not folded):
+    const float* gamma; const float* beta; const float* b1;
+};
+// what launch_pack_mlp3 reads: the fp32 parameters of a block's second half (and of the next block's first linear)
+struct MlpFused3Weights {
+    const float* Wproj; const float* W1; const float* b1; const float* W2;
+    const float* gamma2; const float* beta2;                                         // norm2 of this block: folded into W1 / b1
+    const float* Wqkv_next; const float* bqkv_next; const float* gamma1_next; const float* beta1_next;      // nullable together: the qkv tail
 };
 bool mlp_fused3_supported(int D, int F, int planes);
-long mlp_fused3_pack_elems(int D, int F);       // 16-bit elements of the packed copy, qkv tail slots included (0: unsupported shape)
-int launch_pack_mlp3(const float* Wproj, const float* W1, const float* W2, const float* Wqkv_next /* nullable */, int D, int F, bf16_t* dst,
-                     hipStream_t s, int fmt);
+long mlp_fused3_pack_elems(int D, int F);       // 16-bit elements of the packed copy, qkv tail slots and folded biases included (0: unsupported shape)
+int launch_pack_mlp3(const MlpFused3Weights& w, int D, int F, bf16_t* dst, hipStream_t s, int fmt);
 int launch_mlp_fused3(const MlpFused3Params& p, hipStream_t s);
 // The same launch on ONE operand plane, one wave per SIMD (mlp_fused4.hip; MlpFused3Params without the plane strides and without a qkv tail):
 // Wp = launch_pack_mlp4's 54 slots of 48 fragments (Wproj may be null for an MLP-only copy: its six slots are zero and never read)

@@ -49,9 +49,14 @@ constexpr int NPT = D / 32;                         // projection k-tiles
 constexpr int NSLOT = NPT + 2 * NT;                 // slots per item (108)
 constexpr int RING = 3;
 constexpr int NQT = 3 * D / 32;                     // QKV tail: output tiles of 32 features (36)
-constexpr int B1_OFF = RING * SLOT;                 // b1 [F] fp32
-constexpr int BQ_OFF = B1_OFF + F * 4;              // QKV tail: the next block's qkv bias [1152] fp32
-constexpr int LDS_BYTES = BQ_OFF + 3 * D * 4;       // (the LayerNorm constants and the two residual biases are read from global memory: twice per item)
+constexpr int B1_OFF = RING * SLOT;                 // b1' [F] fp32 (b1 + W1 beta2: the LayerNorm in front of fc1 is folded into the packed copy)
+constexpr int BQ_OFF = B1_OFF + F * 4;              // QKV tail: the next block's folded qkv bias [1152] fp32
+constexpr int BP_OFF = BQ_OFF + 3 * D * 4;          // the two residual biases: b_proj, b2 [D] fp32 each
+constexpr int B2_OFF = BP_OFF + D * 4;
+constexpr int LDS_BYTES = B2_OFF + D * 4;
+// the packed copy of a block: NSLOT (+ NQT) slots, then the folded biases (fp32): b1' [F], bq' [3 D]
+constexpr long BIAS_OFF_BYTES = (long)(NSLOT + NQT) * SLOT;
+[[maybe_unused]] constexpr long PACK_BYTES = BIAS_OFF_BYTES + (F + 3 * D) * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr int PIECES = SLOT / 1024 / NW;            // LDS-DMA pieces per wave and step
 static_assert(PIECES == 12, "three groups of four pieces");
@@ -81,8 +86,11 @@ __host__ __device__ inline void mf3_slot_kind(int n, int& kind, int& t) {      /
 
 #if !defined(MF3_PART) || MF3_PART == 0
 // Wproj [384][384], W1 [1536][384], W2 [384][1536] fp32 -> [slot][pair][lo, hi][64 lanes][8] in the operand format
+// LayerNorm2's weight g2 is folded into the columns of W1 and the next block's LayerNorm1 weight g1n into those of Wqkv (their biases into b1 / bqkv:
+// fold_bias3_kernel): LayerNorm(x) W^T + b = ((x - mean) rstd) (W diag(g))^T + (b + W beta) -- the kernel's LayerNorms need no per-feature constants
 __global__ __launch_bounds__(256) void pack_mlp3_kernel(const float* __restrict__ Wpr, const float* __restrict__ W1, const float* __restrict__ W2,
-                                                        const float* __restrict__ Wqkv, bf16_t* __restrict__ dst, int fmt) {
+                                                        const float* __restrict__ Wqkv, const float* __restrict__ g2, const float* __restrict__ g1n,
+                                                        bf16_t* __restrict__ dst, int fmt) {
     using namespace mf3;
     const long total = (long)(NSLOT + (Wqkv ? NQT : 0)) * NKS * 512;      // (slot, pair, lane, e) tuples; each writes a lo and a hi element
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256) void pack_mlp3_kernel(const float* __restrict_
         mf3_slot_kind(slot, kind, t);
         float v;
         if (kind == 1 || kind == 3) {      // fc1 / qkv: A row = hidden unit / output feature, k = input feature, pair = k-step
-            v = (kind == 1 ? W1 : Wqkv)[(long)(t * HT + i) * D + pair * 16 + h * 8 + e];
+            v = (kind == 1 ? W1 : Wqkv)[(long)(t * HT + i) * D + pair * 16 + h * 8 + e] * (kind == 1 ? g2 : g1n)[pair * 16 + h * 8 + e];
         } else {              // proj / fc2: A row = output feature, k = the tile's 32 inputs, pair = (db, s2)
             const int db = pair >> 1, s2 = pair & 1;
             v = kind == 0 ? Wpr[(long)(db * 32 + i) * D + t * 32 + s2 * 16 + h * 8 + e] : W2[(long)(db * 32 + i) * F + t * HT + s2 * 16 + h * 8 + e];
@@ -109,16 +117,32 @@ __global__ __launch_bounds__(256) void pack_mlp3_kernel(const float* __restrict_
     }
 }
 
-long mlp_fused3_pack_elems(int Dm, int Fh) { return Dm == mf3::D && Fh == mf3::F ? (long)(mf3::NSLOT + mf3::NQT) * mf3::SLOT / 2 : 0; }
+long mlp_fused3_pack_elems(int Dm, int Fh) { return Dm == mf3::D && Fh == mf3::F ? mf3::PACK_BYTES / 2 : 0; }
+
+// out[n] = bias[n] + sum_k W[n][k] beta[k]  (fp32; one wave per output feature)
+__global__ __launch_bounds__(256) void fold_bias3_kernel(const float* __restrict__ W, const float* __restrict__ beta, const float* __restrict__ bias,
+                                                         int N, int K, float* __restrict__ out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc = fmaf(W[(long)n * K + k], beta[k], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[n] = bias[n] + acc;
+}
 bool mlp_fused3_supported(int Dm, int Fh, int planes) { return Dm == mf3::D && Fh == mf3::F && planes == 2; }
 
-int launch_pack_mlp3(const float* Wproj, const float* W1, const float* W2, const float* Wqkv_next, int Dm, int Fh, bf16_t* dst, hipStream_t s,
-                     int fmt) {
-    if (mlp_fused3_pack_elems(Dm, Fh) <= 0 || !Wproj || !W1 || !W2 || !dst) {
+int launch_pack_mlp3(const MlpFused3Weights& w, int Dm, int Fh, bf16_t* dst, hipStream_t s, int fmt) {
+    if (mlp_fused3_pack_elems(Dm, Fh) <= 0 || !w.Wproj || !w.W1 || !w.b1 || !w.W2 || !w.gamma2 || !w.beta2 || !dst ||
+        (w.Wqkv_next && (!w.bqkv_next || !w.gamma1_next || !w.beta1_next))) {
         dinoseg_set_error("pack_mlp3: null pointer or unsupported shape D=%d F=%d", Dm, Fh);
         return -1;
     }
-    hipLaunchKernelGGL(pack_mlp3_kernel, dim3(2048), dim3(256), 0, s, Wproj, W1, W2, Wqkv_next, dst, fmt);
+    hipLaunchKernelGGL(pack_mlp3_kernel, dim3(2048), dim3(256), 0, s, w.Wproj, w.W1, w.W2, w.Wqkv_next, w.gamma2, w.gamma1_next, dst, fmt);
+    float* fb = reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + mf3::BIAS_OFF_BYTES);
+    hipLaunchKernelGGL(fold_bias3_kernel, dim3((Fh + 3) / 4), dim3(256), 0, s, w.W1, w.beta2, w.b1, Fh, Dm, fb);
+    if (w.Wqkv_next)
+        hipLaunchKernelGGL(fold_bias3_kernel, dim3((3 * Dm + 3) / 4), dim3(256), 0, s, w.Wqkv_next, w.beta1_next, w.bqkv_next, 3 * Dm, Dm, fb + Fh);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -138,9 +162,16 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
     constexpr bool has_proj = PROJ;
 
     // ---- constants into LDS: b1 (and the next block's qkv bias)
-    for (int i = tid; i < F / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + B1_OFF)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
-    if constexpr (QKV)
-        for (int i = tid; i < 3 * D / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + BQ_OFF)[i] = reinterpret_cast<const f32x4*>(p.bqkv)[i];
+    {
+        const float* fb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.Wp) + BIAS_OFF_BYTES);      // folded b1', then bq'
+        for (int i = tid; i < F / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + B1_OFF)[i] = reinterpret_cast<const f32x4*>(fb)[i];
+        if constexpr (QKV)
+            for (int i = tid; i < 3 * D / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + BQ_OFF)[i] = reinterpret_cast<const f32x4*>(fb + F)[i];
+        for (int i = tid; i < D / 4; i += THREADS) {
+            if constexpr (PROJ) reinterpret_cast<f32x4*>(smem + BP_OFF)[i] = reinterpret_cast<const f32x4*>(p.bproj)[i];
+            reinterpret_cast<f32x4*>(smem + B2_OFF)[i] = reinterpret_cast<const f32x4*>(p.b2)[i];
+        }
+    }
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
     const float* const sB1 = reinterpret_cast<const float*>(smem + B1_OFF);
     const float* const sBq = reinterpret_cast<const float*>(smem + BQ_OFF);
@@ -311,21 +342,22 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
             });
         }
 
-        // ---- LayerNorm of the rows in o (register 8 s2 + j of block db = feature 32 db + 16 s2 + 8 lh + j) -> xh / xl as hi + lo fragments.
-        // pre / post (optional, [D] fp32): added to o before the statistics / after the normalised copy has been taken (the two residual
-        // biases); the constants come from global memory (every lane half reads the same 32 bytes: L1 hits after the first wave)
-        auto layer_norm = [&](const float* gam, const float* bet, const float* pre, const float* post, auto pre_tag, auto post_tag) __attribute__((always_inline)) {
+        // ---- (x - mean) rstd of the rows in o (register 8 s2 + j of block db = feature 32 db + 16 s2 + 8 lh + j) -> xh / xl as hi + lo fragments: the
+        // LayerNorm's weight and bias ride in the packed weights (pack_mlp3_kernel).  PRE / POST: the residual biases (LDS) added to o before the
+        // statistics / after the normalised copy has been taken
+        auto layer_norm = [&](auto pre_tag, auto post_tag) __attribute__((always_inline)) {
             constexpr bool PRE = decltype(pre_tag)::value, POST = decltype(post_tag)::value;
             uint32_t zz = 0;
             asm volatile("" : "+v"(zz));
             const uint32_t lo8 = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zz)) >> 5) * 8;
+            const float* const pre = reinterpret_cast<const float*>(smem + BP_OFF) + lo8;
+            const float* const post = reinterpret_cast<const float*>(smem + B2_OFF) + lo8;
             if constexpr (PRE) {
 #pragma unroll
                 for (int k = 0; k < NKS; ++k) {
-                    asm volatile("" ::: "memory");      // (one k-step of constants in flight: hoisted, the 144 loads of a LayerNorm would need 576 registers)
-                    __builtin_amdgcn_sched_barrier(0);
-                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(pre + k * 16 + lo8);
-                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(pre + k * 16 + lo8 + 4);
+                    if (k % 4 == 0) __builtin_amdgcn_sched_barrier(0);      // (four k-steps of constants in flight: hoisted, the 48 reads would need 192 registers)
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(pre + k * 16);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(pre + k * 16 + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         o[k >> 1][(k & 1) * 8 + e] += c0[e];
@@ -358,27 +390,22 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
                 }
             qv += __shfl_xor(qv, 32);
             const float rstd = 1.0f / sqrtf(qv * (1.0f / D) + p.eps);
-            float mean_n = mean;
-            asm volatile("" : "+v"(mean_n));
+            float nmr = -mean * rstd;
+            asm volatile("" : "+v"(nmr));
 #pragma unroll
             for (int k = 0; k < NKS; ++k) {
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                const float* gp = gam + k * 16 + lo8;
-                const float* bp = bet + k * 16 + lo8;
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-                const f32x4 e0 = *reinterpret_cast<const f32x4*>(bp), e1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                if (k % 4 == 0) __builtin_amdgcn_sched_barrier(0);
                 f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
                 if constexpr (POST) {
-                    c0 = *reinterpret_cast<const f32x4*>(post + k * 16 + lo8);
-                    c1 = *reinterpret_cast<const f32x4*>(post + k * 16 + lo8 + 4);
+                    c0 = *reinterpret_cast<const f32x4*>(post + k * 16);
+                    c1 = *reinterpret_cast<const f32x4*>(post + k * 16 + 4);
                 }
                 float y[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x0 = o[k >> 1][(k & 1) * 8 + e], x1 = o[k >> 1][(k & 1) * 8 + 4 + e];
-                    y[e] = (x0 - mean_n) * rstd * g0[e] + e0[e];
-                    y[4 + e] = (x1 - mean_n) * rstd * g1[e] + e1[e];
+                    y[e] = fmaf(x0, rstd, nmr);
+                    y[4 + e] = fmaf(x1, rstd, nmr);
                     if constexpr (POST) {
                         o[k >> 1][(k & 1) * 8 + e] = x0 + c0[e];
                         o[k >> 1][(k & 1) * 8 + 4 + e] = x1 + c1[e];
@@ -392,9 +419,10 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
                 xh[k] = __builtin_bit_cast(bf16x8, uh);
                 xl[k] = __builtin_bit_cast(bf16x8, ul);
             }
+            if constexpr (PRE || POST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         // LayerNorm2: sees x + proj(ctx) + b_proj; b2 joins the residual afterwards
-        layer_norm(p.gamma, p.beta, p.bproj, p.b2, std::integral_constant<bool, has_proj>{}, std::true_type{});
+        layer_norm(std::integral_constant<bool, has_proj>{}, std::true_type{});
 
         // ---- the GELU of a tile's 16 accumulator values per lane, one instruction per MFMA gap and element: element n starts at gap
         // 5 n of its carrier step (F1 of the next tile) and runs on into the first gaps of its own fc2 step (gaps 72 ..); the
@@ -565,7 +593,7 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
         if constexpr (QKV) {
             // ---- LayerNorm1 of the next block on the finished rows, then Z(q)^T = Wqkv_q . xn^T + b: 36 steps of the fc1 kind; the block of tile
             // q - 1 is scaled, split and stored in the gaps of step q (behind the step's pieces: stores count in the same vmcnt)
-            layer_norm(p.gamma1, p.beta1, nullptr, nullptr, std::false_type{}, std::false_type{});
+            layer_norm(std::false_type{}, std::false_type{});
             // destination of this lane's row in each of Q, K, V: ((frame * heads) * npad + token) * 64 (+ 8 elements for the upper lane half)
             long qrow;
             {
@@ -705,13 +733,13 @@ template int launch_mlp_fused3_fmt<FMT_FP16>(const MlpFused3Params&, hipStream_t
 extern template int launch_mlp_fused3_fmt<FMT_BF16>(const MlpFused3Params&, hipStream_t);
 
 int launch_mlp_fused3(const MlpFused3Params& p, hipStream_t s) {
-    if (p.M <= 0 || !p.X || !p.gamma || !p.beta || !p.Wp || !p.b1 || !p.b2 || (p.ctx && (!p.bproj || p.ctx_plane <= 0))) {
+    if (p.M <= 0 || !p.X || !p.Wp || !p.b2 || (p.ctx && (!p.bproj || p.ctx_plane <= 0))) {
         dinoseg_set_error("mlp_fused3: null pointer or bad shape (M=%d)", p.M);
         return -1;
     }
-    if (p.q && (!p.ctx || !p.k || !p.v || !p.bqkv || !p.gamma1 || !p.beta1 || p.qkv_plane <= 0 || p.ntok <= 0 || p.npad < p.ntok ||
+    if (p.q && (!p.ctx || !p.k || !p.v || p.qkv_plane <= 0 || p.ntok <= 0 || p.npad < p.ntok ||
                 p.heads * 64 != mf3::D || p.M % p.ntok != 0)) {
-        dinoseg_set_error("mlp_fused3: incomplete qkv tail (needs ctx, bias / norm1 / q / k / v, whole frames of ntok rows)");
+        dinoseg_set_error("mlp_fused3: incomplete qkv tail (needs ctx, q / k / v, whole frames of ntok rows)");
         return -1;
     }
     return p.fmt == FMT_FP16 ? launch_mlp_fused3_fmt<FMT_FP16>(p, s) : launch_mlp_fused3_fmt<FMT_BF16>(p, s);

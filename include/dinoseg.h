@@ -303,23 +303,24 @@ int dinoseg_op_gemm_rs(const void* A, int32_t lda, const void* Wp, const float* 
 /* The same fusion on hi + lo operand planes (the parity modes; mlp_fused3.hip), one launch for
  *     X += ctx . Wproj^T + bproj;   X += fc2(gelu(fc1(LayerNorm(X))))      (vision_transformer.py:104-105, :123, :135 -> :59-65)
  * ctx: the attention output as two planes [2][M][384] (hi, then lo at + ctx_plane elements), or null = the MLP half only (bproj unused).
- * Wp: Wproj, W1, W2 (and optionally the NEXT block's Wqkv [1152, 384], else null) re-packed by dinoseg_op_pack_mlp3
- * (dinoseg_op_mlp3_pack_elems(D, F) 16-bit elements; 0 = unsupported shape).  fmt: 0 = bf16 planes, 1 = fp16 planes.
+ * Wp: dinoseg_op_pack_mlp3's copy (dinoseg_op_mlp3_pack_elems(D, F) 16-bit elements; 0 = unsupported shape): Wproj, W1, W2 -- and optionally the NEXT
+ * block's Wqkv [1152, 384] -- as hi + lo fragment pairs in the order the kernel walks them, with the LayerNorms folded in: norm2's weight into the columns
+ * of W1 and its bias into b1, the next block's norm1 into Wqkv / bqkv (LayerNorm(x) W^T + b = ((x - mean) rstd) (W diag(gamma))^T + (b + W beta)); the kernel
+ * computes (x - mean) rstd only.  fmt: 0 = bf16 planes, 1 = fp16 planes.
  * dinoseg_op_block_tail_fused3: ... and LayerNorm1 + the qkv projection of the NEXT block at the end of the same launch
  * (vision_transformer.py:122 -> :75): afterwards X holds the block's output and q / k / v (each two planes [2][B, heads, npad, 64], lo at
  * + qkv_plane elements; q pre-scaled by qscale; rows >= ntok untouched) hold what LayerNorm + the qkv GEMM would have written from it;
  * v_bf16 (fmt 1 only): V as bf16 planes, what the zero-reference hi + lo attention reads.  M = B * ntok rows.  Library option "qkv_fused3"
  * (default 1) makes dinoseg_forward use it wherever the hi + lo fused launch runs. */
 int64_t dinoseg_op_mlp3_pack_elems(int32_t D, int32_t F);
-int dinoseg_op_pack_mlp3(const float* Wproj, const float* W1, const float* W2, const float* Wqkv_next, int32_t D, int32_t F, int32_t fmt,
-                         void* dst, void* stream);
-int dinoseg_op_proj_mlp_fused3(float* X, const void* ctx, int64_t ctx_plane, const float* bproj, const float* gamma, const float* beta,
-                               float eps, const void* Wp, const float* b1, const float* b2, int32_t M, int32_t D, int32_t F, int32_t fmt,
-                               void* stream);
-int dinoseg_op_block_tail_fused3(float* X, const void* ctx, int64_t ctx_plane, const float* bproj, const float* gamma2, const float* beta2,
-                                 float eps, const void* Wp, const float* b1, const float* b2, const float* bqkv, const float* gamma1,
-                                 const float* beta1, void* q, void* k, void* v, int64_t qkv_plane, int32_t B, int32_t ntok, int32_t npad,
-                                 int32_t heads, float qscale, int32_t v_bf16, int32_t D, int32_t F, int32_t fmt, void* stream);
+int dinoseg_op_pack_mlp3(const float* Wproj, const float* W1, const float* b1, const float* W2, const float* gamma2, const float* beta2,
+                         const float* Wqkv_next, const float* bqkv_next, const float* gamma1_next, const float* beta1_next, int32_t D, int32_t F,
+                         int32_t fmt, void* dst, void* stream);
+int dinoseg_op_proj_mlp_fused3(float* X, const void* ctx, int64_t ctx_plane, const float* bproj, float eps, const void* Wp, const float* b2,
+                               int32_t M, int32_t D, int32_t F, int32_t fmt, void* stream);
+int dinoseg_op_block_tail_fused3(float* X, const void* ctx, int64_t ctx_plane, const float* bproj, float eps, const void* Wp, const float* b2,
+                                 void* q, void* k, void* v, int64_t qkv_plane, int32_t B, int32_t ntok, int32_t npad, int32_t heads, float qscale,
+                                 int32_t v_bf16, int32_t D, int32_t F, int32_t fmt, void* stream);
 
 /* The single-plane fusion with ONE wave per SIMD (mlp_fused4.hip): the same result as dinoseg_op_proj_mlp_fused (fp16 / bf16 operands, the
  * logistic GELU of the benchmark modes), the structure of the hi + lo kernel above -- 128-row items, 32 rows per wave held in registers for

@@ -863,10 +863,11 @@ def _mlp3_case(M_, fp16, seed0, tail=False):
     bq = seeded((3 * D_,), seed0 + 12) * 0.4
     gam1, bet1 = 1 + 0.2 * seeded((D_,), seed0 + 13), 0.1 * seeded((D_,), seed0 + 14)
     n = lib.dinoseg_op_mlp3_pack_elems(D_, F_)
-    assert n == 2 * (D_ * D_ + 2 * D_ * F_ + 3 * D_ * D_)
+    assert n == 2 * (D_ * D_ + 2 * D_ * F_ + 3 * D_ * D_) + 2 * (F_ + 3 * D_)      # (the slots, then the folded biases as fp32)
     Wp = torch.zeros((n,), dtype=torch.int16, device="cuda")
-    capi.check(lib.dinoseg_op_pack_mlp3(Wpr.data_ptr(), W1.data_ptr(), W2.data_ptr(), Wqkv.data_ptr() if tail else None, D_, F_, int(fp16),
-                                        Wp.data_ptr(), S()))
+    capi.check(lib.dinoseg_op_pack_mlp3(Wpr.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), gam.data_ptr(), bet.data_ptr(),
+                                        Wqkv.data_ptr() if tail else None, bq.data_ptr() if tail else None, gam1.data_ptr() if tail else None,
+                                        bet1.data_ptr() if tail else None, D_, F_, int(fp16), Wp.data_ptr(), S()))
     return dict(X=X, ctx=ctx, Wpr=Wpr, bpr=bpr, gam=gam, bet=bet, W1=W1, b1=b1, W2=W2, b2=b2, Wp=Wp, Wqkv=Wqkv, bq=bq, gam1=gam1, bet1=bet1)
 
 
@@ -886,9 +887,8 @@ def test_proj_mlp_fused_hi_lo_planes(cuda, M_, proj, fp16):
     q2 = lambda t: _split_planes(t, fp16)[1]
     ctx_pl, ctx_q = _split_planes(c["ctx"], fp16)
     got = c["X"].clone()
-    capi.check(lib.dinoseg_op_proj_mlp_fused3(got.data_ptr(), ctx_pl.data_ptr() if proj else None, M_ * D_, c["bpr"].data_ptr(),
-                                              c["gam"].data_ptr(), c["bet"].data_ptr(), 1e-6, c["Wp"].data_ptr(), c["b1"].data_ptr(),
-                                              c["b2"].data_ptr(), M_, D_, F_, int(fp16), S()))
+    capi.check(lib.dinoseg_op_proj_mlp_fused3(got.data_ptr(), ctx_pl.data_ptr() if proj else None, M_ * D_, c["bpr"].data_ptr(), 1e-6,
+                                              c["Wp"].data_ptr(), c["b2"].data_ptr(), M_, D_, F_, int(fp16), S()))
     torch.cuda.synchronize()
 
     def model(quant):
@@ -935,18 +935,16 @@ def test_block_tail_fused_hi_lo_planes(cuda, B, ntok, fp16, v_bf16):
     q2 = lambda t: _split_planes(t, fp16)[1]
     ctx_pl, _ = _split_planes(c["ctx"], fp16)
     ref = c["X"].clone()
-    capi.check(lib.dinoseg_op_proj_mlp_fused3(ref.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), c["gam"].data_ptr(),
-                                              c["bet"].data_ptr(), 1e-6, c["Wp"].data_ptr(), c["b1"].data_ptr(), c["b2"].data_ptr(), M_, D_, F_,
-                                              int(fp16), S()))
+    capi.check(lib.dinoseg_op_proj_mlp_fused3(ref.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), 1e-6, c["Wp"].data_ptr(),
+                                              c["b2"].data_ptr(), M_, D_, F_, int(fp16), S()))
     got = c["X"].clone()
     plane = B * H * npad * 64
     q = torch.zeros((2, B, H, npad, 64), dtype=torch.int16, device="cuda")
     k, v = torch.zeros_like(q), torch.zeros_like(q)
     qscale = 0.125 * LOG2E
-    capi.check(lib.dinoseg_op_block_tail_fused3(got.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), c["gam"].data_ptr(),
-                                                c["bet"].data_ptr(), 1e-6, c["Wp"].data_ptr(), c["b1"].data_ptr(), c["b2"].data_ptr(),
-                                                c["bq"].data_ptr(), c["gam1"].data_ptr(), c["bet1"].data_ptr(), q.data_ptr(), k.data_ptr(),
-                                                v.data_ptr(), plane, B, ntok, npad, H, qscale, v_bf16, D_, F_, int(fp16), S()))
+    capi.check(lib.dinoseg_op_block_tail_fused3(got.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), 1e-6, c["Wp"].data_ptr(),
+                                                c["b2"].data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), plane, B, ntok, npad, H, qscale,
+                                                v_bf16, D_, F_, int(fp16), S()))
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
     A = q2(_ln_ref(got, c["gam1"], c["bet1"]).cuda()).double()

@@ -27,13 +27,13 @@ ctx = torch.stack([hi, (c - hi.float()).to(dt)]).contiguous().view(torch.int16)
 lib = capi.lib()
 S = capi.stream_ptr
 Wp = torch.zeros((lib.dinoseg_op_mlp3_pack_elems(D, F),), dtype=torch.int16, device="cuda")
-capi.check(lib.dinoseg_op_pack_mlp3(Wpr.data_ptr(), W1.data_ptr(), W2.data_ptr(), None, D, F, fp16, Wp.data_ptr(), S()))
+capi.check(lib.dinoseg_op_pack_mlp3(Wpr.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), gam.data_ptr(), bet.data_ptr(), None, None, None, None,
+                                    D, F, fp16, Wp.data_ptr(), S()))
 
 
 def run():
-    capi.check(lib.dinoseg_op_proj_mlp_fused3(X.data_ptr(), ctx.data_ptr() if proj else None, M * D, bpr.data_ptr(), gam.data_ptr(),
-                                              bet.data_ptr(), 1e-6, Wp.data_ptr(), b1.data_ptr(), b2.data_ptr(), M, D, F, fp16,
-                                              S()))
+    capi.check(lib.dinoseg_op_proj_mlp_fused3(X.data_ptr(), ctx.data_ptr() if proj else None, M * D, bpr.data_ptr(), 1e-6, Wp.data_ptr(), b2.data_ptr(),
+                                              M, D, F, fp16, S()))
 
 
 for rep in range(3):

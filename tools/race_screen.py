@@ -139,18 +139,15 @@ for (Bq, ntok, fp16) in [(32, 3601, True), (11, 3601, False), (3, 130, True), (1
 
     def run3():
         x3.copy_(c["X"])
-        capi.check(lib.dinoseg_op_proj_mlp_fused3(x3.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), c["gam"].data_ptr(),
-                                                  c["bet"].data_ptr(), 1e-6, c["Wp"].data_ptr(), c["b1"].data_ptr(), c["b2"].data_ptr(), M_, D_, F_,
-                                                  int(fp16), S()))
+        capi.check(lib.dinoseg_op_proj_mlp_fused3(x3.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), 1e-6, c["Wp"].data_ptr(),
+                                                  c["b2"].data_ptr(), M_, D_, F_, int(fp16), S()))
     screen(f"mlp_fused3 B={Bq} N={ntok} fp16={fp16}", run3, lambda: [x3])
 
     def run3t():
         x3.copy_(c["X"])
-        capi.check(lib.dinoseg_op_block_tail_fused3(x3.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), c["gam"].data_ptr(),
-                                                    c["bet"].data_ptr(), 1e-6, c["Wp"].data_ptr(), c["b1"].data_ptr(), c["b2"].data_ptr(),
-                                                    c["bq"].data_ptr(), c["gam1"].data_ptr(), c["bet1"].data_ptr(), q3.data_ptr(), k3.data_ptr(),
-                                                    v3.data_ptr(), Bq * H_ * npad * 64, Bq, ntok, npad, H_, 0.125 * LOG2E, int(fp16), D_, F_,
-                                                    int(fp16), S()))
+        capi.check(lib.dinoseg_op_block_tail_fused3(x3.data_ptr(), ctx_pl.data_ptr(), M_ * D_, c["bpr"].data_ptr(), 1e-6, c["Wp"].data_ptr(),
+                                                    c["b2"].data_ptr(), q3.data_ptr(), k3.data_ptr(), v3.data_ptr(), Bq * H_ * npad * 64, Bq, ntok,
+                                                    npad, H_, 0.125 * LOG2E, int(fp16), D_, F_, int(fp16), S()))
     screen(f"mlp_fused3 + qkv tail B={Bq} N={ntok} fp16={fp16}", run3t, lambda: [x3, q3, k3, v3])
     ctx1, _ = T._one_plane(c["ctx"], fp16)
     Wp4 = T._pack_mlp4(c["Wpr"], c["W1"], c["W2"], fp16)
