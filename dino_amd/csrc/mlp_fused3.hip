@@ -264,12 +264,28 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
         // mma(pair tag J, product 0 / 1 / 2, fragment): the product; valu(gap tag G): vector work of MFMA gap G (0 .. 71)
         // VM: vector-memory operations known to have been issued AFTER the pieces this step reads (normally the previous step's twelve pieces;
         // in the first two steps of an item also at least 48 of the row loads the previous item's last steps issued behind their pieces)
-        auto step = [&](auto order_tag, auto vm_tag, auto&& mma, auto&& valu) __attribute__((always_inline)) {
+        // pre(): runs between the step's scalar work and its first product -- behind the first fragment reads, under their latency
+        auto step = [&](auto order_tag, auto vm_tag, auto&& pre, auto&& mma, auto&& valu) __attribute__((always_inline)) {
             constexpr int ORDER = decltype(order_tag)::value;      // 0: pair J reads fragment pair J; 1: s2-major (J -> 2 (J % 12) + J / 12)
             constexpr int VM = decltype(vm_tag)::value;
             // what this step reads has landed: every wave's pieces of two steps ago
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
             __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t a = frag_rd_i + (uint32_t)rpos * SLOT;
+            rpos = rpos + 1 == RING ? 0 : rpos + 1;
+            bf16x8 fh[NF], fl[NF];
+            auto issue_read = [&](auto j_tag) __attribute__((always_inline)) {
+                constexpr int J = decltype(j_tag)::value;
+                constexpr int IDX = ORDER == 0 ? J : 2 * (J % 12) + J / 12;
+                if (MF3_ABL & 16) return;
+                mf_rd<IDX * 2048 + LO>(fl[J % NF], a);
+                mf_rd<IDX * 2048 + HI>(fh[J % NF], a);
+            };
+            // the first fragment reads go out before the step's scalar work (the LDS-DMA descriptors of the slot two steps ahead): their latency is
+            // the longest thing between the barrier and the first product
+            mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
+            __builtin_amdgcn_sched_barrier(0);
             uint64_t gsb[3];
             uint32_t gld[3];
             {
@@ -282,16 +298,7 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
                 }
                 next_slot();
             }
-            const uint32_t a = frag_rd_i + (uint32_t)rpos * SLOT;
-            rpos = rpos + 1 == RING ? 0 : rpos + 1;
-            bf16x8 fh[NF], fl[NF];
-            auto issue_read = [&](auto j_tag) __attribute__((always_inline)) {
-                constexpr int J = decltype(j_tag)::value;
-                constexpr int IDX = ORDER == 0 ? J : 2 * (J % 12) + J / 12;
-                if (MF3_ABL & 16) return;
-                mf_rd<IDX * 2048 + LO>(fl[J % NF], a);
-                mf_rd<IDX * 2048 + HI>(fh[J % NF], a);
-            };
+            pre();
             auto gap = [&](auto g_tag) __attribute__((always_inline)) {
                 constexpr int G = decltype(g_tag)::value;
                 __builtin_amdgcn_sched_barrier(0);
@@ -302,7 +309,6 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
                 valu(g_tag);
                 __builtin_amdgcn_sched_barrier(0);
             };
-            mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
             mf_for(std::make_integer_sequence<int, NKS>{}, [&](auto j_tag) __attribute__((always_inline)) {
                 constexpr int J = decltype(j_tag)::value;
                 if constexpr (J + RA < NKS) issue_read(std::integral_constant<int, J + RA>{});
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
             const bf16_t* const cr = p.ctx + lane_row(item);
             mf_for(std::make_integer_sequence<int, NPT>{}, [&](auto kt_tag) __attribute__((always_inline)) {
                 constexpr int KT = decltype(kt_tag)::value;
-                step(std::integral_constant<int, 0>{}, std::integral_constant<int, (KT == 0 || (KT == 1 && !QKV) ? 60 : 12)>{},
+                step(std::integral_constant<int, 0>{}, std::integral_constant<int, (KT == 0 || (KT == 1 && !QKV) ? 60 : 12)>{}, []() {},
                      [&](auto j_tag, auto w_tag, const bf16x8& fr) __attribute__((always_inline)) {
                          constexpr int J = decltype(j_tag)::value, W = decltype(w_tag)::value, DB = J >> 1, R = 2 * (KT % 3) + (J & 1);
                          if (!(MF3_ABL & 8)) o[DB] = mfma32f<FMT>(fr, W == 1 ? xl[R] : xh[R], o[DB]);
@@ -475,24 +481,27 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
             });
         };
         // S = b1 of hidden tile t (register j of lane half h = unit (j & 7) + 8 h + 16 (j >> 3): the sigma23 row order)
-        auto s_bias = [&](f32x16& s, const float* table, int t) __attribute__((always_inline)) {
+        // (the four reads go out in front of the step's barrier, the accumulator is written behind the step's first fragment reads: s_bias_set as its pre())
+        f32x4 bc0, bc1, bc2, bc3;
+        auto s_bias_load = [&](const float* table, int t) __attribute__((always_inline)) {
             const float* bp = table + t * HT + lh_i * 8;
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(bp), c1 = *reinterpret_cast<const f32x4*>(bp + 4);
-            const f32x4 c2 = *reinterpret_cast<const f32x4*>(bp + 16), c3 = *reinterpret_cast<const f32x4*>(bp + 20);
+            bc0 = *reinterpret_cast<const f32x4*>(bp); bc1 = *reinterpret_cast<const f32x4*>(bp + 4);
+            bc2 = *reinterpret_cast<const f32x4*>(bp + 16); bc3 = *reinterpret_cast<const f32x4*>(bp + 20);
+        };
+        auto s_bias_set = [&](f32x16& s) __attribute__((always_inline)) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                s[e] = c0[e];
-                s[4 + e] = c1[e];
-                s[8 + e] = c2[e];
-                s[12 + e] = c3[e];
+                s[e] = bc0[e];
+                s[4 + e] = bc1[e];
+                s[8 + e] = bc2[e];
+                s[12 + e] = bc3[e];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         // F1(t): s_nxt = b1(t) + W1(t) . xn^T, with the first 72 gaps of the GELU of s_cur (GELU = false: none)
         auto step_f1 = [&](f32x16& s_nxt, const f32x16& s_cur, int t, auto gelu_tag, auto vm_tag) __attribute__((always_inline)) {
             constexpr bool GELU = decltype(gelu_tag)::value;
-            s_bias(s_nxt, sB1, t);
-            step(std::integral_constant<int, 0>{}, vm_tag,
+            s_bias_load(sB1, t);
+            step(std::integral_constant<int, 0>{}, vm_tag, [&]() __attribute__((always_inline)) { s_bias_set(s_nxt); },
                  [&](auto j_tag, auto w_tag, const bf16x8& fr) __attribute__((always_inline)) {
                      constexpr int J = decltype(j_tag)::value, W = decltype(w_tag)::value;
                      if (!(MF3_ABL & 4)) s_nxt = mfma32f<FMT>(fr, W == 1 ? xl[J] : xh[J], s_nxt);
@@ -544,7 +553,7 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
                 nxr = p.X + nro;
                 if constexpr (has_proj) ncr = p.ctx + nro;
             }
-            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 12>{},
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 12>{}, []() {},
                  [&](auto j_tag, auto w_tag, const bf16x8& fr) __attribute__((always_inline)) {
                      constexpr int J = decltype(j_tag)::value, W = decltype(w_tag)::value, DB = J % 12, S2 = J / 12;
                      const uint4 uh = {pdh[4 * S2], pdh[4 * S2 + 1], pdh[4 * S2 + 2], pdh[4 * S2 + 3]};
@@ -643,13 +652,13 @@ __global__ __launch_bounds__(mf3::THREADS, 1) void mlp_fused3_kernel(MlpFused3Pa
             auto step_q = [&](f32x16& z_nxt, const f32x16& z_cur, int q, auto epi_tag, auto vconv_tag, auto tq_tag) __attribute__((always_inline)) {
                 constexpr bool EPI = decltype(epi_tag)::value;
                 constexpr int TQ = decltype(tq_tag)::value;
-                s_bias(z_nxt, sBq, q);
+                s_bias_load(sBq, q);
                 if constexpr (TQ != 0) {
                     const long nro = lane_row(item + (int)gridDim.x);
                     nxr = p.X + nro;
                     ncr = p.ctx + nro;
                 }
-                step(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{},
+                step(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{}, [&]() __attribute__((always_inline)) { s_bias_set(z_nxt); },
                      [&](auto j_tag, auto w_tag, const bf16x8& fr) __attribute__((always_inline)) {
                          constexpr int J = decltype(j_tag)::value, W = decltype(w_tag)::value;
                          if (!(MF3_ABL & 4)) z_nxt = mfma32f<FMT>(fr, W == 1 ? xl[J] : xh[J], z_nxt);
