@@ -237,26 +237,29 @@ __global__ __launch_bounds__(rs::THREADS, 1) void gemm_bstat_kernel(GemmParams p
                 else asm volatile("" ::"v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w), "v"(dst));
             }
         };
-        auto z_bias = [&](f32x16& z, int n) __attribute__((always_inline)) {
+        // (the four reads go out in front of the step's barrier, the accumulator is written behind the step's first fragment reads)
+        f32x4 zc0, zc1, zc2, zc3;
+        auto z_bias_load = [&](int n) __attribute__((always_inline)) {
             const float* bp = sBias + n * 32 + lh_i * 8;
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(bp), c1 = *reinterpret_cast<const f32x4*>(bp + 4);
-            const f32x4 c2 = *reinterpret_cast<const f32x4*>(bp + 16), c3 = *reinterpret_cast<const f32x4*>(bp + 20);
+            zc0 = *reinterpret_cast<const f32x4*>(bp); zc1 = *reinterpret_cast<const f32x4*>(bp + 4);
+            zc2 = *reinterpret_cast<const f32x4*>(bp + 16); zc3 = *reinterpret_cast<const f32x4*>(bp + 20);
+        };
+        auto z_bias_set = [&](f32x16& z) __attribute__((always_inline)) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                z[e] = c0[e];
-                z[4 + e] = c1[e];
-                z[8 + e] = c2[e];
-                z[12 + e] = c3[e];
+                z[e] = zc0[e];
+                z[4 + e] = zc1[e];
+                z[8 + e] = zc2[e];
+                z[12 + e] = zc3[e];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         // step n: z_nxt = bias(n) + W_n . xn^T; the epilogue of tile n - 1 (z_cur) in the gaps
         auto step = [&](f32x16& z_nxt, const f32x16& z_cur, int n, auto epi_tag) __attribute__((always_inline)) {
             constexpr bool EPI_ON = decltype(epi_tag)::value;
-            z_bias(z_nxt, n);
+            z_bias_load(n);
             // (vmcnt 12: the previous step's pieces may stay in flight; its two stores, younger still, then count among the twelve -- a conservative wait)
             rs_step<KS, KS / NW>(
-                st, frag_rd_i, lane16_i, []() __attribute__((always_inline)) {},
+                st, frag_rd_i, lane16_i, [&]() __attribute__((always_inline)) { z_bias_set(z_nxt); },
                 [&](auto j_tag, const bf16x8& fr) __attribute__((always_inline)) {
                     constexpr int J = decltype(j_tag)::value;
                     if (!(RS_ABL & 4)) z_nxt = mfma32f<FMT>(fr, xn[J], z_nxt);

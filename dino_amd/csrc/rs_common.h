@@ -29,7 +29,19 @@ __device__ __forceinline__ void rs_step(Stream& st, uint32_t frag_rd, uint32_t l
     constexpr int SLOTB = NG * 1024, PW = NG / NW;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");      // this slot's pieces (issued two steps ago) have landed ...
     __builtin_amdgcn_s_barrier();                                   // ... every wave's; and every wave has left the slot refilled below
-    pre();                                                          // (what needs the wait above: operands loaded by uncounted instructions)
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t a = frag_rd + (uint32_t)st.rpos * SLOTB;
+    st.rpos = st.rpos + 1 == RING ? 0 : st.rpos + 1;
+    bf16x8 fr[NFR];
+    auto issue_read = [&](auto j_tag) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_tag)::value;
+        if (RS_ABL & 16) return;
+        mf_rd<J * 1024>(fr[J % NFR], a);
+    };
+    // the first fragment reads go out before the step's scalar work (the LDS-DMA descriptors of the slot two steps ahead) and before pre():
+    // their latency is the longest thing between the barrier and the first product
+    mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
+    __builtin_amdgcn_sched_barrier(0);
     constexpr int NGRP = (PW + 3) / 4;
     uint64_t gsb[NGRP];
     uint32_t gld[NGRP];
@@ -46,15 +58,7 @@ __device__ __forceinline__ void rs_step(Stream& st, uint32_t frag_rd, uint32_t l
         st.sn = st.sn + 1 == st.nslots ? 0 : st.sn + 1;
         st.ipos = st.ipos + 1 == RING ? 0 : st.ipos + 1;
     }
-    const uint32_t a = frag_rd + (uint32_t)st.rpos * SLOTB;
-    st.rpos = st.rpos + 1 == RING ? 0 : st.rpos + 1;
-    bf16x8 fr[NFR];
-    auto issue_read = [&](auto j_tag) __attribute__((always_inline)) {
-        constexpr int J = decltype(j_tag)::value;
-        if (RS_ABL & 16) return;
-        mf_rd<J * 1024>(fr[J % NFR], a);
-    };
-    mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
+    pre();                                                          // (the step's own set-up, e.g. the accumulator's bias: under the reads' latency)
     mf_for(std::make_integer_sequence<int, NG>{}, [&](auto j_tag) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value;
         if constexpr (J + RA < NG) issue_read(std::integral_constant<int, J + RA>{});
