@@ -530,8 +530,9 @@ static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s) {
     for (auto& kv : h->packed_proj) DSEG_TRY(launch_pack_proj(W(h, kv.first + "attn.proj.weight"), Dm, kv.second, s, h->fmt));
     for (auto& kv : h->packed_qkvf) DSEG_TRY(launch_pack_qkv(W(h, kv.first + "attn.qkv.weight"), Dm, kv.second, s, h->fmt));
     for (auto& kv : h->packed_mlp4)
-        DSEG_TRY(launch_pack_mlp4(W(h, kv.first + "attn.proj.weight"), W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc2.weight"), Dm, Fh,
-                                  kv.second, s, h->fmt));
+        DSEG_TRY(launch_pack_mlp4(W(h, kv.first + "attn.proj.weight"), W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc1.bias"),
+                                  W(h, kv.first + "mlp.fc2.weight"), W(h, kv.first + "norm2.weight"), W(h, kv.first + "norm2.bias"), Dm, Fh, kv.second, s,
+                                  h->fmt));
     for (int i = 0; i < h->cfg.n_blocks; ++i) {      // (block i's stream ends with the qkv weight of block i + 1: the tail of its fused launch)
         const std::string b = "dino.blocks." + std::to_string(i) + ".", nb = "dino.blocks." + std::to_string(i + 1) + ".";
         if (!h->packed_mlp3.count(b)) continue;
@@ -763,8 +764,8 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             DSEG_TRY(ensure_mlp_packs(h, s));
             // the same launch with one wave per SIMD (mlp_fused4.hip)
             MlpFused3Params g = {};
-            g.X = X; g.gamma = W(h, b + "norm2.weight"); g.beta = W(h, b + "norm2.bias"); g.eps = c.ln_eps;
-            g.Wp = h->packed_mlp4.at(b); g.b1 = W(h, b + "mlp.fc1.bias"); g.b2 = W(h, b + "mlp.fc2.bias");
+            g.X = X; g.eps = c.ln_eps;
+            g.Wp = h->packed_mlp4.at(b); g.b2 = W(h, b + "mlp.fc2.bias");
             g.M = L.M; g.fmt = FM;
             g.ctx = CTX; g.bproj = W(h, b + "attn.proj.bias");
             DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_mlp_fused4(g, s)));
@@ -1284,25 +1285,24 @@ extern "C" int dinoseg_op_block_tail_fused3(float* X, const void* ctx, int64_t c
 
 extern "C" int64_t dinoseg_op_mlp4_pack_elems(int32_t D, int32_t F) { return mlp_fused4_pack_elems(D, F); }
 
-extern "C" int dinoseg_op_pack_mlp4(const float* Wproj, const float* W1, const float* W2, int32_t D, int32_t F, int32_t fmt, void* dst,
-                                    void* stream) {
+extern "C" int dinoseg_op_pack_mlp4(const float* Wproj, const float* W1, const float* b1, const float* W2, const float* gamma2, const float* beta2,
+                                    int32_t D, int32_t F, int32_t fmt, void* dst, void* stream) {
     if (fmt != FMT_BF16 && fmt != FMT_FP16) {
         dinoseg_set_error("dinoseg_op_pack_mlp4: bad operand format %d", fmt);
         return -1;
     }
-    return launch_pack_mlp4(Wproj, W1, W2, D, F, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), fmt);
+    return launch_pack_mlp4(Wproj, W1, b1, W2, gamma2, beta2, D, F, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), fmt);
 }
 
-extern "C" int dinoseg_op_proj_mlp_fused4(float* X, const void* ctx, const float* bproj, const float* gamma, const float* beta, float eps,
-                                          const void* Wp, const float* b1, const float* b2, int32_t M, int32_t D, int32_t F, int32_t fmt,
-                                          void* stream) {
+extern "C" int dinoseg_op_proj_mlp_fused4(float* X, const void* ctx, const float* bproj, float eps, const void* Wp, const float* b2, int32_t M,
+                                          int32_t D, int32_t F, int32_t fmt, void* stream) {
     if (!mlp_fused4_supported(D, F, 1) || (fmt != FMT_BF16 && fmt != FMT_FP16)) {
         dinoseg_set_error("dinoseg_op_proj_mlp_fused4: unsupported shape D=%d F=%d or format %d", D, F, fmt);
         return -1;
     }
     MlpFused3Params g = {};
-    g.X = X; g.gamma = gamma; g.beta = beta; g.eps = eps;
-    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b1 = b1; g.b2 = b2; g.M = M;
+    g.X = X; g.eps = eps;
+    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b2 = b2; g.M = M;
     g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.bproj = bproj; g.fmt = fmt;
     return launch_mlp_fused4(g, reinterpret_cast<hipStream_t>(stream));
 }

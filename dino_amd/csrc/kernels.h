@@ -132,8 +132,6 @@ struct MlpFused3Params {
     bf16_t* q; bf16_t* k; bf16_t* v; long qkv_plane;      // each [2][B, heads, npad, 64] (lo plane at + qkv_plane elements; rows >= ntok never written)
     int ntok, npad, heads; float qscale;
     int v_bf16;                                 // fmt == FMT_FP16: V as bf16 hi + lo planes (GemmParams::v_bf16)
-    // mlp_fused4.hip only (one plane; its LayerNorm2 is not folded):
-    const float* gamma; const float* beta; const float* b1;
 };
 // what launch_pack_mlp3 reads: the fp32 parameters of a block's second half (and of the next block's first linear)
 struct MlpFused3Weights {
@@ -146,10 +144,12 @@ long mlp_fused3_pack_elems(int D, int F);       // 16-bit elements of the packed
 int launch_pack_mlp3(const MlpFused3Weights& w, int D, int F, bf16_t* dst, hipStream_t s, int fmt);
 int launch_mlp_fused3(const MlpFused3Params& p, hipStream_t s);
 // The same launch on ONE operand plane, one wave per SIMD (mlp_fused4.hip; MlpFused3Params without the plane strides and without a qkv tail):
-// Wp = launch_pack_mlp4's 54 slots of 48 fragments (Wproj may be null for an MLP-only copy: its six slots are zero and never read)
+// Wp = launch_pack_mlp4's 54 slots of 48 fragments (Wproj may be null for an MLP-only copy: its six slots are zero and never read), W1's columns
+// scaled by norm2's weight, then the folded bias b1 + W1 beta2
 bool mlp_fused4_supported(int D, int F, int planes);
-long mlp_fused4_pack_elems(int D, int F);       // 16-bit elements of the packed copy (0: unsupported shape)
-int launch_pack_mlp4(const float* Wproj /* nullable */, const float* W1, const float* W2, int D, int F, bf16_t* dst, hipStream_t s, int fmt);
+long mlp_fused4_pack_elems(int D, int F);       // 16-bit elements of the packed copy, folded bias included (0: unsupported shape)
+int launch_pack_mlp4(const float* Wproj /* nullable */, const float* W1, const float* b1, const float* W2, const float* gamma2, const float* beta2, int D,
+                     int F, bf16_t* dst, hipStream_t s, int fmt);
 int launch_mlp_fused4(const MlpFused3Params& p, hipStream_t s);
 
 // tuning knobs (dinoseg_set_option): see api.hip

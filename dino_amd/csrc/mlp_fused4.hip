@@ -39,10 +39,13 @@ constexpr int NPS = D / 64;                         // projection steps (two k-t
 constexpr int NU = NT / 2;                          // fc1 / fc2 steps (two hidden tiles each)
 constexpr int NSLOT = NPS + 2 * NU;                 // slots per item (54)
 constexpr int RING = 3;
-constexpr int B1_OFF = RING * SLOT;                 // b1 [F] fp32
-constexpr int G_OFF = B1_OFF + F * 4;               // norm2 weight, norm2 bias, b_proj, b2: [D] fp32 each
-constexpr int BE_OFF = G_OFF + D * 4, BP_OFF = BE_OFF + D * 4, B2_OFF = BP_OFF + D * 4;
+constexpr int B1_OFF = RING * SLOT;                 // b1' [F] fp32 (b1 + W1 beta2: LayerNorm2 is folded into the packed copy)
+constexpr int BP_OFF = B1_OFF + F * 4;              // the two residual biases: b_proj, b2 [D] fp32 each
+constexpr int B2_OFF = BP_OFF + D * 4;
 constexpr int LDS_BYTES = B2_OFF + D * 4;
+// the packed copy of a block: NSLOT slots, then the folded bias b1' [F] (fp32)
+constexpr long BIAS_OFF_BYTES = (long)NSLOT * SLOT;
+[[maybe_unused]] constexpr long PACK_BYTES = BIAS_OFF_BYTES + F * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr int PIECES = SLOT / 1024 / NW;            // LDS-DMA pieces per wave and step
 static_assert(PIECES == 12, "three groups of four pieces");
@@ -70,8 +73,10 @@ __host__ __device__ inline void mf4_slot_kind(int n, int& kind, int& u) {      /
 }
 
 // Wproj [384][384], W1 [1536][384], W2 [384][1536] fp32 -> [slot][48 fragments][64 lanes][8] in the operand format, in consumption order
+// LayerNorm2's weight g2 is folded into the columns of W1 (its bias into b1: fold_bias4_kernel): LayerNorm(x) W^T + b = ((x - mean) rstd) (W diag(g))^T +
+// (b + W beta) -- the kernel's LayerNorm needs no per-feature constants
 __global__ __launch_bounds__(256) void pack_mlp4_kernel(const float* __restrict__ Wpr, const float* __restrict__ W1, const float* __restrict__ W2,
-                                                        bf16_t* __restrict__ dst, int fmt) {
+                                                        const float* __restrict__ g2, bf16_t* __restrict__ dst, int fmt) {
     using namespace mf4;
     const long total = (long)NSLOT * NFRAG * 512;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -89,7 +94,8 @@ __global__ __launch_bounds__(256) void pack_mlp4_kernel(const float* __restrict_
                                      // half): the two tiles' products alternate.  k runs in the order LayerNorm2 leaves the row in a lane's registers:
                                      // element e of lane half h = feature 16 ks + 8 (e >> 2) + 4 h + (e & 3)
             const int i = attn::sigma23(lane & 31);
-            v = W1[(long)((2 * u + (frag & 1)) * HT + i) * D + (frag >> 1) * 16 + 8 * (e >> 2) + 4 * h + (e & 3)];
+            const int f = (frag >> 1) * 16 + 8 * (e >> 2) + 4 * h + (e & 3);
+            v = W1[(long)((2 * u + (frag & 1)) * HT + i) * D + f] * g2[f];
         } else if (kind == 0) {      // proj: A row = output feature (natural order: register 4 g + e of lane half h = feature 32 db + 8 g + 4 h + e, the
                                      // two lanes of a row hold adjacent 16-byte pieces), k = the k-tile's 32 inputs, fragment = (k-tile half, db, s2)
             const int db = r >> 1, s2 = r & 1, i = lane & 31;
@@ -102,15 +108,30 @@ __global__ __launch_bounds__(256) void pack_mlp4_kernel(const float* __restrict_
     }
 }
 
-long mlp_fused4_pack_elems(int Dm, int Fh) { return Dm == mf4::D && Fh == mf4::F ? (long)mf4::NSLOT * mf4::SLOT / 2 : 0; }
+long mlp_fused4_pack_elems(int Dm, int Fh) { return Dm == mf4::D && Fh == mf4::F ? mf4::PACK_BYTES / 2 : 0; }
 bool mlp_fused4_supported(int Dm, int Fh, int planes) { return Dm == mf4::D && Fh == mf4::F && planes == 1; }
 
-int launch_pack_mlp4(const float* Wproj, const float* W1, const float* W2, int Dm, int Fh, bf16_t* dst, hipStream_t s, int fmt) {
-    if (mlp_fused4_pack_elems(Dm, Fh) <= 0 || !W1 || !W2 || !dst) {
+// out[n] = bias[n] + sum_k W[n][k] beta[k]  (fp32; one wave per output feature)
+__global__ __launch_bounds__(256) void fold_bias4_kernel(const float* __restrict__ W, const float* __restrict__ beta, const float* __restrict__ bias,
+                                                         int N, int K, float* __restrict__ out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc = fmaf(W[(long)n * K + k], beta[k], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[n] = bias[n] + acc;
+}
+
+int launch_pack_mlp4(const float* Wproj, const float* W1, const float* b1, const float* W2, const float* gamma2, const float* beta2, int Dm, int Fh,
+                     bf16_t* dst, hipStream_t s, int fmt) {
+    if (mlp_fused4_pack_elems(Dm, Fh) <= 0 || !W1 || !b1 || !W2 || !gamma2 || !beta2 || !dst) {
         dinoseg_set_error("pack_mlp4: null pointer or unsupported shape D=%d F=%d", Dm, Fh);
         return -1;
     }
-    hipLaunchKernelGGL(pack_mlp4_kernel, dim3(2048), dim3(256), 0, s, Wproj, W1, W2, dst, fmt);
+    hipLaunchKernelGGL(pack_mlp4_kernel, dim3(2048), dim3(256), 0, s, Wproj, W1, W2, gamma2, dst, fmt);
+    hipLaunchKernelGGL(fold_bias4_kernel, dim3((Fh + 3) / 4), dim3(256), 0, s, W1, beta2, b1, Fh, Dm,
+                       reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + mf4::BIAS_OFF_BYTES));
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -125,13 +146,14 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
     const int nitems = (M + BM - 1) / BM;
     if ((int)blockIdx.x >= nitems) return;
 
-    // ---- constants into LDS: b1, norm2, the two residual biases
-    for (int i = tid; i < F / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + B1_OFF)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
-    for (int i = tid; i < D / 4; i += THREADS) {
-        reinterpret_cast<f32x4*>(smem + G_OFF)[i] = reinterpret_cast<const f32x4*>(p.gamma)[i];
-        reinterpret_cast<f32x4*>(smem + BE_OFF)[i] = reinterpret_cast<const f32x4*>(p.beta)[i];
-        if constexpr (PROJ) reinterpret_cast<f32x4*>(smem + BP_OFF)[i] = reinterpret_cast<const f32x4*>(p.bproj)[i];
-        reinterpret_cast<f32x4*>(smem + B2_OFF)[i] = reinterpret_cast<const f32x4*>(p.b2)[i];
+    // ---- constants into LDS: the folded fc1 bias (behind the slots of the packed copy), the two residual biases
+    {
+        const float* fb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.Wp) + BIAS_OFF_BYTES);
+        for (int i = tid; i < F / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + B1_OFF)[i] = reinterpret_cast<const f32x4*>(fb)[i];
+        for (int i = tid; i < D / 4; i += THREADS) {
+            if constexpr (PROJ) reinterpret_cast<f32x4*>(smem + BP_OFF)[i] = reinterpret_cast<const f32x4*>(p.bproj)[i];
+            reinterpret_cast<f32x4*>(smem + B2_OFF)[i] = reinterpret_cast<const f32x4*>(p.b2)[i];
+        }
     }
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
     const float* const sB1 = reinterpret_cast<const float*>(smem + B1_OFF);
@@ -211,13 +233,6 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
                 mf_for(std::make_integer_sequence<int, NKS>{}, [&](auto k_tag) __attribute__((always_inline)) { load_ctx(p.ctx + lane_row(item), k_tag); });
         } else {
             mf_for(std::make_integer_sequence<int, 2 * NKS>{}, [&](auto j_tag) __attribute__((always_inline)) { load_xs(xr_item, j_tag); });
-#pragma unroll
-            for (int k = 0; k < NKS; ++k)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[k >> 1][(k & 1) * 8 + e] = xs[2 * k][e];
-                    o[k >> 1][(k & 1) * 8 + 4 + e] = xs[2 * k + 1][e];
-                }
         }
 
         // ---- one step: 48 MFMAs on the slot at ring position rpos; the pieces of the slot two steps ahead go into the position before it
@@ -305,66 +320,54 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
             });
         }
 
-        // ---- LayerNorm2 of the rows in o (register 4 g + e of block db = feature 32 db + 8 g + 4 lh + e) -> xn as B-operand fragments (fragment
-        // k = registers 8 (k & 1) .. + 7 of block k >> 1: fc1's weights are packed in that k order).
-        // x + b_proj is added to o before the statistics, b2 after the normalised copy has been taken (the two residual biases)
+        // ---- (v - mean) rstd of the rows v = o + x + b_proj (register 4 g + e of block db = feature 32 db + 8 g + 4 lh + e) -> xn as B-operand fragments
+        // (fragment k = registers 8 (k & 1) .. + 7 of block k >> 1: fc1's weights are packed in that k order, with LayerNorm2's weight in their columns
+        // and its bias in b1').  v is built once in the x row's registers (one read of the accumulators), the statistics and the normalised copy come from
+        // there, and the accumulators are written once: v + b2
         {
             uint32_t zz = 0;
             asm volatile("" : "+v"(zz));
             const uint32_t lo8 = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zz)) >> 5) * 4;      // (this lane's pieces: + 0 and + 8)
-            const float* const sG = reinterpret_cast<const float*>(smem + G_OFF) + lo8;
-            const float* const sBe = reinterpret_cast<const float*>(smem + BE_OFF) + lo8;
             const float* const sBp = reinterpret_cast<const float*>(smem + BP_OFF) + lo8;
             const float* const sB2 = reinterpret_cast<const float*>(smem + B2_OFF) + lo8;
-            if constexpr (PROJ) {
-#pragma unroll
-                for (int k = 0; k < NKS; ++k) {
-                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(sBp + k * 16), c1 = *reinterpret_cast<const f32x4*>(sBp + k * 16 + 8);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o[k >> 1][(k & 1) * 8 + e] += xs[2 * k][e] + c0[e];
-                        o[k >> 1][(k & 1) * 8 + 4 + e] += xs[2 * k + 1][e] + c1[e];
-                    }
-                }
-            }
             float sum = 0.f;
 #pragma unroll
-            for (int db = 0; db < NDB; ++db)
+            for (int j = 0; j < 2 * NKS; ++j) {
+                if constexpr (PROJ) {
+                    if (j % 8 == 0) __builtin_amdgcn_sched_barrier(0);      // (a few pieces of constants in flight, not all 48)
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(sBp + (j >> 1) * 16 + (j & 1) * 8);
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    sum += ((o[db][8 * h] + o[db][8 * h + 1]) + (o[db][8 * h + 2] + o[db][8 * h + 3])) +
-                           ((o[db][8 * h + 4] + o[db][8 * h + 5]) + (o[db][8 * h + 6] + o[db][8 * h + 7]));
+                    for (int e = 0; e < 4; ++e) xs[j][e] += o[j >> 2][((j >> 1) & 1) * 8 + (j & 1) * 4 + e] + c[e];
+                }
+                sum += (xs[j][0] + xs[j][1]) + (xs[j][2] + xs[j][3]);
+            }
             sum += __shfl_xor(sum, 32);
             const float mean = sum * (1.0f / D);
             float qv = 0.f;
 #pragma unroll
-            for (int db = 0; db < NDB; ++db)
+            for (int j = 0; j < 2 * NKS; ++j) {
+                float part = 0.f;
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    float part = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float dlt = o[db][4 * q4 + e] - mean;
-                        part = fmaf(dlt, dlt, part);
-                    }
-                    qv += part;
+                for (int e = 0; e < 4; ++e) {
+                    const float dlt = xs[j][e] - mean;
+                    part = fmaf(dlt, dlt, part);
                 }
+                qv += part;
+            }
             qv += __shfl_xor(qv, 32);
             const float rstd = 1.0f / sqrtf(qv * (1.0f / D) + p.eps);
-            float mean_n = mean;
-            asm volatile("" : "+v"(mean_n));
+            float nmr = -mean * rstd;
+            asm volatile("" : "+v"(nmr));
 #pragma unroll
             for (int k = 0; k < NKS; ++k) {
-                __builtin_amdgcn_sched_barrier(0);
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(sG + k * 16), g1 = *reinterpret_cast<const f32x4*>(sG + k * 16 + 8);
-                const f32x4 e0 = *reinterpret_cast<const f32x4*>(sBe + k * 16), e1 = *reinterpret_cast<const f32x4*>(sBe + k * 16 + 8);
+                if (k % 4 == 0) __builtin_amdgcn_sched_barrier(0);
                 const f32x4 c0 = *reinterpret_cast<const f32x4*>(sB2 + k * 16), c1 = *reinterpret_cast<const f32x4*>(sB2 + k * 16 + 8);
                 float y[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float x0 = o[k >> 1][(k & 1) * 8 + e], x1 = o[k >> 1][(k & 1) * 8 + 4 + e];
-                    y[e] = (x0 - mean_n) * rstd * g0[e] + e0[e];
-                    y[4 + e] = (x1 - mean_n) * rstd * g1[e] + e1[e];
+                    const float x0 = xs[2 * k][e], x1 = xs[2 * k + 1][e];
+                    y[e] = fmaf(x0, rstd, nmr);
+                    y[4 + e] = fmaf(x1, rstd, nmr);
                     o[k >> 1][(k & 1) * 8 + e] = x0 + c0[e];
                     o[k >> 1][(k & 1) * 8 + 4 + e] = x1 + c1[e];
                 }
@@ -558,7 +561,7 @@ static int launch_mlp_fused4_fmt(const MlpFused3Params& p, hipStream_t s) {
 }
 
 int launch_mlp_fused4(const MlpFused3Params& p, hipStream_t s) {
-    if (p.M <= 0 || !p.X || !p.gamma || !p.beta || !p.Wp || !p.b1 || !p.b2 || (p.ctx && !p.bproj) || p.q) {
+    if (p.M <= 0 || !p.X || !p.Wp || !p.b2 || (p.ctx && !p.bproj) || p.q) {
         dinoseg_set_error("mlp_fused4: null pointer, bad shape (M=%d) or a qkv tail (not in this kernel)", p.M);
         return -1;
     }

@@ -324,14 +324,16 @@ int dinoseg_op_block_tail_fused3(float* X, const void* ctx, int64_t ctx_plane, c
 
 /* The single-plane fusion with ONE wave per SIMD (mlp_fused4.hip): the same result as dinoseg_op_proj_mlp_fused (fp16 / bf16 operands, the
  * logistic GELU of the benchmark modes), the structure of the hi + lo kernel above -- 128-row items, 32 rows per wave held in registers for
- * the whole item, the weights as one linear stream of 48-KiB slots.  ctx: [M][384] in the operand format, or null = the MLP half only.
- * Wp: dinoseg_op_pack_mlp4 (dinoseg_op_mlp4_pack_elems(D, F) 16-bit elements; Wproj may be null with ctx == null).  Library option
- * "mlp_fused4" (default 0: it measures equal; set before dinoseg_refresh_weights) makes dinoseg_forward use it instead of dinoseg_op_proj_mlp_fused.  vision_transformer.py:104-105, :123, :135 -> :59-65. */
+ * the whole item, the weights as one linear stream of 48-KiB slots, LayerNorm2's weight folded into W1's columns and its bias into b1 (the kernel
+ * computes (x - mean) rstd).  ctx: [M][384] in the operand format, or null = the MLP half only.  Wp: dinoseg_op_pack_mlp4
+ * (dinoseg_op_mlp4_pack_elems(D, F) 16-bit elements; Wproj may be null with ctx == null).  Library option "mlp_fused4" (default 0: it measures
+ * equal; set before dinoseg_refresh_weights) makes dinoseg_forward use it instead of dinoseg_op_proj_mlp_fused.
+ * vision_transformer.py:104-105, :123, :135 -> :59-65. */
 int64_t dinoseg_op_mlp4_pack_elems(int32_t D, int32_t F);
-int dinoseg_op_pack_mlp4(const float* Wproj, const float* W1, const float* W2, int32_t D, int32_t F, int32_t fmt, void* dst, void* stream);
-int dinoseg_op_proj_mlp_fused4(float* X, const void* ctx, const float* bproj, const float* gamma, const float* beta, float eps,
-                               const void* Wp, const float* b1, const float* b2, int32_t M, int32_t D, int32_t F, int32_t fmt,
-                               void* stream);
+int dinoseg_op_pack_mlp4(const float* Wproj, const float* W1, const float* b1, const float* W2, const float* gamma2, const float* beta2, int32_t D,
+                         int32_t F, int32_t fmt, void* dst, void* stream);
+int dinoseg_op_proj_mlp_fused4(float* X, const void* ctx, const float* bproj, float eps, const void* Wp, const float* b2, int32_t M, int32_t D,
+                               int32_t F, int32_t fmt, void* stream);
 
 /* ... and with LayerNorm1 + the qkv projection of the NEXT block at its end (Block.forward of block i from `x = x + attn` on, then
  * block i+1 up to `qkv = self.qkv(self.norm1(x))`: vision_transformer.py:123, :135, :122 -> :75): after the launch X holds block i's

@@ -150,13 +150,13 @@ for (Bq, ntok, fp16) in [(32, 3601, True), (11, 3601, False), (3, 130, True), (1
                                                     npad, H_, 0.125 * LOG2E, int(fp16), D_, F_, int(fp16), S()))
     screen(f"mlp_fused3 + qkv tail B={Bq} N={ntok} fp16={fp16}", run3t, lambda: [x3, q3, k3, v3])
     ctx1, _ = T._one_plane(c["ctx"], fp16)
-    Wp4 = T._pack_mlp4(c["Wpr"], c["W1"], c["W2"], fp16)
+    Wp4 = T._pack_mlp4(c["Wpr"], c["W1"], c["b1"], c["W2"], c["gam"], c["bet"], fp16)
     x4 = torch.zeros_like(c["X"])
 
     def run4():
         x4.copy_(c["X"])
-        capi.check(lib.dinoseg_op_proj_mlp_fused4(x4.data_ptr(), ctx1.data_ptr(), c["bpr"].data_ptr(), c["gam"].data_ptr(), c["bet"].data_ptr(), 1e-6,
-                                                  Wp4.data_ptr(), c["b1"].data_ptr(), c["b2"].data_ptr(), M_, D_, F_, int(fp16), S()))
+        capi.check(lib.dinoseg_op_proj_mlp_fused4(x4.data_ptr(), ctx1.data_ptr(), c["bpr"].data_ptr(), 1e-6, Wp4.data_ptr(), c["b2"].data_ptr(), M_, D_,
+                                                  F_, int(fp16), S()))
     screen(f"mlp_fused4 B={Bq} N={ntok} fp16={fp16}", run4, lambda: [x4])
     del c, ctx_pl, x3, q3, k3, v3, x4, Wp4
 
