@@ -167,8 +167,8 @@ struct Options {
     int qkv_fused = 0;       // 1: ... and LayerNorm1 + qkv of the NEXT block at its end (blocks 1.. then have no LN+qkv launch); measured
                              // +1 % on one stream, +-0 on two: the tail is bound by the same HBM write burst as the launch it replaces
     int mlp_fused4 = 0;      // one-plane modes: 1 = the fused projection + MLP launch with ONE wave per SIMD (mlp_fused4.hip) instead of mlp_fused2.hip's two
-                             // (no qkv tail: only while qkv_fused is 0).  Measured equal (headline 2582 against 2578 frames/s, the launch 361-368 against
-                             // 360-372 us: profiles/r06_mlp_fused4.md), so the older kernel stays the default.
+                             // (no qkv tail: only while qkv_fused is 0).  The launch 354-360 against 359-371 us, the headline +0.3-0.4 % (profiles/r06_mlp_fused4.md):
+                             // inside the boxes' spread, so the older kernel stays the default.
                              // Read when the weights are packed (dinoseg_refresh_weights) and at every forward
     int qkv_fused3 = 1;      // hi + lo planes (mlp_fused3.hip): 1 = LayerNorm1 + qkv of the NEXT block at the end of the fused projection + MLP launch
     int gemm_rs = 3;         // the row-stationary streaming GEMMs (gemm_rs.hip; embed_dim 768, one plane, >= gemm_rs_min_rows rows), a bit per linear:

@@ -239,10 +239,23 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
         // (every fourth gap one piece; M0 = the LDS destination of a group of four, set in the gap before the group's first piece)
         // mma(gap tag G, fragment): the product; valu(gap tag G): vector work of MFMA gap G (0 .. 47)
         // VM: vector-memory operations known to have been issued AFTER the pieces this step reads (at least the previous step's twelve pieces)
-        auto step = [&](auto vm_tag, auto&& mma, auto&& valu) __attribute__((always_inline)) {
+        // pre(): runs between the step's scalar work and its first product -- behind the first fragment reads, under their latency
+        auto step = [&](auto vm_tag, auto&& pre, auto&& mma, auto&& valu) __attribute__((always_inline)) {
             // what this step reads has landed: every wave's pieces of two steps ago
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(vm_tag)::value) : "memory");
             __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t a = frag_rd_i + (uint32_t)rpos * SLOT;
+            rpos = rpos + 1 == RING ? 0 : rpos + 1;
+            bf16x8 fr[NFR];
+            auto issue_read = [&](auto g_tag) __attribute__((always_inline)) {
+                constexpr int G = decltype(g_tag)::value;
+                if (MF4_ABL & 16) return;
+                mf_rd<G * 1024>(fr[G % NFR], a);
+            };
+            // the first fragment reads go out before the step's scalar work (the LDS-DMA descriptors of the slot two steps ahead)
+            mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
+            __builtin_amdgcn_sched_barrier(0);
             uint64_t gsb[3];
             uint32_t gld[3];
             {
@@ -255,14 +268,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
                 }
                 next_slot();
             }
-            const uint32_t a = frag_rd_i + (uint32_t)rpos * SLOT;
-            rpos = rpos + 1 == RING ? 0 : rpos + 1;
-            bf16x8 fr[NFR];
-            auto issue_read = [&](auto g_tag) __attribute__((always_inline)) {
-                constexpr int G = decltype(g_tag)::value;
-                if (MF4_ABL & 16) return;
-                mf_rd<G * 1024>(fr[G % NFR], a);
-            };
+            pre();
             auto gap = [&](auto g_tag) __attribute__((always_inline)) {
                 constexpr int G = decltype(g_tag)::value;
                 __builtin_amdgcn_sched_barrier(0);
@@ -276,7 +282,6 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
                 valu(g_tag);
                 __builtin_amdgcn_sched_barrier(0);
             };
-            mf_for(std::make_integer_sequence<int, RA>{}, issue_read);
             mf_for(std::make_integer_sequence<int, NFRAG>{}, [&](auto g_tag) __attribute__((always_inline)) {
                 constexpr int G = decltype(g_tag)::value;
                 if constexpr ((G & 1) == 0) {
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
         if constexpr (PROJ) {
             mf_for(std::make_integer_sequence<int, NPS>{}, [&](auto u_tag) __attribute__((always_inline)) {
                 constexpr int U = decltype(u_tag)::value;
-                step(std::integral_constant<int, (U == 0 ? 36 : U == 1 ? 44 : 20)>{},
+                step(std::integral_constant<int, (U == 0 ? 36 : U == 1 ? 44 : 20)>{}, []() {},
                      [&](auto g_tag, const bf16x8& fr) __attribute__((always_inline)) {
                          constexpr int G = decltype(g_tag)::value, KT = 2 * U + G / NKS, R = G % NKS, DB = R >> 1, S2 = R & 1;
                          if (!(MF4_ABL & 8)) {
@@ -432,24 +437,28 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
             }
         };
         // S = b1 of hidden tile t (register j of lane half h = unit (j & 7) + 8 h + 16 (j >> 3): the sigma23 row order)
-        auto s_bias = [&](f32x16& s, int t) __attribute__((always_inline)) {
+        // (the eight reads go out in front of the step's barrier, the accumulators are written behind the step's first fragment reads)
+        f32x4 bca[4], bcb[4];
+        auto s_bias_load = [&](f32x4 (&c)[4], int t) __attribute__((always_inline)) {
             const float* bp = sB1 + t * HT + lh_i * 8;
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(bp), c1 = *reinterpret_cast<const f32x4*>(bp + 4);
-            const f32x4 c2 = *reinterpret_cast<const f32x4*>(bp + 16), c3 = *reinterpret_cast<const f32x4*>(bp + 20);
+            c[0] = *reinterpret_cast<const f32x4*>(bp); c[1] = *reinterpret_cast<const f32x4*>(bp + 4);
+            c[2] = *reinterpret_cast<const f32x4*>(bp + 16); c[3] = *reinterpret_cast<const f32x4*>(bp + 20);
+        };
+        auto s_bias_set = [&](f32x16& s, const f32x4 (&c)[4]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[e] = c0[e];
-                s[4 + e] = c1[e];
-                s[8 + e] = c2[e];
-                s[12 + e] = c3[e];
-            }
+            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[4 * q4 + e] = c[q4][e];
         };
         // F1(u): sa_n = S(2u), sb_n = S(2u+1); its gaps carry the end of tile 2u-2's program (from sa_c) and the start of tile 2u-1's (from sb_c)
         auto step_f1 = [&](f32x16& sa_n, f32x16& sb_n, const f32x16& sa_c, const f32x16& sb_c, int u, auto gelu_tag) __attribute__((always_inline)) {
-            s_bias(sa_n, 2 * u);
-            s_bias(sb_n, 2 * u + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            s_bias_load(bca, 2 * u);
+            s_bias_load(bcb, 2 * u + 1);
             step(std::integral_constant<int, 12>{},
+                 [&]() __attribute__((always_inline)) {
+                     s_bias_set(sa_n, bca);
+                     s_bias_set(sb_n, bcb);
+                 },
                  [&](auto g_tag, const bf16x8& fr) __attribute__((always_inline)) {
                      // (the two tiles' accumulation chains alternate: a product never waits for the one issued just before it)
                      constexpr int G = decltype(g_tag)::value, KS = G >> 1;
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
         auto step_f2 = [&](const f32x16& sb_c, const f32x16& sa_c, auto tail_tag) __attribute__((always_inline)) {
             constexpr bool TAIL = decltype(tail_tag)::value;
             if constexpr (TAIL && PROJ) ncr = p.ctx + lane_row(item + (int)gridDim.x);
-            step(std::integral_constant<int, 12>{},
+            step(std::integral_constant<int, 12>{}, []() {},
                  [&](auto g_tag, const bf16x8& fr) __attribute__((always_inline)) {
                      constexpr int G = decltype(g_tag)::value, R = G % NKS, S2 = R / NDB, DB = R % NDB;
                      uint4 u;
