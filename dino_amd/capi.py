@@ -97,8 +97,9 @@ SIGNATURES = {
     "dinoseg_op_pack_mlp3": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _vp, _vp]),
     "dinoseg_op_proj_mlp_fused3": (C.c_int, [_fp, _vp, _i64, _fp, _f32, _vp, _fp, _i32, _i32, _i32, _i32, _vp]),
     "dinoseg_op_mlp4_pack_elems": (_i64, [_i32, _i32]),
-    "dinoseg_op_pack_mlp4": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _vp, _vp]),
+    "dinoseg_op_pack_mlp4": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _vp, _vp]),
     "dinoseg_op_proj_mlp_fused4": (C.c_int, [_fp, _vp, _fp, _f32, _vp, _fp, _i32, _i32, _i32, _i32, _vp]),
+    "dinoseg_op_block_tail_fused4": (C.c_int, [_fp, _vp, _fp, _f32, _vp, _fp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
     "dinoseg_op_block_tail_fused3": (C.c_int, [_fp, _vp, _i64, _fp, _f32, _vp, _fp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _i32,
                                                _i32, _i32, _vp]),
     "dinoseg_op_attention": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _fp, _i32, _i32, _i32, _i32, _i32, _vp]),

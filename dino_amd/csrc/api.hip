@@ -529,10 +529,18 @@ static int ensure_mlp_packs(dinoseg_handle* h, hipStream_t s) {
         DSEG_TRY(launch_pack_mlp(W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc2.weight"), Dm, Fh, kv.second, s, h->fmt));
     for (auto& kv : h->packed_proj) DSEG_TRY(launch_pack_proj(W(h, kv.first + "attn.proj.weight"), Dm, kv.second, s, h->fmt));
     for (auto& kv : h->packed_qkvf) DSEG_TRY(launch_pack_qkv(W(h, kv.first + "attn.qkv.weight"), Dm, kv.second, s, h->fmt));
-    for (auto& kv : h->packed_mlp4)
-        DSEG_TRY(launch_pack_mlp4(W(h, kv.first + "attn.proj.weight"), W(h, kv.first + "mlp.fc1.weight"), W(h, kv.first + "mlp.fc1.bias"),
-                                  W(h, kv.first + "mlp.fc2.weight"), W(h, kv.first + "norm2.weight"), W(h, kv.first + "norm2.bias"), Dm, Fh, kv.second, s,
-                                  h->fmt));
+    for (int i = 0; i < h->cfg.n_blocks; ++i) {      // (one-plane copies of the same streams: mlp_fused4.hip)
+        const std::string b = "dino.blocks." + std::to_string(i) + ".", nb = "dino.blocks." + std::to_string(i + 1) + ".";
+        if (!h->packed_mlp4.count(b)) continue;
+        MlpFused3Weights w = {};
+        w.Wproj = W(h, b + "attn.proj.weight"); w.W1 = W(h, b + "mlp.fc1.weight"); w.b1 = W(h, b + "mlp.fc1.bias"); w.W2 = W(h, b + "mlp.fc2.weight");
+        w.gamma2 = W(h, b + "norm2.weight"); w.beta2 = W(h, b + "norm2.bias");
+        if (i + 1 < h->cfg.n_blocks) {
+            w.Wqkv_next = W(h, nb + "attn.qkv.weight"); w.bqkv_next = W(h, nb + "attn.qkv.bias");
+            w.gamma1_next = W(h, nb + "norm1.weight"); w.beta1_next = W(h, nb + "norm1.bias");
+        }
+        DSEG_TRY(launch_pack_mlp4(w, Dm, Fh, h->packed_mlp4.at(b), s, h->fmt));
+    }
     for (int i = 0; i < h->cfg.n_blocks; ++i) {      // (block i's stream ends with the qkv weight of block i + 1: the tail of its fused launch)
         const std::string b = "dino.blocks." + std::to_string(i) + ".", nb = "dino.blocks." + std::to_string(i + 1) + ".";
         if (!h->packed_mlp3.count(b)) continue;
@@ -768,6 +776,11 @@ static int forward_impl(dinoseg_handle* h, const void* x, int32_t x_kind, int32_
             g.Wp = h->packed_mlp4.at(b); g.b2 = W(h, b + "mlp.fc2.bias");
             g.M = L.M; g.fmt = FM;
             g.ctx = CTX; g.bproj = W(h, b + "attn.proj.bias");
+            // ... and LayerNorm1 + qkv of the next block (a tap of this block's output still reads X, which is complete)
+            if (options().qkv_fused4 && i + 1 < c.n_blocks) {
+                g.q = Q; g.k = Kb; g.v = V; g.ntok = L.ntok; g.npad = L.npad; g.heads = H; g.qscale = qscale;
+                qkv_ready = true;
+            }
             DSEG_PROF(DINOSEG_PROF_FC1, DSEG_TRY(launch_mlp_fused4(g, s)));
         } else if (fuse_mlp) {
             DSEG_TRY(ensure_mlp_packs(h, s));      // (a split forward has done this before its fork)
@@ -1047,6 +1060,10 @@ extern "C" int dinoseg_set_option(const char* key, int32_t value) {
         dseg::options().qkv_fused3 = value ? 1 : 0;
         return 0;
     }
+    if (strcmp(key, "qkv_fused4") == 0) {
+        dseg::options().qkv_fused4 = value ? 1 : 0;
+        return 0;
+    }
     if (strcmp(key, "mlp_fused4") == 0) {
         dseg::options().mlp_fused4 = value ? 1 : 0;
         return 0;
@@ -1286,12 +1303,14 @@ extern "C" int dinoseg_op_block_tail_fused3(float* X, const void* ctx, int64_t c
 extern "C" int64_t dinoseg_op_mlp4_pack_elems(int32_t D, int32_t F) { return mlp_fused4_pack_elems(D, F); }
 
 extern "C" int dinoseg_op_pack_mlp4(const float* Wproj, const float* W1, const float* b1, const float* W2, const float* gamma2, const float* beta2,
-                                    int32_t D, int32_t F, int32_t fmt, void* dst, void* stream) {
+                                    const float* Wqkv_next, const float* bqkv_next, const float* gamma1_next, const float* beta1_next, int32_t D,
+                                    int32_t F, int32_t fmt, void* dst, void* stream) {
     if (fmt != FMT_BF16 && fmt != FMT_FP16) {
         dinoseg_set_error("dinoseg_op_pack_mlp4: bad operand format %d", fmt);
         return -1;
     }
-    return launch_pack_mlp4(Wproj, W1, b1, W2, gamma2, beta2, D, F, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), fmt);
+    MlpFused3Weights w = {Wproj, W1, b1, W2, gamma2, beta2, Wqkv_next, bqkv_next, gamma1_next, beta1_next};
+    return launch_pack_mlp4(w, D, F, reinterpret_cast<bf16_t*>(dst), reinterpret_cast<hipStream_t>(stream), fmt);
 }
 
 extern "C" int dinoseg_op_proj_mlp_fused4(float* X, const void* ctx, const float* bproj, float eps, const void* Wp, const float* b2, int32_t M,
@@ -1304,6 +1323,22 @@ extern "C" int dinoseg_op_proj_mlp_fused4(float* X, const void* ctx, const float
     g.X = X; g.eps = eps;
     g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b2 = b2; g.M = M;
     g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.bproj = bproj; g.fmt = fmt;
+    return launch_mlp_fused4(g, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dinoseg_op_block_tail_fused4(float* X, const void* ctx, const float* bproj, float eps, const void* Wp, const float* b2, void* q, void* k,
+                                            void* v, int32_t B, int32_t ntok, int32_t npad, int32_t heads, float qscale, int32_t D, int32_t F,
+                                            int32_t fmt, void* stream) {
+    if (!mlp_fused4_supported(D, F, 1) || (fmt != FMT_BF16 && fmt != FMT_FP16) || !q || B <= 0 || npad % 64 != 0) {
+        dinoseg_set_error("dinoseg_op_block_tail_fused4: unsupported shape D=%d F=%d, format %d, or null q", D, F, fmt);
+        return -1;
+    }
+    MlpFused3Params g = {};
+    g.X = X; g.eps = eps;
+    g.Wp = reinterpret_cast<const bf16_t*>(Wp); g.b2 = b2; g.M = B * ntok;
+    g.ctx = reinterpret_cast<const bf16_t*>(ctx); g.bproj = bproj; g.fmt = fmt;
+    g.q = reinterpret_cast<bf16_t*>(q); g.k = reinterpret_cast<bf16_t*>(k); g.v = reinterpret_cast<bf16_t*>(v);
+    g.ntok = ntok; g.npad = npad; g.heads = heads; g.qscale = qscale;
     return launch_mlp_fused4(g, reinterpret_cast<hipStream_t>(stream));
 }
 

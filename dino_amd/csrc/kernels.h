@@ -143,13 +143,12 @@ bool mlp_fused3_supported(int D, int F, int planes);
 long mlp_fused3_pack_elems(int D, int F);       // 16-bit elements of the packed copy, qkv tail slots and folded biases included (0: unsupported shape)
 int launch_pack_mlp3(const MlpFused3Weights& w, int D, int F, bf16_t* dst, hipStream_t s, int fmt);
 int launch_mlp_fused3(const MlpFused3Params& p, hipStream_t s);
-// The same launch on ONE operand plane, one wave per SIMD (mlp_fused4.hip; MlpFused3Params without the plane strides and without a qkv tail):
-// Wp = launch_pack_mlp4's 54 slots of 48 fragments (Wproj may be null for an MLP-only copy: its six slots are zero and never read), W1's columns
-// scaled by norm2's weight, then the folded bias b1 + W1 beta2
+// The same launch on ONE operand plane, one wave per SIMD (mlp_fused4.hip; MlpFused3Params without the plane strides; the qkv tail writes one plane
+// each, V as bf16): Wp = launch_pack_mlp4's 54 (+ 18: the next block's Wqkv) slots of 48 fragments (Wproj may be null for an MLP-only copy: its six
+// slots are zero and never read), the LayerNorms folded in as in launch_pack_mlp3, then the folded biases
 bool mlp_fused4_supported(int D, int F, int planes);
-long mlp_fused4_pack_elems(int D, int F);       // 16-bit elements of the packed copy, folded bias included (0: unsupported shape)
-int launch_pack_mlp4(const float* Wproj /* nullable */, const float* W1, const float* b1, const float* W2, const float* gamma2, const float* beta2, int D,
-                     int F, bf16_t* dst, hipStream_t s, int fmt);
+long mlp_fused4_pack_elems(int D, int F);       // 16-bit elements of the packed copy, tail slots and folded biases included (0: unsupported shape)
+int launch_pack_mlp4(const MlpFused3Weights& w, int D, int F, bf16_t* dst, hipStream_t s, int fmt);
 int launch_mlp_fused4(const MlpFused3Params& p, hipStream_t s);
 
 // tuning knobs (dinoseg_set_option): see api.hip
@@ -170,6 +169,7 @@ struct Options {
                              // (no qkv tail: only while qkv_fused is 0).  The launch 354-360 against 359-371 us, the headline +0.3-0.4 % (profiles/r06_mlp_fused4.md):
                              // inside the boxes' spread, so the older kernel stays the default.
                              // Read when the weights are packed (dinoseg_refresh_weights) and at every forward
+    int qkv_fused4 = 1;      // ... with LayerNorm1 + qkv of the NEXT block at its end (as qkv_fused3 for the hi + lo launch)
     int qkv_fused3 = 1;      // hi + lo planes (mlp_fused3.hip): 1 = LayerNorm1 + qkv of the NEXT block at the end of the fused projection + MLP launch
     int gemm_rs = 3;         // the row-stationary streaming GEMMs (gemm_rs.hip; embed_dim 768, one plane, >= gemm_rs_min_rows rows), a bit per linear:
                              // 1 = mlp.fc1 (its GELU epilogue rides in the MFMA gaps: 329 against gemm_big's 357 us at 57 616 rows), 2 = attn.qkv

@@ -38,15 +38,17 @@ constexpr int NFRAG = SLOT / 1024;
 constexpr int NPS = D / 64;                         // projection steps (two k-tiles each)
 constexpr int NU = NT / 2;                          // fc1 / fc2 steps (two hidden tiles each)
 constexpr int NSLOT = NPS + 2 * NU;                 // slots per item (54)
+constexpr int NQS = 3 * D / 64;                     // QKV tail: steps of two 32-feature tiles of the next block's Wqkv (18)
 constexpr int RING = 3;
 constexpr int B1_OFF = RING * SLOT;                 // b1' [F] fp32 (b1 + W1 beta2: LayerNorm2 is folded into the packed copy)
 constexpr int BP_OFF = B1_OFF + F * 4;              // the two residual biases: b_proj, b2 [D] fp32 each
 constexpr int B2_OFF = BP_OFF + D * 4;
-constexpr int LDS_BYTES = B2_OFF + D * 4;
-// the packed copy of a block: NSLOT slots, then the folded bias b1' [F] (fp32)
-constexpr long BIAS_OFF_BYTES = (long)NSLOT * SLOT;
-[[maybe_unused]] constexpr long PACK_BYTES = BIAS_OFF_BYTES + F * 4;
+constexpr int BQ_OFF = B2_OFF + D * 4;              // QKV tail: the next block's folded qkv bias [1152] fp32
+constexpr int LDS_BYTES = BQ_OFF + 3 * D * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+// the packed copy of a block: NSLOT (+ NQS) slots, then the folded biases (fp32): b1' [F], bq' [3 D]
+constexpr long BIAS_OFF_BYTES = (long)(NSLOT + NQS) * SLOT;
+[[maybe_unused]] constexpr long PACK_BYTES = BIAS_OFF_BYTES + (F + 3 * D) * 4;
 constexpr int PIECES = SLOT / 1024 / NW;            // LDS-DMA pieces per wave and step
 static_assert(PIECES == 12, "three groups of four pieces");
 #ifndef MF4_RA
@@ -62,8 +64,9 @@ static_assert(RA % 2 == 0 && RA >= 2, "pairs");
 #endif
 
 // stream slot n (0 .. 53) of a block's packed weights -> which matrix tiles it holds
-__host__ __device__ inline void mf4_slot_kind(int n, int& kind, int& u) {      // kind 0 proj, 1 fc1, 2 fc2; u = step index of that kind
+__host__ __device__ inline void mf4_slot_kind(int n, int& kind, int& u) {      // kind 0 proj, 1 fc1, 2 fc2, 3 qkv tail; u = step index of that kind
     using namespace mf4;
+    if (n >= NSLOT) { kind = 3; u = n - NSLOT; return; }
     if (n < NPS) { kind = 0; u = n; return; }
     const int m = n - NPS;
     if (m == 0) { kind = 1; u = 0; }
@@ -76,9 +79,10 @@ __host__ __device__ inline void mf4_slot_kind(int n, int& kind, int& u) {      /
 // LayerNorm2's weight g2 is folded into the columns of W1 (its bias into b1: fold_bias4_kernel): LayerNorm(x) W^T + b = ((x - mean) rstd) (W diag(g))^T +
 // (b + W beta) -- the kernel's LayerNorm needs no per-feature constants
 __global__ __launch_bounds__(256) void pack_mlp4_kernel(const float* __restrict__ Wpr, const float* __restrict__ W1, const float* __restrict__ W2,
-                                                        const float* __restrict__ g2, bf16_t* __restrict__ dst, int fmt) {
+                                                        const float* __restrict__ g2, const float* __restrict__ Wqkv, const float* __restrict__ g1n,
+                                                        bf16_t* __restrict__ dst, int fmt) {
     using namespace mf4;
-    const long total = (long)NSLOT * NFRAG * 512;
+    const long total = (long)(NSLOT + (Wqkv ? NQS : 0)) * NFRAG * 512;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         long q = idx;
         const int e = (int)(q & 7); q >>= 3;
@@ -90,12 +94,12 @@ __global__ __launch_bounds__(256) void pack_mlp4_kernel(const float* __restrict_
         int kind, u;
         mf4_slot_kind(slot, kind, u);
         float v;
-        if (kind == 1) {             // fc1: A row = hidden unit (sigma23 order: the accumulator layout is fc2's operand layout), fragment = (k-step, tile
+        if (kind == 1 || kind == 3) {      // fc1 / qkv tail: A row = hidden unit / output feature (sigma23 order: the accumulator layout is fc2's operand layout), fragment = (k-step, tile
                                      // half): the two tiles' products alternate.  k runs in the order LayerNorm2 leaves the row in a lane's registers:
                                      // element e of lane half h = feature 16 ks + 8 (e >> 2) + 4 h + (e & 3)
             const int i = attn::sigma23(lane & 31);
             const int f = (frag >> 1) * 16 + 8 * (e >> 2) + 4 * h + (e & 3);
-            v = W1[(long)((2 * u + (frag & 1)) * HT + i) * D + f] * g2[f];
+            v = (kind == 1 ? W1 : Wqkv)[(long)((2 * u + (frag & 1)) * HT + i) * D + f] * (kind == 1 ? g2 : g1n)[f];
         } else if (kind == 0) {      // proj: A row = output feature (natural order: register 4 g + e of lane half h = feature 32 db + 8 g + 4 h + e, the
                                      // two lanes of a row hold adjacent 16-byte pieces), k = the k-tile's 32 inputs, fragment = (k-tile half, db, s2)
             const int db = r >> 1, s2 = r & 1, i = lane & 31;
@@ -123,21 +127,27 @@ __global__ __launch_bounds__(256) void fold_bias4_kernel(const float* __restrict
     if (lane == 0) out[n] = bias[n] + acc;
 }
 
-int launch_pack_mlp4(const float* Wproj, const float* W1, const float* b1, const float* W2, const float* gamma2, const float* beta2, int Dm, int Fh,
-                     bf16_t* dst, hipStream_t s, int fmt) {
-    if (mlp_fused4_pack_elems(Dm, Fh) <= 0 || !W1 || !b1 || !W2 || !gamma2 || !beta2 || !dst) {
+int launch_pack_mlp4(const MlpFused3Weights& w, int Dm, int Fh, bf16_t* dst, hipStream_t s, int fmt) {
+    if (mlp_fused4_pack_elems(Dm, Fh) <= 0 || !w.W1 || !w.b1 || !w.W2 || !w.gamma2 || !w.beta2 || !dst ||
+        (w.Wqkv_next && (!w.bqkv_next || !w.gamma1_next || !w.beta1_next))) {
         dinoseg_set_error("pack_mlp4: null pointer or unsupported shape D=%d F=%d", Dm, Fh);
         return -1;
     }
-    hipLaunchKernelGGL(pack_mlp4_kernel, dim3(2048), dim3(256), 0, s, Wproj, W1, W2, gamma2, dst, fmt);
-    hipLaunchKernelGGL(fold_bias4_kernel, dim3((Fh + 3) / 4), dim3(256), 0, s, W1, beta2, b1, Fh, Dm,
-                       reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + mf4::BIAS_OFF_BYTES));
+    hipLaunchKernelGGL(pack_mlp4_kernel, dim3(2048), dim3(256), 0, s, w.Wproj, w.W1, w.W2, w.gamma2, w.Wqkv_next, w.gamma1_next, dst, fmt);
+    float* fb = reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + mf4::BIAS_OFF_BYTES);
+    hipLaunchKernelGGL(fold_bias4_kernel, dim3((Fh + 3) / 4), dim3(256), 0, s, w.W1, w.beta2, w.b1, Fh, Dm, fb);
+    if (w.Wqkv_next)
+        hipLaunchKernelGGL(fold_bias4_kernel, dim3((3 * Dm + 3) / 4), dim3(256), 0, s, w.Wqkv_next, w.beta1_next, w.bqkv_next, 3 * Dm, Dm, fb + Fh);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-template <int FMT, bool PROJ>
+// QKV: LayerNorm1 + the qkv projection of the NEXT block at the end of the same launch (vision_transformer.py:122 -> :75): the finished rows are
+// normalised from the accumulators, then 18 steps of the fc1 kind on the next block's Wqkv (two 32-feature tiles per step: Q tiles 0 .. 11, K 12 .. 23,
+// V 24 .. 35); a step's two tiles are scaled (Q: 64^-0.5 log2 e), packed and stored to Q / K / V [B, heads, npad, 64] from the gaps of the next step
+template <int FMT, bool PROJ, bool QKV>
 __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Params p) {
+    static_assert(PROJ || !QKV, "the qkv tail comes with the projection build");
     using namespace mf4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -150,6 +160,8 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
     {
         const float* fb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.Wp) + BIAS_OFF_BYTES);
         for (int i = tid; i < F / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + B1_OFF)[i] = reinterpret_cast<const f32x4*>(fb)[i];
+        if constexpr (QKV)
+            for (int i = tid; i < 3 * D / 4; i += THREADS) reinterpret_cast<f32x4*>(smem + BQ_OFF)[i] = reinterpret_cast<const f32x4*>(fb + F)[i];
         for (int i = tid; i < D / 4; i += THREADS) {
             if constexpr (PROJ) reinterpret_cast<f32x4*>(smem + BP_OFF)[i] = reinterpret_cast<const f32x4*>(p.bproj)[i];
             reinterpret_cast<f32x4*>(smem + B2_OFF)[i] = reinterpret_cast<const f32x4*>(p.b2)[i];
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
     };
     const uint64_t wp = reinterpret_cast<uint64_t>(p.Wp);
     const uint32_t piece0 = (uint32_t)wave * PIECES * 1024;      // this wave's share of a slot: bytes piece0 .. piece0 + 12 KiB
-    constexpr int first_slot = PROJ ? 0 : NPS, end_slot = NSLOT;
+    constexpr int first_slot = PROJ ? 0 : NPS, end_slot = QKV ? NSLOT + NQS : NSLOT;
 
     // the weight stream: sn = stream slot the next step issues, ipos = the ring position it goes to, rpos = the position the next step reads
     int sn = first_slot, ipos = 0, rpos = 0;
@@ -228,9 +240,11 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
             xn[k] = __builtin_bit_cast(bf16x8, u);
         };
         const float* const xr_item = p.X + lane_row_x(item);
+        const bf16_t* const cr_item = PROJ ? p.ctx + lane_row(item) : nullptr;
         if constexpr (PROJ) {
+            // (the ctx fragments of a projection step are loaded two steps ahead: those of P0 and P1 here / in the previous item's last step)
             if (item == (int)blockIdx.x)
-                mf_for(std::make_integer_sequence<int, NKS>{}, [&](auto k_tag) __attribute__((always_inline)) { load_ctx(p.ctx + lane_row(item), k_tag); });
+                mf_for(std::make_integer_sequence<int, 8>{}, [&](auto k_tag) __attribute__((always_inline)) { load_ctx(cr_item, k_tag); });
         } else {
             mf_for(std::make_integer_sequence<int, 2 * NKS>{}, [&](auto j_tag) __attribute__((always_inline)) { load_xs(xr_item, j_tag); });
         }
@@ -298,13 +312,13 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
             });
         };
 
-        // ---- projection: o^T = Wproj . ctx^T, six steps of two k-tiles; eight of the x row's loads in the gaps of each.
-        // Behind the pieces a step reads came at least: P0 -- the previous step's pieces and 24 of the row operations of the boundary (the ctx loads of
-        // a first item, the stores of a later one: issued after the last step's pieces); P1 -- P0's pieces, its 8 loads and those 24; then 12 + 8
+        // ---- projection: o^T = Wproj . ctx^T, six steps of two k-tiles; eight of the x row's loads and the four ctx fragments of the step after the
+        // next in the gaps of each.  Behind the pieces a step reads came at least: P0 -- the previous step's pieces and the 8 ctx loads of the boundary;
+        // P1 -- those 8, P0's pieces and its 12 row loads; then a step's pieces and 8 loads
         if constexpr (PROJ) {
             mf_for(std::make_integer_sequence<int, NPS>{}, [&](auto u_tag) __attribute__((always_inline)) {
                 constexpr int U = decltype(u_tag)::value;
-                step(std::integral_constant<int, (U == 0 ? 36 : U == 1 ? 44 : 20)>{}, []() {},
+                step(std::integral_constant<int, (U == 0 ? 20 : U == 1 ? 32 : 20)>{}, []() {},
                      [&](auto g_tag, const bf16x8& fr) __attribute__((always_inline)) {
                          constexpr int G = decltype(g_tag)::value, KT = 2 * U + G / NKS, R = G % NKS, DB = R >> 1, S2 = R & 1;
                          if (!(MF4_ABL & 8)) {
@@ -321,6 +335,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
                      [&](auto g_tag) __attribute__((always_inline)) {
                          constexpr int G = decltype(g_tag)::value;
                          if constexpr ((G & 3) == 1 && G < 32) load_xs(xr_item, std::integral_constant<int, 8 * U + (G >> 2)>{});
+                         if constexpr ((G & 3) == 3 && G < 16 && U + 2 < NPS) load_ctx(cr_item, std::integral_constant<int, 4 * (U + 2) + (G >> 2)>{});
                      });
             });
         }
@@ -475,7 +490,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
         const bf16_t* ncr = nullptr;
         auto step_f2 = [&](const f32x16& sb_c, const f32x16& sa_c, auto tail_tag) __attribute__((always_inline)) {
             constexpr bool TAIL = decltype(tail_tag)::value;
-            if constexpr (TAIL && PROJ) ncr = p.ctx + lane_row(item + (int)gridDim.x);
+            if constexpr (TAIL && PROJ && !QKV) ncr = p.ctx + lane_row(item + (int)gridDim.x);
             step(std::integral_constant<int, 12>{}, []() {},
                  [&](auto g_tag, const bf16x8& fr) __attribute__((always_inline)) {
                      constexpr int G = decltype(g_tag)::value, R = G % NKS, S2 = R / NDB, DB = R % NDB;
@@ -487,7 +502,7 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
                  [&](auto g_tag) __attribute__((always_inline)) {
                      constexpr int G = decltype(g_tag)::value;
                      gelu_gap(g_tag, std::false_type{}, std::true_type{}, std::integral_constant<bool, !TAIL>{}, sa_c, sb_c);
-                     if constexpr (TAIL && PROJ && G < NKS) load_ctx(ncr, g_tag);
+                     if constexpr (TAIL && PROJ && !QKV && G < 8) load_ctx(ncr, g_tag);
                  });
             if constexpr (TAIL) {
                 // (no row guard: a lane past the last row works on a copy of row M - 1 -- the clamped loads -- and every output column of an
@@ -537,6 +552,135 @@ __global__ __launch_bounds__(mf4::THREADS, 1) void mlp_fused4_kernel(MlpFused3Pa
         // (the last F2 above started tile 46 = SA1; tile 47 = SB1 has not started)
         filler(std::integral_constant<int, NFRAG - CARRY>{}, std::integral_constant<int, GELU_LEN - (NFRAG - CARRY)>{}, I0{}, SA1, SB1);
         step_f2(SB1, SA1, std::true_type{});                                            // F2(23) + tile 47 (end): the rows out, the next item's rows in
+
+        if constexpr (QKV) {
+            // ---- LayerNorm1 of the next block on the finished rows: (v - mean) rstd from a copy in the x registers -> xn (its weight and bias ride in
+            // Wqkv' / bq')
+            {
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2 * NKS; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xs[j][e] = o[j >> 2][((j >> 1) & 1) * 8 + (j & 1) * 4 + e];
+                    sum += (xs[j][0] + xs[j][1]) + (xs[j][2] + xs[j][3]);
+                }
+                sum += __shfl_xor(sum, 32);
+                const float mean = sum * (1.0f / D);
+                float qv = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2 * NKS; ++j) {
+                    float part = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dlt = xs[j][e] - mean;
+                        part = fmaf(dlt, dlt, part);
+                    }
+                    qv += part;
+                }
+                qv += __shfl_xor(qv, 32);
+                const float rstd = 1.0f / sqrtf(qv * (1.0f / D) + p.eps);
+                const float nmr = -mean * rstd;
+#pragma unroll
+                for (int k = 0; k < NKS; ++k) {
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[e] = fmaf(xs[2 * k][e], rstd, nmr);
+                        y[4 + e] = fmaf(xs[2 * k + 1][e], rstd, nmr);
+                    }
+                    uint4 u;
+                    u.x = pack2<FMT>(y[0], y[1]);
+                    u.y = pack2<FMT>(y[2], y[3]);
+                    u.z = pack2<FMT>(y[4], y[5]);
+                    u.w = pack2<FMT>(y[6], y[7]);
+                    xn[k] = __builtin_bit_cast(bf16x8, u);
+                }
+            }
+            // destination of this lane's row in each of Q, K, V: ((frame * heads) * npad + token) * 64 (+ 8 elements for the upper lane half)
+            long qrow;
+            {
+                uint32_t z = 0;
+                asm volatile("" : "+v"(z));
+                const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+                const int r = item * BM + wave * 32 + (int)(l & 31);
+                const int rc = r < M ? r : M - 1;
+                const int fr_ = rc / p.ntok, tok_ = rc - fr_ * p.ntok;
+                qrow = ((long)fr_ * p.heads * p.npad + tok_) * 64 + (l >> 5) * 8;
+            }
+            const float* const sBq = reinterpret_cast<const float*>(smem + BQ_OFF);
+            float ezA[16], ezB[16];
+            uint32_t zpA[8], zpB[8];
+            // epilogue program of the two tiles 2 uq (values in za) and 2 uq + 1 (zb), gap G of the step that carries it: element n of the first tile is
+            // read out of its accumulator at gap n and scaled at n + 1, a pair packed at n + 2, the tile's two 16-byte stores at gaps 19, 20; the second
+            // tile 21 gaps later.  V tiles (24 ..) are bf16 whatever FMT is (the one-plane attention's P.V product); Q / K saturate like gemm_big.hip
+            auto epi_tile = [&](auto x_tag, const f32x16& z, float(&ez)[16], uint32_t(&zp)[8], int tq) __attribute__((always_inline)) {
+                constexpr int X = decltype(x_tag)::value;
+                mf_for(std::make_integer_sequence<int, 16>{}, [&](auto n_tag) __attribute__((always_inline)) {
+                    constexpr int N = decltype(n_tag)::value;
+                    if constexpr (X == N) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(ez[N]) : "a"(z[N]));
+                    if constexpr (X == N + 1) ez[N] = ez[N] * (tq < NDB ? p.qscale : 1.0f);
+                    if constexpr ((N & 1) == 1 && X == N + 2) {
+                        if (FMT == FMT_BF16 || tq >= 2 * NDB) zp[N >> 1] = pack_bf16x2(ez[N - 1], ez[N]);
+                        else zp[N >> 1] = pack2_sat<FMT>(ez[N - 1], ez[N]);
+                    }
+                });
+                if constexpr (X == 19 || X == 20) {
+                    // (no row guard: duplicates of row M - 1 store the same bits to the same place, as the residual rows)
+                    constexpr int GG = X - 19;
+                    const int which = tq / NDB, hb = tq - which * NDB;
+                    bf16_t* dst = (which == 0 ? p.q : (which == 1 ? p.k : p.v)) + qrow + (long)(hb >> 1) * p.npad * 64 + (hb & 1) * 32 + GG * 16;
+                    const uint4 u = {zp[4 * GG], zp[4 * GG + 1], zp[4 * GG + 2], zp[4 * GG + 3]};
+                    if (!(MF4_ABL & (32 | 64))) *reinterpret_cast<uint4*>(dst) = u;
+                    else asm volatile("" ::"v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w));
+                }
+            };
+            auto epi_gap = [&](auto g_tag, const f32x16& za, const f32x16& zb, int uq) __attribute__((always_inline)) {
+                constexpr int G = decltype(g_tag)::value;
+                if constexpr (G <= 20) epi_tile(g_tag, za, ezA, zpA, 2 * uq);
+                if constexpr (G >= 21 && G <= 41) epi_tile(std::integral_constant<int, G - 21>{}, zb, ezB, zpB, 2 * uq + 1);
+            };
+            // LASTQ: the next item's first ctx fragments into xn[0 .. 7] (last read by product 15) in gaps 16 .. 23
+            const bf16_t* ncq = nullptr;
+            auto step_q = [&](f32x16& za_n, f32x16& zb_n, const f32x16& za_c, const f32x16& zb_c, int uq, auto epi_tag, auto last_tag) __attribute__((always_inline)) {
+                constexpr bool EPI = decltype(epi_tag)::value, LASTQ = decltype(last_tag)::value;
+                {
+                    const float* bp = sBq + (2 * uq) * 32 + lh_i * 8;
+                    bca[0] = *reinterpret_cast<const f32x4*>(bp); bca[1] = *reinterpret_cast<const f32x4*>(bp + 4);
+                    bca[2] = *reinterpret_cast<const f32x4*>(bp + 16); bca[3] = *reinterpret_cast<const f32x4*>(bp + 20);
+                    bcb[0] = *reinterpret_cast<const f32x4*>(bp + 32); bcb[1] = *reinterpret_cast<const f32x4*>(bp + 36);
+                    bcb[2] = *reinterpret_cast<const f32x4*>(bp + 48); bcb[3] = *reinterpret_cast<const f32x4*>(bp + 52);
+                }
+                if constexpr (LASTQ) ncq = p.ctx + lane_row(item + (int)gridDim.x);
+                step(std::integral_constant<int, 12>{},
+                     [&]() __attribute__((always_inline)) {
+                         s_bias_set(za_n, bca);
+                         s_bias_set(zb_n, bcb);
+                     },
+                     [&](auto g_tag, const bf16x8& fr) __attribute__((always_inline)) {
+                         constexpr int G = decltype(g_tag)::value, KS = G >> 1;
+                         if (!(MF4_ABL & 4)) {
+                             if constexpr ((G & 1) == 0) za_n = mfma32f<FMT>(fr, xn[KS], za_n);
+                             else zb_n = mfma32f<FMT>(fr, xn[KS], zb_n);
+                         }
+                     },
+                     [&](auto g_tag) __attribute__((always_inline)) {
+                         constexpr int G = decltype(g_tag)::value;
+                         if constexpr (EPI) epi_gap(g_tag, za_c, zb_c, uq - 1);
+                         if constexpr (LASTQ && G >= 16 && G < 24) load_ctx(ncq, std::integral_constant<int, G - 16>{});
+                     });
+            };
+            step_q(SA0, SB0, SA0, SB0, 0, std::false_type{}, std::false_type{});
+#pragma unroll 1
+            for (int uq = 1; uq < NQS - 1; uq += 2) {
+                step_q(SA1, SB1, SA0, SB0, uq, std::true_type{}, std::false_type{});
+                step_q(SA0, SB0, SA1, SB1, uq + 1, std::true_type{}, std::false_type{});
+            }
+            step_q(SA1, SB1, SA0, SB0, NQS - 1, std::true_type{}, std::true_type{});
+            mf_for(std::make_integer_sequence<int, 42>{}, [&](auto g_tag) __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+                epi_gap(g_tag, SA1, SB1, NQS - 1);
+            });
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring pieces issued past the last item's end
 }
@@ -546,8 +690,9 @@ static int launch_mlp_fused4_fmt(const MlpFused3Params& p, hipStream_t s) {
     static PerDeviceOnce once;
     if (once.first()) {
         auto opt_in = [](const void* fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mf4::LDS_BYTES); };
-        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&mlp_fused4_kernel<FMT, false>)));
-        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&mlp_fused4_kernel<FMT, true>)));
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&mlp_fused4_kernel<FMT, false, false>)));
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&mlp_fused4_kernel<FMT, true, false>)));
+        DSEG_CHECK_HIP(opt_in(reinterpret_cast<const void*>(&mlp_fused4_kernel<FMT, true, true>)));
         once.mark();
     }
     const int ncu = device_cu_count();
@@ -563,15 +708,20 @@ static int launch_mlp_fused4_fmt(const MlpFused3Params& p, hipStream_t s) {
         grid = (nitems + rounds - 1) / rounds;
     }
     const dim3 g(grid), b(mf4::THREADS);
-    if (p.ctx) hipLaunchKernelGGL((mlp_fused4_kernel<FMT, true>), g, b, mf4::LDS_BYTES, s, p);
-    else hipLaunchKernelGGL((mlp_fused4_kernel<FMT, false>), g, b, mf4::LDS_BYTES, s, p);
+    if (p.q) hipLaunchKernelGGL((mlp_fused4_kernel<FMT, true, true>), g, b, mf4::LDS_BYTES, s, p);
+    else if (p.ctx) hipLaunchKernelGGL((mlp_fused4_kernel<FMT, true, false>), g, b, mf4::LDS_BYTES, s, p);
+    else hipLaunchKernelGGL((mlp_fused4_kernel<FMT, false, false>), g, b, mf4::LDS_BYTES, s, p);
     DSEG_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_mlp_fused4(const MlpFused3Params& p, hipStream_t s) {
-    if (p.M <= 0 || !p.X || !p.Wp || !p.b2 || (p.ctx && !p.bproj) || p.q) {
-        dinoseg_set_error("mlp_fused4: null pointer, bad shape (M=%d) or a qkv tail (not in this kernel)", p.M);
+    if (p.M <= 0 || !p.X || !p.Wp || !p.b2 || (p.ctx && !p.bproj)) {
+        dinoseg_set_error("mlp_fused4: null pointer or bad shape (M=%d)", p.M);
+        return -1;
+    }
+    if (p.q && (!p.ctx || !p.k || !p.v || p.ntok <= 0 || p.npad < p.ntok || p.heads * 64 != mf4::D || p.M % p.ntok != 0)) {
+        dinoseg_set_error("mlp_fused4: incomplete qkv tail (needs ctx, q / k / v, whole frames of ntok rows)");
         return -1;
     }
     return p.fmt == FMT_FP16 ? launch_mlp_fused4_fmt<FMT_FP16>(p, s) : launch_mlp_fused4_fmt<FMT_BF16>(p, s);

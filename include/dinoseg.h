@@ -330,10 +330,17 @@ int dinoseg_op_block_tail_fused3(float* X, const void* ctx, int64_t ctx_plane, c
  * equal; set before dinoseg_refresh_weights) makes dinoseg_forward use it instead of dinoseg_op_proj_mlp_fused.
  * vision_transformer.py:104-105, :123, :135 -> :59-65. */
 int64_t dinoseg_op_mlp4_pack_elems(int32_t D, int32_t F);
-int dinoseg_op_pack_mlp4(const float* Wproj, const float* W1, const float* b1, const float* W2, const float* gamma2, const float* beta2, int32_t D,
-                         int32_t F, int32_t fmt, void* dst, void* stream);
+int dinoseg_op_pack_mlp4(const float* Wproj, const float* W1, const float* b1, const float* W2, const float* gamma2, const float* beta2,
+                         const float* Wqkv_next, const float* bqkv_next, const float* gamma1_next, const float* beta1_next, int32_t D, int32_t F,
+                         int32_t fmt, void* dst, void* stream);
 int dinoseg_op_proj_mlp_fused4(float* X, const void* ctx, const float* bproj, float eps, const void* Wp, const float* b2, int32_t M, int32_t D,
                                int32_t F, int32_t fmt, void* stream);
+/* ... and LayerNorm1 + the qkv projection of the NEXT block at the end of the same launch (Wp packed with Wqkv_next; as
+ * dinoseg_op_block_tail_fused3 on one plane: q / k / v [B, heads, npad, 64] in the operand format, V as bf16, q pre-scaled, rows >= ntok untouched).
+ * Library option "qkv_fused4" (default 1). */
+int dinoseg_op_block_tail_fused4(float* X, const void* ctx, const float* bproj, float eps, const void* Wp, const float* b2, void* q, void* k, void* v,
+                                 int32_t B, int32_t ntok, int32_t npad, int32_t heads, float qscale, int32_t D, int32_t F, int32_t fmt,
+                                 void* stream);
 
 /* ... and with LayerNorm1 + the qkv projection of the NEXT block at its end (Block.forward of block i from `x = x + attn` on, then
  * block i+1 up to `qkv = self.qkv(self.norm1(x))`: vision_transformer.py:123, :135, :122 -> :75): after the launch X holds block i's

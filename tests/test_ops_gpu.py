@@ -770,14 +770,67 @@ def _q1(x: torch.Tensor, fp16: bool) -> torch.Tensor:
     return x.to(torch.float16 if fp16 else torch.bfloat16).float()
 
 
-def _pack_mlp4(Wpr, W1, b1, W2, gam, bet, fp16: bool) -> torch.Tensor:
+def _pack_mlp4(Wpr, W1, b1, W2, gam, bet, fp16: bool, tail=None) -> torch.Tensor:
+    """tail: (Wqkv_next, bqkv_next, gamma1_next, beta1_next) or None"""
     F_, D_ = W1.shape
     n = capi.lib().dinoseg_op_mlp4_pack_elems(D_, F_)
-    assert n == 54 * 48 * 512 + 2 * F_      # (the slots, then the folded fc1 bias as fp32)
-    out = torch.empty((n,), dtype=torch.int16, device=W1.device)
+    assert n == (54 + 18) * 48 * 512 + 2 * (F_ + 3 * D_)      # (the slots, then the folded biases as fp32)
+    out = torch.zeros((n,), dtype=torch.int16, device=W1.device)
+    t = [x.contiguous().data_ptr() for x in tail] if tail is not None else [None] * 4
     capi.check(capi.lib().dinoseg_op_pack_mlp4(None if Wpr is None else Wpr.contiguous().data_ptr(), W1.contiguous().data_ptr(), b1.data_ptr(),
-                                                W2.contiguous().data_ptr(), gam.data_ptr(), bet.data_ptr(), D_, F_, int(fp16), out.data_ptr(), S()))
+                                                W2.contiguous().data_ptr(), gam.data_ptr(), bet.data_ptr(), t[0], t[1], t[2], t[3], D_, F_, int(fp16),
+                                                out.data_ptr(), S()))
     return out
+
+
+@pytest.mark.parametrize("fp16", [True, False])
+@pytest.mark.parametrize("B,ntok", [(1, 65), (3, 130), (2, 901), (11, 3601)])
+def test_block_tail_fused_one_wave(cuda, B, ntok, fp16):
+    """mlp_fused4.hip with the qkv tail: projection + MLP of block i, then LayerNorm1 + qkv of block i + 1 in the same launch
+    (vision_transformer.py:123, :135, then :122 -> :75 / :82), one operand plane.  X must equal the launch without the tail bit for bit; Q / K / V
+    against fp64 on the operands the kernel sees ((x - mean) rstd and Wqkv diag(gamma1) rounded to the format, the folded bias), in the
+    [B, heads, npad, 64] layout with Q pre-scaled, V as bf16 and the pad rows untouched.  (11, 3601): 39 611 rows = more items than CUs, ragged."""
+    D_, F_, H = 384, 1536, 6
+    M_ = B * ntok
+    npad = (ntok + 63) // 64 * 64
+    c = _mlp3_case(M_, fp16, 470, tail=True)
+    lib = capi.lib()
+    ctx_i, _ = _one_plane(c["ctx"], fp16)
+    Wp = _pack_mlp4(c["Wpr"], c["W1"], c["b1"], c["W2"], c["gam"], c["bet"], fp16, tail=(c["Wqkv"], c["bq"], c["gam1"], c["bet1"]))
+    ref = c["X"].clone()
+    capi.check(lib.dinoseg_op_proj_mlp_fused4(ref.data_ptr(), ctx_i.data_ptr(), c["bpr"].data_ptr(), 1e-6, Wp.data_ptr(), c["b2"].data_ptr(), M_, D_, F_,
+                                              int(fp16), S()))
+    got = c["X"].clone()
+    q = torch.zeros((B, H, npad, 64), dtype=torch.int16, device="cuda")
+    k, v = torch.zeros_like(q), torch.zeros_like(q)
+    qscale = 0.125 * LOG2E
+    capi.check(lib.dinoseg_op_block_tail_fused4(got.data_ptr(), ctx_i.data_ptr(), c["bpr"].data_ptr(), 1e-6, Wp.data_ptr(), c["b2"].data_ptr(),
+                                                q.data_ptr(), k.data_ptr(), v.data_ptr(), B, ntok, npad, H, qscale, D_, F_, int(fp16), S()))
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    xo = got.double()
+    mu = xo.mean(dim=1, keepdim=True)
+    xhat = (xo - mu) / torch.sqrt(((xo - mu) ** 2).mean(dim=1, keepdim=True) + 1e-6)
+    A = _q1(xhat.float(), fp16).double()
+    z = (A @ _q1(c["Wqkv"] * c["gam1"][None, :], fp16).double().t() + (c["bq"].double() + c["Wqkv"].double() @ c["bet1"].double())).float()
+    z = z.reshape(B, ntok, 3, H, 64).permute(2, 0, 3, 1, 4)
+    dt = torch.float16 if fp16 else torch.bfloat16
+    gq, gk, gv = q.view(dt).float(), k.view(dt).float(), v.view(torch.bfloat16).float()
+    ulp = 2.0 ** -10 if fp16 else 2.0 ** -7
+    tol = lambda r, e: 3 * e * float(r.abs().max()) + 1e-4
+    eq, ek, ev = (float((g[:, :, :ntok] - r).abs().max()) for g, r in ((gq, z[0] * qscale), (gk, z[1]), (gv, z[2])))
+    print(f"tail4 B={B} ntok={ntok} fp16={fp16}: dq {eq:.2e} dk {ek:.2e} dv {ev:.2e}")
+    assert eq <= tol(z[0] * qscale, ulp) and ek <= tol(z[1], ulp) and ev <= tol(z[2], 2.0 ** -7)
+    assert float(gk.abs().max()) > 0.5
+    for t in (q, k, v):
+        assert torch.all(t[:, :, ntok:] == 0)
+    # bit-repeatable
+    q2, k2, v2 = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
+    again = c["X"].clone()
+    capi.check(lib.dinoseg_op_block_tail_fused4(again.data_ptr(), ctx_i.data_ptr(), c["bpr"].data_ptr(), 1e-6, Wp.data_ptr(), c["b2"].data_ptr(),
+                                                q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), B, ntok, npad, H, qscale, D_, F_, int(fp16), S()))
+    torch.cuda.synchronize()
+    assert torch.equal(again, got) and torch.equal(q2, q) and torch.equal(k2, k) and torch.equal(v2, v)
 
 
 @pytest.mark.parametrize("fp16", [True, False])

@@ -27,7 +27,9 @@ lib = capi.lib()
 S = capi.stream_ptr
 capi.check(lib.dinoseg_set_option(b"op_fmt", fp16))
 Wp4 = torch.zeros((lib.dinoseg_op_mlp4_pack_elems(D, F),), dtype=torch.int16, device="cuda")
-capi.check(lib.dinoseg_op_pack_mlp4(Wpr.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), gam.data_ptr(), bet.data_ptr(), D, F, fp16, Wp4.data_ptr(), S()))
+Wq, bq = seeded((3 * D, D), 11) * 0.05, seeded((3 * D,), 12) * 0.1
+capi.check(lib.dinoseg_op_pack_mlp4(Wpr.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), gam.data_ptr(), bet.data_ptr(), Wq.data_ptr(), bq.data_ptr(),
+                                    gam.data_ptr(), bet.data_ptr(), D, F, fp16, Wp4.data_ptr(), S()))
 Wp2 = torch.zeros((lib.dinoseg_op_mlp_fused_pack_elems(D, F),), dtype=torch.int16, device="cuda")
 capi.check(lib.dinoseg_op_pack_mlp(W1.data_ptr(), W2.data_ptr(), D, F, Wp2.data_ptr(), S()))
 Wpr2 = torch.zeros((lib.dinoseg_op_proj_pack_elems(D),), dtype=torch.int16, device="cuda")
