@@ -158,7 +158,16 @@ for (Bq, ntok, fp16) in [(32, 3601, True), (11, 3601, False), (3, 130, True), (1
         capi.check(lib.dinoseg_op_proj_mlp_fused4(x4.data_ptr(), ctx1.data_ptr(), c["bpr"].data_ptr(), 1e-6, Wp4.data_ptr(), c["b2"].data_ptr(), M_, D_,
                                                   F_, int(fp16), S()))
     screen(f"mlp_fused4 B={Bq} N={ntok} fp16={fp16}", run4, lambda: [x4])
-    del c, ctx_pl, x3, q3, k3, v3, x4, Wp4
+    Wp4t = T._pack_mlp4(c["Wpr"], c["W1"], c["b1"], c["W2"], c["gam"], c["bet"], fp16, tail=(c["Wqkv"], c["bq"], c["gam1"], c["bet1"]))
+    q4 = torch.zeros((Bq, H_, npad, 64), dtype=torch.int16, device="cuda")
+    k4, v4 = torch.zeros_like(q4), torch.zeros_like(q4)
+
+    def run4t():
+        x4.copy_(c["X"])
+        capi.check(lib.dinoseg_op_block_tail_fused4(x4.data_ptr(), ctx1.data_ptr(), c["bpr"].data_ptr(), 1e-6, Wp4t.data_ptr(), c["b2"].data_ptr(),
+                                                    q4.data_ptr(), k4.data_ptr(), v4.data_ptr(), Bq, ntok, npad, H_, 0.125 * LOG2E, D_, F_, int(fp16), S()))
+    screen(f"mlp_fused4 + qkv tail B={Bq} N={ntok} fp16={fp16}", run4t, lambda: [x4, q4, k4, v4])
+    del c, ctx_pl, x3, q3, k3, v3, x4, Wp4, Wp4t, q4, k4, v4
 
 for (M_, fp16) in [(57616, True), (24001, False), (300, True)]:
     capi.check(lib.dinoseg_set_option(b"op_fmt", int(fp16)))
